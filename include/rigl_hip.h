@@ -1,0 +1,239 @@
+/* rigl_hip.h -- C ABI of the MI355X (gfx950) RigL hot path.
+ *
+ * The reference (google-research/rigl) has no native code and no FFI: its hot
+ * path sits behind Python signatures and runs inside TensorFlow ops.  This
+ * header is the boundary a maintainer binds INSTEAD of those TF ops; every
+ * entry point cites the reference call site it replaces.  Rules:
+ *   - plain C, `extern "C"`, no torch / C++ types in any signature;
+ *   - the caller owns every buffer and passes raw DEVICE pointers + sizes and
+ *     the hipStream_t to enqueue on (as void*); nothing is allocated inside,
+ *     scratch comes from a caller-provided workspace (`*_workspace_bytes`);
+ *   - every call only ENQUEUES work on `stream` (no hidden synchronisation);
+ *   - return 0 on success, a negative RIGL_E* code otherwise; the message for
+ *     the calling thread is available from rigl_last_error(); never throws;
+ *   - re-entrant: no mutable global state besides the loaded code object.
+ *
+ * Layout conventions (the reference's):
+ *   activations  NHWC, bf16 (raw uint16 bit patterns)
+ *   weights      HWIO  [kh][kw][cin][cout] fp32 master copy (FC: [in][out]);
+ *                flat index = C order -- this is the index space in which the
+ *                masks, the top-k tie-break ("lower index first") and the
+ *                golden vectors are defined
+ *   mask         1 bit / weight, bit (i & 31) of uint32 word (i >> 5), i = flat
+ *                HWIO index; bits at positions >= n in the last word are 0
+ */
+#ifndef RIGL_HIP_H_
+#define RIGL_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RIGL_ABI_VERSION 1
+
+typedef void* rigl_stream_t; /* hipStream_t */
+typedef uint16_t rigl_bf16;  /* raw bfloat16 bits */
+
+enum {
+  RIGL_OK = 0,
+  RIGL_EINVAL = -1,       /* bad argument (NULL, negative size, misaligned) */
+  RIGL_ELAUNCH = -2,      /* HIP runtime / launch failure */
+  RIGL_EWORKSPACE = -3,   /* workspace too small */
+  RIGL_EUNSUPPORTED = -4  /* shape / mode not supported by this build */
+};
+
+int rigl_version(void);
+/* Message of the last failing call made by THIS thread ("" if none). */
+const char* rigl_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Mask bitmap <-> 0/1 float mask.
+ * Replaces: the fp32 `mask` variable of tf.contrib.model_pruning
+ * (registered by layers.masked_conv2d, rigl/imagenet_resnet/pruning_layers.py
+ * :139-157) -- the bitmap is the HBM-resident form, the float form exists
+ * only at the API surface (get_masks()).
+ * ---------------------------------------------------------------------- */
+int rigl_mask_pack(const float* mask01, uint32_t* bits, int64_t n,
+                   rigl_stream_t stream);
+int rigl_mask_unpack(const uint32_t* bits, float* mask01, int64_t n,
+                     rigl_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K2: fused magnitude-prune / gradient-regrow mask update.
+ * Replaces: SparseRigLOptimizerBase.generic_mask_update
+ *   (rigl/sparse_optimizers_base.py:523-538) + _get_update_op (:276-343)
+ *   + get_grow_tensor (:355-400, :540-553) + reset_momentum (:555-564), i.e.
+ *   the two full-length nn_ops.top_k sorts, two scatter_nd, where/assign.
+ * Also serves SET / Static / Momentum (sparse_optimizers.py:109-214) through
+ * the explicit-score pointers.
+ *
+ * Result (bit-exact with the reference semantics on identical inputs):
+ *   n_ones  = popcount(mask);  n_prune = (int32)((float)n_ones * drop_fraction)
+ *   n_keep  = n_ones - n_prune
+ *   mask1   = the n_keep entries with the largest drop score, equal scores
+ *             resolved by LOWER flat index first (tf.nn.top_k order)
+ *   lifted  = mask1 ? (min(grow score) - 1) : grow score
+ *   mask2   = the n_prune entries with the largest lifted score (same ties)
+ *   new     = mask2 & (reinit_when_same ? 1 : ~mask_old)
+ *   w[new]  = grow value;  momentum[new] = reset value;  mask = mask1 | mask2
+ * drop score = |mask*w| (+ drop_noise[i], one fp32 add) unless score_drop is
+ * given; grow score = |dense_grad| unless score_grow is given.
+ * ---------------------------------------------------------------------- */
+typedef struct RiglPruneRegrowLayer {
+  int64_t n;               /* number of weights in this tensor (< 2^31)     */
+  float* w;                /* in/out fp32 [n]                                */
+  float* momentum;         /* in/out fp32 [n], NULL = no slot                */
+  uint32_t* mask_bits;     /* in/out ceil(n/32) words                        */
+  const float* dense_grad; /* fp32 [n] dense dL/d(mask*W); may be NULL only  */
+                           /* if score_grow is given and modes need no grad  */
+  const float* drop_noise; /* fp32 [n] or NULL (noise_std = 0)               */
+  const float* score_drop; /* fp32 [n] or NULL: explicit drop scores         */
+  const float* score_grow; /* fp32 [n] or NULL: explicit grow scores         */
+  const float* grow_values;/* fp32 [n] or NULL: explicit grown-weight values */
+} RiglPruneRegrowLayer;
+
+enum {
+  RIGL_GROW_ZEROS = 0,      /* grow_init='zeros'          (:372-373)         */
+  RIGL_GROW_GRAD_SCALE = 1, /* 'grad_scale_d': g / d      (:542-545)         */
+  RIGL_GROW_GRAD_SIGN = 2,  /* 'grad_sign_d': sign(g) / d (:546-549)         */
+  RIGL_GROW_EXPLICIT = 3    /* values from grow_values    (random_* / initial_dist_* drawn by the host) */
+};
+enum {
+  RIGL_MOMRESET_ZEROS = 0,  /* SET: zeros                 (:345-353)         */
+  RIGL_MOMRESET_GRAD = 1    /* RigL: dense_grad * initial_acc_scale (:555-564) */
+};
+
+typedef struct RiglPruneRegrowParams {
+  float drop_fraction;
+  int32_t grow_init_mode;
+  float grow_init_div;
+  int32_t momentum_reset_mode;
+  float initial_acc_scale;
+  int32_t reinit_when_same;
+} RiglPruneRegrowParams;
+
+#define RIGL_COUNTS_PER_LAYER 8
+/* out_counts[l*8 + ..]: 0 n_ones, 1 n_prune, 2 n_keep, 3 n_new_connections,
+ * 4 overlap (!=0 <=> the reference's Assert(mask1*mask2==0) would fire),
+ * 5 ties admitted at the drop threshold, 6 ties admitted at the grow
+ * threshold, 7 popcount of the new mask.                                   */
+size_t rigl_prune_regrow_workspace_bytes(const int64_t* n_per_layer,
+                                         int32_t n_layers);
+int rigl_prune_regrow(const RiglPruneRegrowLayer* layers /* host */,
+                      int32_t n_layers, const RiglPruneRegrowParams* params,
+                      int32_t* out_counts /* device, 8*n_layers, nullable */,
+                      void* workspace /* device */, size_t workspace_bytes,
+                      rigl_stream_t stream);
+
+/* One-shot "keep the k best" mask (SNIP / DNW, sparse_optimizers.py:287-317,
+ * :430-460): mask = the n_keep entries of score with the largest value, ties
+ * by lower index.  Uses the same selection kernels as rigl_prune_regrow.    */
+int rigl_topk_mask(const float* score, int64_t n, int64_t n_keep,
+                   uint32_t* mask_bits, void* workspace,
+                   size_t workspace_bytes, rigl_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K3: masked fused SGD / momentum update (+ bf16 shadow of mask*W).
+ * Replaces: the TF ApplyMomentum / ApplyGradientDescent kernels behind
+ *   tf.train.MomentumOptimizer(lr, momentum, use_nesterov=True)
+ *   (rigl/imagenet_resnet/imagenet_train_eval.py:360-361,
+ *    rigl/cifar_resnet/resnet_train_eval.py:202-203) together with the
+ *   `mask *` of the masked-weight gradient and the l2_regularizer gradient:
+ *     g  = (mask ? grad_scale*dense_grad : 0) + weight_decay * w
+ *     a  = momentum*a + g
+ *     w -= lr*g + lr*momentum*a   (nesterov)   |   w -= lr*a   (plain)
+ *   every product / sum rounded to fp32 separately (no FMA contraction), so
+ *   the result is bit-identical to the oracle.
+ * mask_bits == NULL means "all ones" (dense tensors: BN, biases, dense stem).
+ * momentum == NULL means plain gradient descent (w -= lr*g).
+ * w_shadow (nullable) receives bf16(mask ? w_new : 0), same flat order.
+ * ---------------------------------------------------------------------- */
+int rigl_masked_sgd_momentum(int64_t n, float* w, float* momentum,
+                             const float* dense_grad, const uint32_t* mask_bits,
+                             float lr, float mu, float weight_decay,
+                             float grad_scale, int32_t nesterov,
+                             rigl_bf16* w_shadow, rigl_stream_t stream);
+
+/* bf16 shadows of mask*W for the conv kernels:  hwio[i] = bf16(mask_i?w_i:0)
+ * in flat HWIO order (dgrad operand) and ohwi = the [cout][kh*kw*cin]
+ * transpose (fwd operand).  Either output may be NULL.  k = kh*kw*cin.      */
+int rigl_pack_weights(const float* w, const uint32_t* mask_bits /* nullable */,
+                      int32_t k, int32_t cout, rigl_bf16* hwio, rigl_bf16* ohwi,
+                      rigl_stream_t stream);
+/* The same for a whole model in one launch per 64 tensors (`layers` is a host
+ * array; it is consumed before the call returns).                          */
+typedef struct RiglPackLayer {
+  const float* w;
+  const uint32_t* mask_bits; /* nullable */
+  rigl_bf16* hwio;           /* nullable */
+  rigl_bf16* ohwi;           /* nullable */
+  int32_t k, cout;
+} RiglPackLayer;
+int rigl_pack_weights_batched(const RiglPackLayer* layers, int32_t n_layers,
+                              rigl_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K1: masked convolution as an implicit GEMM on MFMA (bf16 in, fp32
+ * accumulate).  Replaces: layers.masked_conv2d / masked_fully_connected
+ *   (rigl/imagenet_resnet/pruning_layers.py:139-157, :222-233), i.e.
+ *   y = conv2d(x, mask*W), and their TF autodiff:
+ *   dx = conv2d_backprop_input(dy, mask*W),
+ *   dW_dense = conv2d_backprop_filter(x, dy)   (dense: RigL's grow score,
+ *   rigl/sparse_optimizers_base.py:478-485).
+ * The weight operand is the packed bf16 shadow of mask*W (rigl_pack_weights),
+ * so the mask costs no bandwidth inside the conv.
+ * Padding is explicit (pad_top/left; bottom/right implied by out size), which
+ * covers TF 'SAME' (incl. its asymmetric stride-2 case), 'VALID' and the
+ * reference's fixed_padding (resnet_model.py:85-106).  FC = 1x1 conv, H=W=1.
+ * ---------------------------------------------------------------------- */
+typedef struct RiglConvDesc {
+  int32_t n, h, w, cin;      /* input  NHWC  */
+  int32_t ho, wo, cout;      /* output NHWC  */
+  int32_t kh, kw;
+  int32_t stride_h, stride_w;
+  int32_t pad_top, pad_left;
+} RiglConvDesc;
+
+size_t rigl_conv2d_workspace_bytes(const RiglConvDesc* d, int32_t which /*0 fwd,1 dgrad,2 wgrad*/);
+int rigl_masked_conv2d_fwd(const RiglConvDesc* d, const rigl_bf16* x,
+                           const rigl_bf16* w_ohwi, rigl_bf16* y,
+                           void* workspace, size_t workspace_bytes,
+                           rigl_stream_t stream);
+int rigl_masked_conv2d_dgrad(const RiglConvDesc* d, const rigl_bf16* dy,
+                             const rigl_bf16* w_hwio, rigl_bf16* dx,
+                             void* workspace, size_t workspace_bytes,
+                             rigl_stream_t stream);
+/* dw: fp32 [kh][kw][cin][cout], DENSE (overwritten, not accumulated).       */
+int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x,
+                             const rigl_bf16* dy, float* dw, void* workspace,
+                             size_t workspace_bytes, rigl_stream_t stream);
+
+/* Direct (non-MFMA) kernels, same operand layouts, any channel count: taken
+ * for shapes the MFMA path reports RIGL_EUNSUPPORTED for (cin/cout not a
+ * multiple of 8 -- MNIST MLP 784-300-100-10, 10-class logits) and used as an
+ * independent on-device cross-check.                                        */
+int rigl_conv2d_fwd_ref(const RiglConvDesc* d, const rigl_bf16* x,
+                        const rigl_bf16* w_ohwi, rigl_bf16* y,
+                        rigl_stream_t stream);
+int rigl_conv2d_dgrad_ref(const RiglConvDesc* d, const rigl_bf16* dy,
+                          const rigl_bf16* w_hwio, rigl_bf16* dx,
+                          rigl_stream_t stream);
+int rigl_conv2d_wgrad_ref(const RiglConvDesc* d, const rigl_bf16* x,
+                          const rigl_bf16* dy, float* dw, rigl_stream_t stream);
+
+/* Optional per-kernel timing (HIP events recorded on the launch stream around
+ * every K1/K2/K3 launch while enabled).  rigl_prof_collect synchronises the
+ * recorded events and returns accumulated milliseconds / launch counts per
+ * kernel family: 0 conv_fwd, 1 conv_dgrad, 2 conv_wgrad, 3 prune_regrow,
+ * 4 sgd_momentum, 5 pack_weights.                                           */
+#define RIGL_PROF_KINDS 6
+int rigl_prof_enable(int32_t on);
+int rigl_prof_collect(double* ms_per_kind /*[6]*/, int64_t* launches /*[6]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIGL_HIP_H_ */

@@ -1,0 +1,119 @@
+"""ctypes binding of the C ABI in ``include/rigl_hip.h`` (librigl_hip.so).
+
+There is NO fallback: if the library is missing or a call fails, this module
+raises.  The product never computes the hot path any other way.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'librigl_hip.so')
+
+RIGL_OK = 0
+RIGL_EINVAL = -1
+RIGL_ELAUNCH = -2
+RIGL_EWORKSPACE = -3
+RIGL_EUNSUPPORTED = -4
+COUNTS_PER_LAYER = 8
+PROF_KINDS = ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'prune_regrow',
+              'sgd_momentum', 'pack_weights')
+
+GROW_ZEROS, GROW_GRAD_SCALE, GROW_GRAD_SIGN, GROW_EXPLICIT = 0, 1, 2, 3
+MOMRESET_ZEROS, MOMRESET_GRAD = 0, 1
+
+
+class RiglError(RuntimeError):
+
+  def __init__(self, code, msg):
+    super().__init__('librigl_hip: error %d: %s' % (code, msg))
+    self.code = code
+
+
+class PruneRegrowLayer(C.Structure):
+  _fields_ = [('n', C.c_int64), ('w', C.c_void_p), ('momentum', C.c_void_p),
+              ('mask_bits', C.c_void_p), ('dense_grad', C.c_void_p),
+              ('drop_noise', C.c_void_p), ('score_drop', C.c_void_p),
+              ('score_grow', C.c_void_p), ('grow_values', C.c_void_p)]
+
+
+class PruneRegrowParams(C.Structure):
+  _fields_ = [('drop_fraction', C.c_float), ('grow_init_mode', C.c_int32),
+              ('grow_init_div', C.c_float), ('momentum_reset_mode', C.c_int32),
+              ('initial_acc_scale', C.c_float), ('reinit_when_same', C.c_int32)]
+
+
+class PackLayer(C.Structure):
+  _fields_ = [('w', C.c_void_p), ('mask_bits', C.c_void_p),
+              ('hwio', C.c_void_p), ('ohwi', C.c_void_p), ('k', C.c_int32),
+              ('cout', C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+  _fields_ = [('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32),
+              ('cin', C.c_int32), ('ho', C.c_int32), ('wo', C.c_int32),
+              ('cout', C.c_int32), ('kh', C.c_int32), ('kw', C.c_int32),
+              ('stride_h', C.c_int32), ('stride_w', C.c_int32),
+              ('pad_top', C.c_int32), ('pad_left', C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/rigl_hip.h
+_P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+SIGNATURES = {
+    'rigl_version': (C.c_int, []),
+    'rigl_last_error': (C.c_char_p, []),
+    'rigl_mask_pack': (C.c_int, [_P, _P, _I64, _P]),
+    'rigl_mask_unpack': (C.c_int, [_P, _P, _I64, _P]),
+    'rigl_prune_regrow_workspace_bytes': (_SZ, [C.POINTER(_I64), _I32]),
+    'rigl_prune_regrow': (C.c_int, [C.POINTER(PruneRegrowLayer), _I32,
+                                    C.POINTER(PruneRegrowParams), _P, _P, _SZ,
+                                    _P]),
+    'rigl_topk_mask': (C.c_int, [_P, _I64, _I64, _P, _P, _SZ, _P]),
+    'rigl_masked_sgd_momentum': (C.c_int, [_I64, _P, _P, _P, _P, _F, _F, _F, _F,
+                                           _I32, _P, _P]),
+    'rigl_pack_weights': (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P]),
+    'rigl_pack_weights_batched': (C.c_int, [C.POINTER(PackLayer), _I32, _P]),
+    'rigl_conv2d_workspace_bytes': (_SZ, [C.POINTER(ConvDesc), _I32]),
+    'rigl_masked_conv2d_fwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P,
+                                         _SZ, _P]),
+    'rigl_masked_conv2d_dgrad': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P,
+                                           _SZ, _P]),
+    'rigl_masked_conv2d_wgrad': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P,
+                                           _SZ, _P]),
+    'rigl_conv2d_fwd_ref': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    'rigl_conv2d_dgrad_ref': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    'rigl_conv2d_wgrad_ref': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    'rigl_prof_enable': (C.c_int, [_I32]),
+    'rigl_prof_collect': (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64)]),
+}
+
+_lib = None
+
+
+def load():
+  """Loads librigl_hip.so (after torch, so both share one HIP runtime)."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise RiglError(
+        RIGL_ELAUNCH, 'HIP extension not built: %s is missing; run '
+        '`python -c "import __graft_entry__ as g; g.build()"` or '
+        '`make -C rigl_amd/csrc`' % LIB_PATH)
+  try:
+    import torch  # noqa: F401  pylint: disable=unused-import,import-outside-toplevel
+  except ImportError:
+    pass
+  lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+  for name, (res, args) in SIGNATURES.items():
+    fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+    fn.restype = res
+    fn.argtypes = args
+  if lib.rigl_version() != 1:
+    raise RiglError(RIGL_EINVAL, 'ABI version mismatch')
+  _lib = lib
+  return lib
+
+
+def check(rc):
+  if rc != RIGL_OK:
+    raise RiglError(rc, load().rigl_last_error().decode('utf-8', 'replace'))

@@ -1,0 +1,637 @@
+// K1: masked convolution (fwd / dgrad / wgrad) as implicit GEMM on the gfx950
+// matrix cores: bf16 operands, fp32 accumulation, v_mfma_f32_32x32x16_bf16.
+//
+//   fwd    Y [M=N*Ho*Wo][Cout]  = im2col(X)[M][kh*kw*Cin]  x  W_ohwi[Cout][kh*kw*Cin]^T
+//   dgrad  dX[M=N*H*W ][Cin ]  = gather(dY)[M][kh*kw*Cout] x  W_hwio[(tap,ci)][Cout]^T
+//   wgrad  dW[tap][Cin][Cout]  = sum_m X^T[Cin][m] x dY^T[Cout][m]^T      (dense, fp32)
+//
+// The im2col matrix is never materialised: each K-tile is one filter tap and
+// one block of channels, gathered straight from the NHWC activation (zero
+// filled outside the image) into an XOR-swizzled LDS tile.  The weight operand
+// is the pre-packed bf16 shadow of mask*W (rigl_pack_weights), so the 1-bit
+// mask costs no bandwidth here.  Workgroup = 256 threads = 4 waves (2x2), each
+// wave owns TMxTN 32x32 MFMA tiles (block tile 64*TM x 64*TN), K-tile BK,
+// double-buffered LDS with register staging (next tile's global loads are in
+// flight while the current tile is multiplied), one barrier per K-tile.
+#include "common.hpp"
+
+namespace rigl {
+namespace k1 {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int THREADS = 256;
+
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// Byte offset of 16-byte chunk `chunk` of row `row` in a [rows][BK] bf16 tile.
+// The chunk index is XORed with a row-derived value so that the 16-lane groups
+// of ds_read_b128 (rows r..r+3, r+12.., r+20..) hit 16 distinct 16-B slots.
+template <int BK>
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  constexpr int CPR = BK / 8;
+  constexpr int SH = (CPR == 8) ? 1 : (CPR == 4 ? 2 : 3);
+  return row * (BK * 2) + (((chunk ^ (row >> SH)) & (CPR - 1)) << 4);
+}
+
+// XCD-aware, bijective block remap: consecutive logical tiles land on the same
+// XCD (hardware dispatches block b to XCD b % 8), so tiles that share operand
+// panels share an L2.  Speed only -- results never depend on placement.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
+  const uint32_t q = nblk >> 3, r = nblk & 7u, x = bid & 7u, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+__device__ __forceinline__ uint32_t dword_of(const uint4& v, int d) {
+  return d == 0 ? v.x : (d == 1 ? v.y : (d == 2 ? v.z : v.w));
+}
+
+struct IgemmArgs {
+  const uint16_t* A;   // gathered activation tensor (x for fwd, dy for dgrad), NHWC
+  const uint16_t* B;   // packed weights
+  void* C;             // output rows
+  int M, N, Cred;      // GEMM rows, columns, reduction channels per tap
+  int KH, KW;
+  int RH, RW;          // spatial size of the row space (ho,wo | h,w)
+  int GH, GW;          // spatial size of the gathered tensor
+  int sh, sw, ph, pw;
+  int b_row_stride, b_tap_stride;
+  int ldc;
+  int tiles_n;
+};
+
+template <int TM, int TN, int BK, int MODE /*0 fwd, 1 dgrad*/, bool OUT_F32>
+__global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, CPR = BK / 8, RPP = THREADS / CPR;
+  constexpr int APASS = (BM + RPP - 1) / RPP, BPASS = (BN + RPP - 1) / RPP;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int CS_LD = BN + 8;
+  constexpr int EPI = OUT_F32 ? 0 : BM * CS_LD * 2;
+  constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (int)(tile / (uint32_t)P.tiles_n) * BM, n0 = (int)(tile % (uint32_t)P.tiles_n) * BN;
+  const int lrow = tid / CPR, lchunk = tid % CPR;
+
+  // ---- per-thread gather rows (fixed for the whole K loop) ------------------
+  int a_pix[APASS], a_c0[APASS], a_c1[APASS];
+  bool a_ok[APASS];
+#pragma unroll
+  for (int p = 0; p < APASS; ++p) {
+    const int row = p * RPP + lrow, m = m0 + row;
+    a_ok[p] = row < BM && m < P.M;
+    const int mm = a_ok[p] ? m : 0;
+    const int rw = mm % P.RW, t = mm / P.RW, rh = t % P.RH, n = t / P.RH;
+    a_pix[p] = n * P.GH * P.GW;
+    if (MODE == 0) { a_c0[p] = rh * P.sh - P.ph; a_c1[p] = rw * P.sw - P.pw; }
+    else { a_c0[p] = rh + P.ph; a_c1[p] = rw + P.pw; }
+  }
+  int b_off[BPASS];
+  bool b_ok[BPASS];
+#pragma unroll
+  for (int p = 0; p < BPASS; ++p) {
+    const int row = p * RPP + lrow, nn = n0 + row;
+    b_ok[p] = row < BN && nn < P.N;
+    b_off[p] = (b_ok[p] ? nn : 0) * P.b_row_stride;
+  }
+
+  const int kc_tiles = (P.Cred + BK - 1) / BK;
+  const int KT = P.KH * P.KW * kc_tiles;
+  uint4 ra[APASS], rb[BPASS];
+
+  // (macros, not lambdas: by-reference lambda captures of the staging arrays
+  //  kept them in scratch memory instead of registers)
+#define RIGL_LOAD_TILE(r_, s_, cb_)                                                                   \
+  {                                                                                                   \
+    const int cofs = (cb_) * BK + lchunk * 8;                                                         \
+    const bool c_ok = cofs < P.Cred;                                                                  \
+    _Pragma("unroll") for (int p = 0; p < APASS; ++p) {                                               \
+      bool ok = a_ok[p] && c_ok;                                                                      \
+      int gh, gw;                                                                                     \
+      if (MODE == 0) {                                                                                \
+        gh = a_c0[p] + (r_); gw = a_c1[p] + (s_);                                                     \
+      } else {                                                                                        \
+        int th = a_c0[p] - (r_), tw = a_c1[p] - (s_);                                                 \
+        ok = ok && th >= 0 && tw >= 0;                                                                \
+        if (P.sh == 1) gh = th; else { gh = th / P.sh; ok = ok && (th - gh * P.sh) == 0; }            \
+        if (P.sw == 1) gw = tw; else { gw = tw / P.sw; ok = ok && (tw - gw * P.sw) == 0; }            \
+      }                                                                                               \
+      ok = ok && (unsigned)gh < (unsigned)P.GH && (unsigned)gw < (unsigned)P.GW;                      \
+      const int off = (a_pix[p] + gh * P.GW + gw) * P.Cred + cofs;                                    \
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);                                                           \
+      if (ok) v = *reinterpret_cast<const uint4*>(P.A + off);                                         \
+      ra[p] = v;                                                                                      \
+    }                                                                                                 \
+    const int tap = (r_) * P.KW + (s_);                                                               \
+    _Pragma("unroll") for (int p = 0; p < BPASS; ++p) {                                               \
+      const int off = b_off[p] + tap * P.b_tap_stride + cofs;                                         \
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);                                                           \
+      if (b_ok[p] && c_ok) v = *reinterpret_cast<const uint4*>(P.B + off);                            \
+      rb[p] = v;                                                                                      \
+    }                                                                                                 \
+  }
+#define RIGL_STORE_TILE(buf_)                                                                         \
+  {                                                                                                   \
+    unsigned char* As_ = smem + (buf_) * STAGE;                                                       \
+    unsigned char* Bs_ = As_ + A_BYTES;                                                               \
+    _Pragma("unroll") for (int p = 0; p < APASS; ++p) {                                               \
+      const int row = p * RPP + lrow;                                                                 \
+      if (row < BM) *reinterpret_cast<uint4*>(As_ + lds_off<BK>(row, lchunk)) = ra[p];                \
+    }                                                                                                 \
+    _Pragma("unroll") for (int p = 0; p < BPASS; ++p) {                                               \
+      const int row = p * RPP + lrow;                                                                 \
+      if (row < BN) *reinterpret_cast<uint4*>(Bs_ + lds_off<BK>(row, lchunk)) = rb[p];                \
+    }                                                                                                 \
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // ---- main loop ------------------------------------------------------------
+  int r = 0, s = 0, cb = 0;
+#define RIGL_ADVANCE() { if (++cb == kc_tiles) { cb = 0; if (++s == P.KW) { s = 0; ++r; } } }
+  RIGL_LOAD_TILE(r, s, cb);
+  RIGL_STORE_TILE(0);
+  RIGL_ADVANCE();
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < KT;
+    if (more) { RIGL_LOAD_TILE(r, s, cb); RIGL_ADVANCE(); }
+    const unsigned char* As = smem + buf * STAGE;
+    const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int chunk = ks * 2 + (lane >> 5);
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off<BK>(wm * 32 * TM + i * 32 + (lane & 31), chunk));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<BK>(wn * 32 * TN + j * 32 + (lane & 31), chunk));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) RIGL_STORE_TILE(buf ^ 1);
+    __syncthreads();
+  }
+#undef RIGL_LOAD_TILE
+#undef RIGL_STORE_TILE
+#undef RIGL_ADVANCE
+
+  // ---- epilogue -------------------------------------------------------------
+  // C/D layout of 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+  if (OUT_F32) {
+    float* C = static_cast<float*>(P.C);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          const int n = n0 + wn * 32 * TN + j * 32 + (lane & 31);
+          if (m < P.M && n < P.N) C[(int64_t)m * P.ldc + n] = acc[i][j][e];
+        }
+  } else {
+    uint16_t* Cs = reinterpret_cast<uint16_t*>(smem);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          const int col = wn * 32 * TN + j * 32 + (lane & 31);
+          Cs[row * CS_LD + col] = f2bf(acc[i][j][e]);
+        }
+    __syncthreads();
+    uint16_t* C = static_cast<uint16_t*>(P.C);
+    constexpr int CH = BN / 8;
+    for (int idx = tid; idx < BM * CH; idx += THREADS) {
+      const int row = idx / CH, ch = idx % CH;
+      const int m = m0 + row, n = n0 + ch * 8;
+      if (m < P.M && n < P.N)
+        *reinterpret_cast<uint4*>(C + (int64_t)m * P.ldc + n) = *reinterpret_cast<const uint4*>(Cs + row * CS_LD + ch * 8);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ wgrad
+struct WgradArgs {
+  const uint16_t* X;   // NHWC input activations
+  const uint16_t* DY;  // NHWC output gradients
+  float* OUT;          // [splits][KH*KW][Cin][Cout] partial slabs (or dw itself when splits == 1)
+  int M;               // N*Ho*Wo pixels (reduction length)
+  int Cin, Cout;
+  int KH, KW;
+  int H, W, Ho, Wo;
+  int sh, sw, ph, pw;
+  int tiles_ci, tiles_co;
+  int splits;
+  int64_t slab_elems;  // KH*KW*Cin*Cout
+};
+
+template <int TM, int TN>
+__global__ __launch_bounds__(THREADS) void k_wgrad(WgradArgs P) {
+  constexpr int BK = 64;  // pixels per K-tile
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_BLOCKS = (BM / 8) * 8, B_BLOCKS = (BN / 8) * 8;  // 8x8 transposition blocks
+  constexpr int NPASS = (A_BLOCKS + B_BLOCKS + THREADS - 1) / THREADS;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // block -> (split, tap, tile_ci, tile_co); co fastest so neighbours share X
+  uint32_t b = xcd_remap(blockIdx.x, gridDim.x);
+  const int tco = b % P.tiles_co; b /= P.tiles_co;
+  const int tci = b % P.tiles_ci; b /= P.tiles_ci;
+  const int tap = b % (P.KH * P.KW);
+  const int split = b / (P.KH * P.KW);
+  const int r = tap / P.KW, s = tap % P.KW;
+  const int ci0 = tci * BM, co0 = tco * BN;
+  const int KT_all = (P.M + BK - 1) / BK;
+  const int kt_begin = (int)((int64_t)KT_all * split / P.splits);
+  const int kt_end = (int)((int64_t)KT_all * (split + 1) / P.splits);
+  const bool direct = P.KH == 1 && P.KW == 1 && P.sh == 1 && P.sw == 1 && P.ph == 0 && P.pw == 0;
+
+  uint4 rg[NPASS][8];
+
+  // Each thread owns 8x8 blocks: 8 consecutive pixels x one 8-channel chunk.
+  // (macros rather than lambdas so that rg[][] stays in registers)
+#define RIGL_W_LOAD(kt_)                                                                              \
+  {                                                                                                   \
+    const int mbase = (kt_) * BK;                                                                     \
+    _Pragma("unroll") for (int q = 0; q < NPASS; ++q) {                                               \
+      const int blk = q * THREADS + tid;                                                              \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) rg[q][i] = make_uint4(0u, 0u, 0u, 0u);            \
+      if (blk < A_BLOCKS) {                                                                           \
+        const int cc = blk % (BM / 8), pg = blk / (BM / 8);                                           \
+        const int ch = ci0 + cc * 8;                                                                  \
+        const bool c_ok = ch < P.Cin;                                                                 \
+        const int m = mbase + pg * 8;                                                                 \
+        if (direct) {                                                                                 \
+          _Pragma("unroll") for (int i = 0; i < 8; ++i)                                               \
+            if (c_ok && m + i < P.M)                                                                  \
+              rg[q][i] = *reinterpret_cast<const uint4*>(P.X + (int64_t)(m + i) * P.Cin + ch);        \
+        } else {                                                                                      \
+          int wo = m % P.Wo, t = m / P.Wo, ho = t % P.Ho, n = t / P.Ho;                               \
+          _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                             \
+            const int hi = ho * P.sh - P.ph + r, wi = wo * P.sw - P.pw + s;                           \
+            if (c_ok && (m + i) < P.M && (unsigned)hi < (unsigned)P.H && (unsigned)wi < (unsigned)P.W) \
+              rg[q][i] = *reinterpret_cast<const uint4*>(P.X + ((int64_t)(n * P.H + hi) * P.W + wi) * P.Cin + ch); \
+            if (++wo == P.Wo) { wo = 0; if (++ho == P.Ho) { ho = 0; ++n; } }                          \
+          }                                                                                           \
+        }                                                                                             \
+      } else if (blk < A_BLOCKS + B_BLOCKS) {                                                         \
+        const int bb = blk - A_BLOCKS;                                                                \
+        const int cc = bb % (BN / 8), pg = bb / (BN / 8);                                             \
+        const int ch = co0 + cc * 8;                                                                  \
+        const bool c_ok = ch < P.Cout;                                                                \
+        const int m = mbase + pg * 8;                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                 \
+          if (c_ok && m + i < P.M)                                                                    \
+            rg[q][i] = *reinterpret_cast<const uint4*>(P.DY + (int64_t)(m + i) * P.Cout + ch);        \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+  // 8x8 bf16 transpose in registers, then 8 x 16-byte LDS stores ([channel][pixel] tile).
+#define RIGL_W_STORE(buf_)                                                                            \
+  {                                                                                                   \
+    unsigned char* As_ = smem + (buf_) * STAGE;                                                       \
+    unsigned char* Bs_ = As_ + A_BYTES;                                                               \
+    _Pragma("unroll") for (int q = 0; q < NPASS; ++q) {                                               \
+      const int blk = q * THREADS + tid;                                                              \
+      if (blk < A_BLOCKS + B_BLOCKS) {                                                                \
+        const bool isA = blk < A_BLOCKS;                                                              \
+        const int bb = isA ? blk : blk - A_BLOCKS;                                                    \
+        const int nch = isA ? (BM / 8) : (BN / 8);                                                    \
+        const int cc = bb % nch, pg = bb / nch;                                                       \
+        unsigned char* base = isA ? As_ : Bs_;                                                        \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                               \
+          uint32_t o[4];                                                                              \
+          _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                             \
+            const uint32_t lo = dword_of(rg[q][2 * d], c >> 1), hi = dword_of(rg[q][2 * d + 1], c >> 1); \
+            o[d] = (c & 1) ? ((lo >> 16) | (hi & 0xFFFF0000u)) : ((lo & 0xFFFFu) | (hi << 16));        \
+          }                                                                                           \
+          *reinterpret_cast<uint4*>(base + lds_off<BK>(cc * 8 + c, pg)) = make_uint4(o[0], o[1], o[2], o[3]); \
+        }                                                                                             \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (kt_begin < kt_end) {
+    RIGL_W_LOAD(kt_begin);
+    RIGL_W_STORE(0);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int buf = (kt - kt_begin) & 1;
+      const bool more = kt + 1 < kt_end;
+      if (more) RIGL_W_LOAD(kt + 1);
+      const unsigned char* As = smem + buf * STAGE;
+      const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        const int chunk = ks * 2 + (lane >> 5);
+        bf16x8 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off<BK>(wm * 32 * TM + i * 32 + (lane & 31), chunk));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<BK>(wn * 32 * TN + j * 32 + (lane & 31), chunk));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) RIGL_W_STORE(buf ^ 1);
+      __syncthreads();
+    }
+  }
+#undef RIGL_W_LOAD
+#undef RIGL_W_STORE
+  float* out = P.OUT + (int64_t)split * P.slab_elems + (int64_t)tap * P.Cin * P.Cout;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = ci0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int co = co0 + wn * 32 * TN + j * 32 + (lane & 31);
+        if (ci < P.Cin && co < P.Cout) out[(int64_t)ci * P.Cout + co] = acc[i][j][e];
+      }
+}
+
+// dw[i] = sum_s slab[s][i], s ascending (deterministic).  n_out <= slab_elems
+// lets the small-Cin (im2col) path drop its zero padding rows.
+__global__ __launch_bounds__(THREADS) void k_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                           int64_t n_out, int64_t slab_elems, int splits) {
+  const int64_t stride = (int64_t)gridDim.x * THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n_out; i += stride) {
+    float a = slabs[i];
+    for (int s2 = 1; s2 < splits; ++s2) a += slabs[(int64_t)s2 * slab_elems + i];
+    dw[i] = a;
+  }
+}
+
+// ------------------------------------------------------------------ small-Cin (stem) path
+// Explicit im2col for layers whose Cin is not a multiple of 8 (the 7x7x3 stem):
+// col[m][kk] = x[n, ho*sh-ph+r, wo*sw-pw+s, c] with kk = (r*KW+s)*Cin + c, zero
+// padded to Kp columns.  The conv then runs as a 1x1 conv over `col`.
+struct Im2colArgs {
+  const uint16_t* X; uint16_t* COL;
+  int M, Cin, KH, KW, H, W, Ho, Wo, sh, sw, ph, pw, K, Kp;
+};
+__global__ __launch_bounds__(THREADS) void k_im2col(Im2colArgs P) {
+  const int CH = P.Kp / 8;
+  const int64_t total = (int64_t)P.M * CH;
+  const int64_t stride = (int64_t)gridDim.x * THREADS;
+  for (int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x; idx < total; idx += stride) {
+    const int m = (int)(idx / CH), ch = (int)(idx % CH);
+    const int wo = m % P.Wo, t = m / P.Wo, ho = t % P.Ho, n = t / P.Ho;
+    uint16_t v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kk = ch * 8 + e;
+      uint16_t x = 0;
+      if (kk < P.K) {
+        const int c = kk % P.Cin, tap = kk / P.Cin, s = tap % P.KW, r = tap / P.KW;
+        const int hi = ho * P.sh - P.ph + r, wi = wo * P.sw - P.pw + s;
+        if ((unsigned)hi < (unsigned)P.H && (unsigned)wi < (unsigned)P.W)
+          x = P.X[((int64_t)(n * P.H + hi) * P.W + wi) * P.Cin + c];
+      }
+      v[e] = x;
+    }
+    *reinterpret_cast<uint4*>(P.COL + (int64_t)m * P.Kp + ch * 8) = *reinterpret_cast<const uint4*>(v);
+  }
+}
+// wp[co][kk] = w_ohwi[co][kk] for kk < K else 0  (row length Kp, 16-byte aligned rows)
+__global__ __launch_bounds__(THREADS) void k_pad_rows(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
+                                                       int rows, int K, int Kp) {
+  const int64_t total = (int64_t)rows * Kp;
+  const int64_t stride = (int64_t)gridDim.x * THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += stride) {
+    const int rr = (int)(i / Kp), kk = (int)(i % Kp);
+    dst[i] = kk < K ? src[(int64_t)rr * K + kk] : (uint16_t)0;
+  }
+}
+
+// ------------------------------------------------------------------ dispatch
+template <int MODE, bool F32>
+static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
+  IgemmArgs a = a0;
+  const bool wide_n = a.N > 64;
+  const int BM = 128;
+  const int BN = wide_n ? 128 : 64;
+  const int tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  dim3 grid((unsigned)(tiles_m * a.tiles_n)), blk(THREADS);
+  const int bk = a.Cred >= 64 ? 64 : (a.Cred >= 32 ? 32 : 16);
+  if (wide_n) {
+    if (bk == 64) hipLaunchKernelGGL((k_igemm<2, 2, 64, MODE, F32>), grid, blk, 0, st, a);
+    else if (bk == 32) hipLaunchKernelGGL((k_igemm<2, 2, 32, MODE, F32>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((k_igemm<2, 2, 16, MODE, F32>), grid, blk, 0, st, a);
+  } else {
+    if (bk == 64) hipLaunchKernelGGL((k_igemm<2, 1, 64, MODE, F32>), grid, blk, 0, st, a);
+    else if (bk == 32) hipLaunchKernelGGL((k_igemm<2, 1, 32, MODE, F32>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((k_igemm<2, 1, 16, MODE, F32>), grid, blk, 0, st, a);
+  }
+}
+
+static int check_desc(const RiglConvDesc* d, const char* who) {
+  if (!d) return fail(RIGL_EINVAL, "%s: NULL descriptor", who);
+  if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->ho <= 0 || d->wo <= 0 || d->cout <= 0 || d->kh <= 0 ||
+      d->kw <= 0 || d->stride_h <= 0 || d->stride_w <= 0 || d->pad_top < 0 || d->pad_left < 0)
+    return fail(RIGL_EINVAL, "%s: non-positive dimension in descriptor", who);
+  // every output pixel's window must start inside the padded image
+  if ((d->ho - 1) * d->stride_h - d->pad_top >= d->h || (d->wo - 1) * d->stride_w - d->pad_left >= d->w)
+    return fail(RIGL_EINVAL, "%s: output size inconsistent with input/stride/pad", who);
+  const int64_t lim = (int64_t(1) << 31) - 1;
+  if ((int64_t)d->n * d->h * d->w * d->cin > lim || (int64_t)d->n * d->ho * d->wo * d->cout > lim ||
+      (int64_t)d->kh * d->kw * d->cin * d->cout > lim)
+    return fail(RIGL_EUNSUPPORTED, "%s: tensor exceeds 2^31 elements", who);
+  return RIGL_OK;
+}
+
+static inline bool small_cin(const RiglConvDesc* d) { return (d->cin % 8) != 0; }
+static inline int kpad(const RiglConvDesc* d) { return (d->kh * d->kw * d->cin + 31) / 32 * 32; }
+
+struct WgradPlan { int tm, tn, tiles_ci, tiles_co, splits; int64_t slab; };
+static WgradPlan plan_wgrad(int M, int cin, int cout, int taps) {
+  WgradPlan p;
+  p.tm = cin > 64 ? 2 : 1;
+  p.tn = cout > 64 ? 2 : 1;
+  p.tiles_ci = (cin + 64 * p.tm - 1) / (64 * p.tm);
+  p.tiles_co = (cout + 64 * p.tn - 1) / (64 * p.tn);
+  const int64_t base = (int64_t)p.tiles_ci * p.tiles_co * taps;
+  const int kt = (M + 63) / 64;
+  int64_t s = (1024 + base - 1) / base;      // aim for ~1024 workgroups (4 per CU)
+  if (s > kt / 4) s = kt / 4;                // at least 4 K-tiles (256 pixels) per split
+  if (s < 1) s = 1;
+  if (s > 512) s = 512;
+  p.splits = (int)s;
+  p.slab = (int64_t)taps * cin * cout;
+  return p;
+}
+
+}  // namespace k1
+}  // namespace rigl
+
+extern "C" {
+
+size_t rigl_conv2d_workspace_bytes(const RiglConvDesc* d, int32_t which) {
+  using namespace rigl;
+  using namespace rigl::k1;
+  if (!d) return 0;
+  const int64_t M = (int64_t)d->n * d->ho * d->wo;
+  if (small_cin(d)) {
+    const int Kp = kpad(d);
+    size_t col = align_up((size_t)M * Kp * 2, 256);
+    if (which == 0) return col + align_up((size_t)d->cout * Kp * 2, 256);
+    if (which == 2) {
+      WgradPlan p = plan_wgrad((int)M, Kp, d->cout, 1);
+      return col + align_up((size_t)p.splits * p.slab * 4, 256);
+    }
+    return 0;
+  }
+  if (which == 2) {
+    WgradPlan p = plan_wgrad((int)M, d->cin, d->cout, d->kh * d->kw);
+    return p.splits > 1 ? align_up((size_t)p.splits * p.slab * 4, 256) : 0;
+  }
+  return 0;
+}
+
+int rigl_masked_conv2d_fwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* w_ohwi, rigl_bf16* y,
+                           void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+  using namespace rigl;
+  using namespace rigl::k1;
+  int rc = check_desc(d, "rigl_masked_conv2d_fwd");
+  if (rc) return rc;
+  if (!x || !w_ohwi || !y) return fail(RIGL_EINVAL, "rigl_masked_conv2d_fwd: NULL tensor");
+  if (d->cout % 8) return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_fwd: cout %% 8 != 0 (use the reference kernel)");
+  hipStream_t st = as_stream(stream);
+  ProfScope prof(PROF_CONV_FWD, st);
+  IgemmArgs a = {};
+  a.C = y; a.M = d->n * d->ho * d->wo; a.N = d->cout; a.ldc = d->cout;
+  if (small_cin(d)) {
+    const int K = d->kh * d->kw * d->cin, Kp = kpad(d);
+    const size_t need = rigl_conv2d_workspace_bytes(d, 0);
+    if (!workspace || workspace_bytes < need) return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_fwd: workspace %zu < %zu", workspace_bytes, need);
+    uint16_t* col = static_cast<uint16_t*>(workspace);
+    uint16_t* wp = reinterpret_cast<uint16_t*>(static_cast<char*>(workspace) + align_up((size_t)a.M * Kp * 2, 256));
+    Im2colArgs ia = {x, col, a.M, d->cin, d->kh, d->kw, d->h, d->w, d->ho, d->wo, d->stride_h, d->stride_w, d->pad_top, d->pad_left, K, Kp};
+    hipLaunchKernelGGL(k_im2col, dim3(2048), dim3(THREADS), 0, st, ia);
+    hipLaunchKernelGGL(k_pad_rows, dim3(64), dim3(THREADS), 0, st, w_ohwi, wp, d->cout, K, Kp);
+    a.A = col; a.B = wp; a.Cred = Kp; a.KH = a.KW = 1; a.RH = 1; a.RW = a.M; a.GH = 1; a.GW = a.M;
+    a.sh = a.sw = 1; a.ph = a.pw = 0; a.b_row_stride = Kp; a.b_tap_stride = 0;
+    // row space = one long row of M pixels in a single "image"
+  } else {
+    a.A = x; a.B = w_ohwi; a.Cred = d->cin; a.KH = d->kh; a.KW = d->kw; a.RH = d->ho; a.RW = d->wo;
+    a.GH = d->h; a.GW = d->w; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
+    a.b_row_stride = d->kh * d->kw * d->cin; a.b_tap_stride = d->cin;
+  }
+  launch_igemm<0, false>(a, st);
+  RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
+  return RIGL_OK;
+}
+
+int rigl_masked_conv2d_dgrad(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf16* w_hwio, rigl_bf16* dx,
+                             void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+  using namespace rigl;
+  using namespace rigl::k1;
+  (void)workspace; (void)workspace_bytes;
+  int rc = check_desc(d, "rigl_masked_conv2d_dgrad");
+  if (rc) return rc;
+  if (!dy || !w_hwio || !dx) return fail(RIGL_EINVAL, "rigl_masked_conv2d_dgrad: NULL tensor");
+  if ((d->cin % 8) || (d->cout % 8)) return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_dgrad: cin/cout %% 8 != 0 (use the reference kernel)");
+  hipStream_t st = as_stream(stream);
+  ProfScope prof(PROF_CONV_DGRAD, st);
+  IgemmArgs a = {};
+  a.A = dy; a.B = w_hwio; a.C = dx;
+  a.M = d->n * d->h * d->w; a.N = d->cin; a.Cred = d->cout; a.ldc = d->cin;
+  a.KH = d->kh; a.KW = d->kw; a.RH = d->h; a.RW = d->w; a.GH = d->ho; a.GW = d->wo;
+  a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
+  a.b_row_stride = d->cout; a.b_tap_stride = d->cin * d->cout;
+  launch_igemm<1, false>(a, st);
+  RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
+  return RIGL_OK;
+}
+
+int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, float* dw,
+                             void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+  using namespace rigl;
+  using namespace rigl::k1;
+  int rc = check_desc(d, "rigl_masked_conv2d_wgrad");
+  if (rc) return rc;
+  if (!x || !dy || !dw) return fail(RIGL_EINVAL, "rigl_masked_conv2d_wgrad: NULL tensor");
+  if (d->cout % 8) return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_wgrad: cout %% 8 != 0 (use the reference kernel)");
+  hipStream_t st = as_stream(stream);
+  const size_t need = rigl_conv2d_workspace_bytes(d, 2);
+  if (need && (!workspace || workspace_bytes < need)) return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
+  ProfScope prof(PROF_CONV_WGRAD, st);
+  WgradArgs a = {};
+  a.DY = dy; a.M = d->n * d->ho * d->wo; a.Cout = d->cout;
+  int64_t n_out;
+  char* ws = static_cast<char*>(workspace);
+  if (small_cin(d)) {
+    const int K = d->kh * d->kw * d->cin, Kp = kpad(d);
+    uint16_t* col = reinterpret_cast<uint16_t*>(ws);
+    ws += align_up((size_t)a.M * Kp * 2, 256);
+    Im2colArgs ia = {x, col, a.M, d->cin, d->kh, d->kw, d->h, d->w, d->ho, d->wo, d->stride_h, d->stride_w, d->pad_top, d->pad_left, K, Kp};
+    hipLaunchKernelGGL(k_im2col, dim3(2048), dim3(THREADS), 0, st, ia);
+    a.X = col; a.Cin = Kp; a.KH = a.KW = 1; a.H = 1; a.W = a.M; a.Ho = 1; a.Wo = a.M; a.sh = a.sw = 1; a.ph = a.pw = 0;
+    n_out = (int64_t)K * d->cout;
+  } else {
+    a.X = x; a.Cin = d->cin; a.KH = d->kh; a.KW = d->kw; a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo;
+    a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
+    n_out = (int64_t)d->kh * d->kw * d->cin * d->cout;
+  }
+  WgradPlan p = plan_wgrad(a.M, a.Cin, a.Cout, a.KH * a.KW);
+  a.tiles_ci = p.tiles_ci; a.tiles_co = p.tiles_co; a.splits = p.splits; a.slab_elems = p.slab;
+  const bool two_pass = p.splits > 1 || small_cin(d);
+  a.OUT = two_pass ? reinterpret_cast<float*>(ws) : dw;
+  dim3 grid((unsigned)((int64_t)p.tiles_ci * p.tiles_co * a.KH * a.KW * p.splits)), blk(THREADS);
+  if (p.tm == 2 && p.tn == 2) hipLaunchKernelGGL((k_wgrad<2, 2>), grid, blk, 0, st, a);
+  else if (p.tm == 2) hipLaunchKernelGGL((k_wgrad<2, 1>), grid, blk, 0, st, a);
+  else if (p.tn == 2) hipLaunchKernelGGL((k_wgrad<1, 2>), grid, blk, 0, st, a);
+  else hipLaunchKernelGGL((k_wgrad<1, 1>), grid, blk, 0, st, a);
+  if (two_pass) {
+    int64_t blocks = ceil_div64(n_out, THREADS);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)blocks), blk, 0, st, reinterpret_cast<const float*>(ws), dw, n_out, p.slab, p.splits);
+  }
+  RIGL_CHECK_LAUNCH("rigl_masked_conv2d_wgrad");
+  return RIGL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,798 @@
+// K2: fused |W|-magnitude prune + |dL/dW| regrow mask update for gfx950.
+//
+// Restates rigl/sparse_optimizers_base.py:276-343 (+ :523-538, :540-564) without
+// sorting: "the first k entries of a full descending sort, ties by lower index"
+// is exactly  { key > T }  U  { the r lowest-index entries with key == T },
+// where T is the k-th largest key.  T is found by a 3-digit (11/11/10 bit) MSD
+// radix select over order-preserving uint32 images of the fp32 scores; the r
+// tie winners are found with an index-ordered prefix count (per-4096-chunk
+// counts -> per-layer exclusive scan -> in-chunk scan).  All layers of a model
+// are processed by the same launches (segmented by a chunk table), so a whole
+// ResNet-50 update is 17 launches, not 54 x 17.
+//
+// HBM-bound integer/compare work: 16 B/lane coalesced loads, wave64 shuffles to
+// assemble the 1-bit/weight bitmap, LDS histograms, no MFMA.
+#include <vector>
+
+#include "common.hpp"
+
+namespace rigl {
+namespace k2 {
+
+constexpr int BLOCK = 256;
+constexpr int VEC = 4;
+constexpr int SEGS = 4;                       // j
+constexpr int CHUNK = BLOCK * VEC * SEGS;     // 4096 elements per workgroup
+constexpr int NB = 2048;                      // histogram bins (11-bit digits)
+
+struct LayerDev {
+  int64_t n;
+  float* w;
+  float* mom;
+  uint32_t* mask;
+  const float* g;
+  const float* noise;
+  const float* sdrop;
+  const float* sgrow;
+  const float* gvals;
+  uint32_t* mask1;       // workspace bitmap (or the output bitmap for topk_mask)
+  uint32_t chunk_begin;  // first global chunk of this layer
+  uint32_t n_chunks;
+  int64_t fixed_k;       // >= 0: select exactly this many in the drop pass
+};
+
+struct SelState {
+  uint32_t prefix;
+  uint32_t k_rem;
+  uint32_t T;
+  uint32_t r;
+  uint32_t mode;  // 0 = threshold select, 1 = select none, 2 = select all
+  uint32_t pad[3];
+};
+
+struct LayerState {
+  uint32_t n_ones;
+  uint32_t gmin_key;
+  int32_t n_prune;
+  int32_t n_keep;
+  uint32_t lifted_key;
+  uint32_t n_grown;
+  uint32_t overlap;
+  uint32_t n_new_ones;
+  SelState d;
+  SelState g;
+  uint32_t hist[NB];
+};
+
+struct Params {
+  float drop_fraction;
+  int grow_init_mode;
+  float grow_init_div;
+  int momentum_reset_mode;
+  float initial_acc_scale;
+  int reinit_when_same;
+};
+
+// ---------------------------------------------------------------- device utils
+__device__ __forceinline__ uint32_t f2key(float x) {
+  uint32_t b = __float_as_uint(x);
+  if ((b << 1) == 0u) b = 0u;  // -0.0 == +0.0 (they tie, as in TF's comparator)
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+  uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(b);
+}
+
+// Finds the layer that owns global chunk `c` (layers sorted by chunk_begin).
+__device__ __forceinline__ int find_layer(const LayerDev* L, int n_layers, uint32_t c) {
+  int lo = 0, hi = n_layers - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (L[mid].chunk_begin <= c) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+struct Pos {
+  int64_t e0;   // first element (within the layer) of this thread's quad
+  int nvalid;   // 0..4
+};
+__device__ __forceinline__ Pos quad_pos(int64_t n, uint32_t chunk_local, int j) {
+  Pos p;
+  p.e0 = (int64_t)chunk_local * CHUNK + (int64_t)j * (BLOCK * VEC) + (int64_t)threadIdx.x * VEC;
+  int64_t rem = n - p.e0;
+  p.nvalid = rem >= VEC ? VEC : (rem > 0 ? (int)rem : 0);
+  return p;
+}
+
+__device__ __forceinline__ void load4(const float* __restrict__ p, const Pos& q, float out[4]) {
+  const float* a = p + q.e0;
+  if (q.nvalid == VEC && ((reinterpret_cast<uintptr_t>(a) & 15u) == 0)) {
+    float4 v = *reinterpret_cast<const float4*>(a);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) out[v] = v < q.nvalid ? a[v] : 0.f;
+  }
+}
+
+__device__ __forceinline__ uint32_t load_nibble(const uint32_t* __restrict__ bits, const Pos& q) {
+  if (q.nvalid == 0) return 0u;
+  uint32_t word = bits[q.e0 >> 5];
+  return (word >> (uint32_t)(q.e0 & 31)) & 0xFu;
+}
+
+// ORs the 4-bit nibbles of 8 consecutive lanes into one mask word and stores it.
+__device__ __forceinline__ void store_nibble(uint32_t* __restrict__ bits, const Pos& q, uint32_t nib) {
+  uint32_t val = nib << ((threadIdx.x & 7) * 4);
+  val |= __shfl_xor(val, 1);
+  val |= __shfl_xor(val, 2);
+  val |= __shfl_xor(val, 4);
+  if ((threadIdx.x & 7) == 0 && q.nvalid > 0) bits[q.e0 >> 5] = val;
+}
+
+__device__ __forceinline__ void drop_keys(const LayerDev& L, const Pos& q, uint32_t nib, uint32_t key[4]) {
+  float s[4];
+  if (L.sdrop) {
+    load4(L.sdrop, q, s);
+  } else {
+    float wv[4];
+    load4(L.w, q, wv);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s[v] = ((nib >> v) & 1u) ? fabsf(wv[v]) : 0.f;
+    if (L.noise) {
+      float nz[4];
+      load4(L.noise, q, nz);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) s[v] = __fadd_rn(s[v], nz[v]);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) key[v] = f2key(s[v]);
+}
+
+__device__ __forceinline__ void grow_scores(const LayerDev& L, const Pos& q, uint32_t key[4]) {
+  float s[4];
+  if (L.sgrow) {
+    load4(L.sgrow, q, s);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) key[v] = f2key(s[v]);
+  } else {
+    load4(L.g, q, s);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) key[v] = f2key(fabsf(s[v]));
+  }
+}
+
+template <int P>
+__device__ __forceinline__ bool digit_of(uint32_t key, uint32_t prefix, uint32_t* bin) {
+  if (P == 0) { *bin = key >> 21; return true; }
+  if (P == 1) { *bin = (key >> 10) & 0x7FFu; return (key >> 21) == prefix; }
+  *bin = key & 0x3FFu; return (key >> 10) == prefix;
+}
+
+__device__ __forceinline__ void hist_clear(uint32_t* h) {
+  for (int i = threadIdx.x; i < NB; i += BLOCK) h[i] = 0u;
+}
+__device__ __forceinline__ void hist_flush(const uint32_t* h, uint32_t* gh) {
+  for (int i = threadIdx.x; i < NB; i += BLOCK) {
+    uint32_t c = h[i];
+    if (c) atomicAdd(&gh[i], c);
+  }
+}
+
+// Exclusive prefix of `x` over the 256 threads of the block (thread order), and
+// the block total.  LDS Hillis-Steele; used only on the rare tie path and in
+// the tiny per-layer scans, so simplicity beats speed.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t* sh /*[256]*/, uint32_t* total) {
+  const int t = threadIdx.x;
+  __syncthreads();
+  sh[t] = x;
+  __syncthreads();
+  for (int off = 1; off < BLOCK; off <<= 1) {
+    uint32_t v = sh[t] + (t >= off ? sh[t - off] : 0u);
+    __syncthreads();
+    sh[t] = v;
+    __syncthreads();
+  }
+  uint32_t incl = sh[t];
+  *total = sh[BLOCK - 1];
+  __syncthreads();
+  return incl - x;
+}
+
+// Membership test of one quad given the selection state and the tie ranks.
+// rank_base = number of ties (key == T) at lower flat indices than this quad.
+__device__ __forceinline__ uint32_t select_nibble(const uint32_t key[4], int nvalid, const SelState& s,
+                                                  uint32_t rank_base) {
+  uint32_t nib = 0u;
+  if (s.mode == 1u) return 0u;
+  uint32_t rank = rank_base;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    if (v < nvalid) {
+      bool in;
+      if (s.mode == 2u) in = true;
+      else if (key[v] > s.T) in = true;
+      else if (key[v] == s.T) { in = rank < s.r; ++rank; }
+      else in = false;
+      nib |= (in ? 1u : 0u) << v;
+    }
+  }
+  return nib;
+}
+
+// Computes rank_base (see above) for the 4 quads of this thread in one chunk.
+// tie_nib[j] = per-quad 4-bit "key == T" flags.
+__device__ __forceinline__ void tie_rank_bases(const uint32_t tie_nib[SEGS], uint32_t chunk_off,
+                                               uint32_t chunk_ties, uint32_t r, uint32_t* sh,
+                                               uint32_t rank_base[SEGS]) {
+  // Uniform fast paths: no ties here, all admitted, or none admitted.
+  if (chunk_ties == 0u || chunk_off + chunk_ties <= r) {
+#pragma unroll
+    for (int j = 0; j < SEGS; ++j) rank_base[j] = 0u;          // every tie: rank < r
+    return;
+  }
+  if (chunk_off >= r) {
+#pragma unroll
+    for (int j = 0; j < SEGS; ++j) rank_base[j] = r;           // every tie: rank >= r
+    return;
+  }
+  uint32_t base = chunk_off;
+#pragma unroll
+  for (int j = 0; j < SEGS; ++j) {
+    uint32_t total;
+    uint32_t ex = block_excl_scan(__popc(tie_nib[j]), sh, &total);
+    rank_base[j] = base + ex;
+    base += total;
+  }
+}
+
+// ------------------------------------------------------------------ kernels
+// Pass A of the drop selection: histogram of the top digit of the drop keys;
+// P == 0 additionally gathers popcount(mask) and min(grow score).
+template <int P>
+__global__ __launch_bounds__(BLOCK) void k_drop_hist(const LayerDev* __restrict__ Ls, LayerState* __restrict__ St,
+                                                     int n_layers) {
+  __shared__ uint32_t h[NB];
+  const int li = find_layer(Ls, n_layers, blockIdx.x);
+  const LayerDev L = Ls[li];
+  LayerState& S = St[li];
+  const uint32_t cl = blockIdx.x - L.chunk_begin;
+  const SelState sel = S.d;
+  if (P > 0 && sel.mode != 0u) return;
+  hist_clear(h);
+  __syncthreads();
+  uint32_t ones = 0u, gmin = 0xFFFFFFFFu;
+#pragma unroll
+  for (int j = 0; j < SEGS; ++j) {
+    Pos q = quad_pos(L.n, cl, j);
+    if (q.nvalid == 0) continue;
+    uint32_t nib = L.sdrop ? 0u : load_nibble(L.mask, q);
+    uint32_t key[4];
+    drop_keys(L, q, nib, key);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      if (v < q.nvalid) {
+        uint32_t bin;
+        if (digit_of<P>(key[v], sel.prefix, &bin)) atomicAdd(&h[bin], 1u);
+      }
+    }
+    if (P == 0) {
+      uint32_t mnib = L.sdrop ? load_nibble(L.mask, q) : nib;
+      ones += __popc(mnib);
+      if (L.fixed_k < 0) {
+        uint32_t gk[4];
+        grow_scores(L, q, gk);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) if (v < q.nvalid) gmin = min(gmin, gk[v]);
+      }
+    }
+  }
+  if (P == 0) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ones += __shfl_xor(ones, off);
+      gmin = min(gmin, __shfl_xor(gmin, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (ones) atomicAdd(&S.n_ones, ones);
+      if (L.fixed_k < 0) atomicMin(&S.gmin_key, gmin);
+    }
+  }
+  __syncthreads();
+  hist_flush(h, S.hist);
+}
+
+// Per-layer digit scan: picks the bin holding the k-th largest key.
+template <int WHICH, int P>
+__global__ __launch_bounds__(BLOCK) void k_scan(const LayerDev* __restrict__ Ls, LayerState* __restrict__ St,
+                                                Params prm) {
+  __shared__ uint32_t sh[BLOCK];
+  __shared__ uint32_t s_mode, s_k;
+  const LayerDev L = Ls[blockIdx.x];
+  LayerState& S = St[blockIdx.x];
+  SelState& sel = WHICH ? S.g : S.d;
+  const int t = threadIdx.x;
+  if (L.n == 0) return;
+  if (t == 0) {
+    if (P == 0) {
+      int64_t k;
+      if (WHICH == 0) {
+        if (L.fixed_k >= 0) {
+          k = L.fixed_k;
+          S.n_prune = 0;
+          S.n_keep = (int32_t)k;
+        } else {
+          // sparse_optimizers_base.py:286-290 -- fp32 product, truncating cast
+          int32_t n_ones = (int32_t)S.n_ones;
+          int32_t n_prune = (int32_t)__fmul_rn((float)n_ones, prm.drop_fraction);
+          S.n_prune = n_prune;
+          S.n_keep = n_ones - n_prune;
+          k = S.n_keep;
+          // :307-310  min(score_grow) - 1, one fp32 subtract
+          S.lifted_key = f2key(__fsub_rn(key2f(S.gmin_key), 1.0f));
+        }
+      } else {
+        k = S.n_prune;
+      }
+      sel.prefix = 0u;
+      if (k <= 0) { sel.mode = 1u; sel.T = 0xFFFFFFFFu; sel.r = 0u; sel.k_rem = 0u; }
+      else if (k >= L.n) { sel.mode = 2u; sel.T = 0u; sel.r = (uint32_t)L.n; sel.k_rem = 0u; }
+      else { sel.mode = 0u; sel.k_rem = (uint32_t)k; }
+    }
+    s_mode = sel.mode;
+    s_k = sel.k_rem;
+  }
+  __syncthreads();
+  const uint32_t mode = s_mode, k = s_k;
+  constexpr int NBINS = (P == 2) ? 1024 : NB;
+  constexpr int PER = NBINS / BLOCK;
+  uint32_t own[PER];
+  uint32_t tsum = 0u;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { own[i] = S.hist[t * PER + i]; tsum += own[i]; }
+  __syncthreads();  // every thread has read its bins before anyone clears them
+  // zero the whole histogram for the next pass
+  for (int i = t; i < NB; i += BLOCK) S.hist[i] = 0u;
+  if (mode != 0u) return;
+  // inclusive SUFFIX sums over threads
+  sh[t] = tsum;
+  __syncthreads();
+  for (int off = 1; off < BLOCK; off <<= 1) {
+    uint32_t v = sh[t] + (t + off < BLOCK ? sh[t + off] : 0u);
+    __syncthreads();
+    sh[t] = v;
+    __syncthreads();
+  }
+  const uint32_t s_here = sh[t];
+  const uint32_t s_next = (t + 1 < BLOCK) ? sh[t + 1] : 0u;
+  if (s_here >= k && s_next < k) {
+    uint32_t acc = s_next;
+#pragma unroll
+    for (int i = PER - 1; i >= 0; --i) {
+      uint32_t c = own[i];
+      if (acc + c >= k) {
+        const uint32_t bin = (uint32_t)(t * PER + i);
+        const uint32_t krem = k - acc;  // 1..c
+        if (P == 0) sel.prefix = bin;
+        else if (P == 1) sel.prefix = (sel.prefix << 11) | bin;
+        else { sel.T = (sel.prefix << 10) | bin; sel.r = krem; }
+        sel.k_rem = krem;
+        break;
+      }
+      acc += c;
+    }
+  }
+}
+
+// Per-chunk count of keys equal to the threshold.
+template <int WHICH>
+__global__ __launch_bounds__(BLOCK) void k_tiecount(const LayerDev* __restrict__ Ls, const LayerState* __restrict__ St,
+                                                    int n_layers, uint32_t* __restrict__ tie_cnt) {
+  __shared__ uint32_t s_cnt;
+  const int li = find_layer(Ls, n_layers, blockIdx.x);
+  const LayerDev L = Ls[li];
+  const LayerState& S = St[li];
+  const SelState sel = WHICH ? S.g : S.d;
+  const uint32_t cl = blockIdx.x - L.chunk_begin;
+  if (threadIdx.x == 0) s_cnt = 0u;
+  __syncthreads();
+  uint32_t cnt = 0u;
+  if (sel.mode == 0u) {
+#pragma unroll
+    for (int j = 0; j < SEGS; ++j) {
+      Pos q = quad_pos(L.n, cl, j);
+      if (q.nvalid == 0) continue;
+      uint32_t key[4];
+      if (WHICH == 0) {
+        uint32_t nib = L.sdrop ? 0u : load_nibble(L.mask, q);
+        drop_keys(L, q, nib, key);
+      } else {
+        uint32_t m1 = load_nibble(L.mask1, q);
+        grow_scores(L, q, key);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) if ((m1 >> v) & 1u) key[v] = S.lifted_key;
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) cnt += (v < q.nvalid && key[v] == sel.T) ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_cnt, cnt);
+  __syncthreads();
+  if (threadIdx.x == 0) tie_cnt[blockIdx.x] = s_cnt;
+}
+
+// Per-layer exclusive scan of the chunk tie counts (index order).
+__global__ __launch_bounds__(BLOCK) void k_tiescan(const LayerDev* __restrict__ Ls, const uint32_t* __restrict__ tie_cnt,
+                                                   uint32_t* __restrict__ tie_off) {
+  __shared__ uint32_t sh[BLOCK];
+  const LayerDev L = Ls[blockIdx.x];
+  uint32_t carry = 0u;
+  for (uint32_t base = 0; base < L.n_chunks; base += BLOCK) {
+    uint32_t i = base + threadIdx.x;
+    uint32_t x = i < L.n_chunks ? tie_cnt[L.chunk_begin + i] : 0u;
+    uint32_t total;
+    uint32_t ex = block_excl_scan(x, sh, &total);
+    if (i < L.n_chunks) tie_off[L.chunk_begin + i] = carry + ex;
+    carry += total;
+  }
+}
+
+// mask1 = top-n_keep of the drop scores; fused with pass A of the grow select.
+template <bool WITH_GROW>
+__global__ __launch_bounds__(BLOCK) void k_apply1(const LayerDev* __restrict__ Ls, LayerState* __restrict__ St,
+                                                  int n_layers, const uint32_t* __restrict__ tie_cnt,
+                                                  const uint32_t* __restrict__ tie_off) {
+  __shared__ uint32_t h[NB];
+  __shared__ uint32_t sh[BLOCK];
+  const int li = find_layer(Ls, n_layers, blockIdx.x);
+  const LayerDev L = Ls[li];
+  LayerState& S = St[li];
+  const SelState sel = S.d;
+  const uint32_t cl = blockIdx.x - L.chunk_begin;
+  if (WITH_GROW) { hist_clear(h); }
+  uint32_t key[SEGS][4], tie_nib[SEGS], rank_base[SEGS];
+  Pos q[SEGS];
+#pragma unroll
+  for (int j = 0; j < SEGS; ++j) {
+    q[j] = quad_pos(L.n, cl, j);
+    tie_nib[j] = 0u;
+    if (q[j].nvalid) {
+      uint32_t nib = L.sdrop ? 0u : load_nibble(L.mask, q[j]);
+      drop_keys(L, q[j], nib, key[j]);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+        tie_nib[j] |= ((v < q[j].nvalid && key[j][v] == sel.T) ? 1u : 0u) << v;
+    }
+  }
+  const uint32_t c_ties = sel.mode == 0u ? tie_cnt[blockIdx.x] : 0u;
+  const uint32_t c_off = sel.mode == 0u ? tie_off[blockIdx.x] : 0u;
+  tie_rank_bases(tie_nib, c_off, c_ties, sel.r, sh, rank_base);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < SEGS; ++j) {
+    uint32_t in1 = q[j].nvalid ? select_nibble(key[j], q[j].nvalid, sel, rank_base[j]) : 0u;
+    store_nibble(L.mask1, q[j], in1);
+    if (WITH_GROW && q[j].nvalid) {
+      uint32_t gk[4];
+      grow_scores(L, q[j], gk);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        if (v < q[j].nvalid) {
+          uint32_t k2 = ((in1 >> v) & 1u) ? S.lifted_key : gk[v];
+          atomicAdd(&h[k2 >> 21], 1u);
+        }
+      }
+    }
+  }
+  if (WITH_GROW) {
+    __syncthreads();
+    hist_flush(h, S.hist);
+  }
+}
+
+template <int P>
+__global__ __launch_bounds__(BLOCK) void k_grow_hist(const LayerDev* __restrict__ Ls, LayerState* __restrict__ St,
+                                                     int n_layers) {
+  __shared__ uint32_t h[NB];
+  const int li = find_layer(Ls, n_layers, blockIdx.x);
+  const LayerDev L = Ls[li];
+  LayerState& S = St[li];
+  const SelState sel = S.g;
+  if (sel.mode != 0u) return;
+  const uint32_t cl = blockIdx.x - L.chunk_begin;
+  hist_clear(h);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < SEGS; ++j) {
+    Pos q = quad_pos(L.n, cl, j);
+    if (q.nvalid == 0) continue;
+    uint32_t m1 = load_nibble(L.mask1, q);
+    uint32_t gk[4];
+    grow_scores(L, q, gk);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      if (v < q.nvalid) {
+        uint32_t k2 = ((m1 >> v) & 1u) ? S.lifted_key : gk[v];
+        uint32_t bin;
+        if (digit_of<P>(k2, sel.prefix, &bin)) atomicAdd(&h[bin], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  hist_flush(h, S.hist);
+}
+
+// mask2 + weight / momentum re-initialisation + new bitmap.
+__global__ __launch_bounds__(BLOCK) void k_apply2(const LayerDev* __restrict__ Ls, LayerState* __restrict__ St,
+                                                  int n_layers, const uint32_t* __restrict__ tie_cnt,
+                                                  const uint32_t* __restrict__ tie_off, Params prm) {
+  __shared__ uint32_t sh[BLOCK];
+  const int li = find_layer(Ls, n_layers, blockIdx.x);
+  const LayerDev L = Ls[li];
+  LayerState& S = St[li];
+  const SelState sel = S.g;
+  const uint32_t cl = blockIdx.x - L.chunk_begin;
+  uint32_t key[SEGS][4], tie_nib[SEGS], rank_base[SEGS], m1[SEGS];
+  Pos q[SEGS];
+#pragma unroll
+  for (int j = 0; j < SEGS; ++j) {
+    q[j] = quad_pos(L.n, cl, j);
+    tie_nib[j] = 0u;
+    m1[j] = 0u;
+    if (q[j].nvalid) {
+      m1[j] = load_nibble(L.mask1, q[j]);
+      grow_scores(L, q[j], key[j]);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        if ((m1[j] >> v) & 1u) key[j][v] = S.lifted_key;
+        tie_nib[j] |= ((v < q[j].nvalid && key[j][v] == sel.T) ? 1u : 0u) << v;
+      }
+    }
+  }
+  const uint32_t c_ties = sel.mode == 0u ? tie_cnt[blockIdx.x] : 0u;
+  const uint32_t c_off = sel.mode == 0u ? tie_off[blockIdx.x] : 0u;
+  tie_rank_bases(tie_nib, c_off, c_ties, sel.r, sh, rank_base);
+  __syncthreads();
+  uint32_t grown = 0u, overlap = 0u, ones = 0u;
+#pragma unroll
+  for (int j = 0; j < SEGS; ++j) {
+    uint32_t in2 = 0u, newc = 0u;
+    if (q[j].nvalid) {
+      in2 = select_nibble(key[j], q[j].nvalid, sel, rank_base[j]);
+      uint32_t old = load_nibble(L.mask, q[j]);
+      overlap |= in2 & m1[j];
+      newc = prm.reinit_when_same ? in2 : (in2 & ~old);
+      if (newc) {
+        float gv[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool need_g = (prm.grow_init_mode == RIGL_GROW_GRAD_SCALE || prm.grow_init_mode == RIGL_GROW_GRAD_SIGN ||
+                             (L.mom && prm.momentum_reset_mode == RIGL_MOMRESET_GRAD));
+        if (need_g && L.g) load4(L.g, q[j], gv);
+        float ev[4] = {0.f, 0.f, 0.f, 0.f};
+        if (prm.grow_init_mode == RIGL_GROW_EXPLICIT && L.gvals) load4(L.gvals, q[j], ev);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          if ((newc >> v) & 1u) {
+            float nw = 0.f;
+            if (prm.grow_init_mode == RIGL_GROW_GRAD_SCALE) nw = __fdiv_rn(gv[v], prm.grow_init_div);
+            else if (prm.grow_init_mode == RIGL_GROW_GRAD_SIGN) {
+              float sg = gv[v] > 0.f ? 1.f : (gv[v] < 0.f ? -1.f : gv[v]);  // tf.sign: sign(+-0) = +-0
+              nw = __fdiv_rn(sg, prm.grow_init_div);
+            } else if (prm.grow_init_mode == RIGL_GROW_EXPLICIT) nw = ev[v];
+            L.w[q[j].e0 + v] = nw;
+            if (L.mom)
+              L.mom[q[j].e0 + v] =
+                  prm.momentum_reset_mode == RIGL_MOMRESET_GRAD ? __fmul_rn(gv[v], prm.initial_acc_scale) : 0.f;
+          }
+        }
+      }
+    }
+    const uint32_t nm = m1[j] | in2;
+    store_nibble(L.mask, q[j], nm);
+    grown += __popc(newc);
+    ones += __popc(nm);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    grown += __shfl_xor(grown, off);
+    ones += __shfl_xor(ones, off);
+    overlap |= __shfl_xor(overlap, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (grown) atomicAdd(&S.n_grown, grown);
+    if (ones) atomicAdd(&S.n_new_ones, ones);
+    if (overlap) atomicOr(&S.overlap, 1u);
+  }
+}
+
+__global__ void k_counts(const LayerState* __restrict__ St, int n_layers, int32_t* __restrict__ out) {
+  int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n_layers) return;
+  const LayerState& S = St[l];
+  int32_t* o = out + l * RIGL_COUNTS_PER_LAYER;
+  o[0] = (int32_t)S.n_ones;
+  o[1] = S.n_prune;
+  o[2] = S.n_keep;
+  o[3] = (int32_t)S.n_grown;
+  o[4] = (int32_t)S.overlap;
+  o[5] = (int32_t)S.d.r;
+  o[6] = (int32_t)S.g.r;
+  o[7] = (int32_t)S.n_new_ones;
+}
+
+__global__ void k_init_state(LayerState* __restrict__ St, int n_layers) {
+  // zero everything, gmin to +max
+  const size_t words = sizeof(LayerState) / 4;
+  uint32_t* p = reinterpret_cast<uint32_t*>(St + blockIdx.x);
+  for (size_t i = threadIdx.x; i < words; i += blockDim.x) p[i] = 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) St[blockIdx.x].gmin_key = 0xFFFFFFFFu;
+}
+
+// The layer table travels in kernel arguments (copied at launch), so the host
+// array may die as soon as the launch call returns: no staging, no sync.
+constexpr int TABLE_BATCH = 32;
+struct LayerBatch { LayerDev l[TABLE_BATCH]; };
+__global__ void k_write_table(LayerBatch b, LayerDev* __restrict__ dst, int base, int count) {
+  int i = threadIdx.x;
+  if (i < count) dst[base + i] = b.l[i];
+}
+
+// ------------------------------------------------------------------ host side
+struct Layout {
+  size_t off_layers, off_state, off_tiecnt, off_tieoff, off_mask1, total;
+  uint32_t total_chunks;
+};
+
+static Layout make_layout(const int64_t* n_per_layer, int n_layers) {
+  Layout lo;
+  size_t off = 0;
+  lo.off_layers = off; off = align_up(off + sizeof(LayerDev) * (size_t)n_layers, 256);
+  lo.off_state = off;  off = align_up(off + sizeof(LayerState) * (size_t)n_layers, 256);
+  uint64_t chunks = 0, mwords = 0;
+  for (int i = 0; i < n_layers; ++i) {
+    chunks += (uint64_t)ceil_div64(n_per_layer[i], CHUNK);
+    mwords += (uint64_t)align_up((size_t)ceil_div64(n_per_layer[i], 32), 4);
+  }
+  lo.total_chunks = (uint32_t)chunks;
+  lo.off_tiecnt = off; off = align_up(off + 4 * (size_t)chunks, 256);
+  lo.off_tieoff = off; off = align_up(off + 4 * (size_t)chunks, 256);
+  lo.off_mask1 = off;  off = align_up(off + 4 * (size_t)mwords, 256);
+  lo.total = off;
+  return lo;
+}
+
+static int run(const RiglPruneRegrowLayer* layers, int n_layers, const int64_t* fixed_k, const Params& prm,
+               bool with_grow, uint32_t* const* mask1_override, int32_t* out_counts, void* ws, size_t ws_bytes,
+               hipStream_t stream) {
+  if (n_layers <= 0) return RIGL_OK;
+  std::vector<int64_t> ns(n_layers);
+  for (int i = 0; i < n_layers; ++i) {
+    const RiglPruneRegrowLayer& l = layers[i];
+    if (l.n < 0 || l.n >= (int64_t(1) << 31)) return fail(RIGL_EINVAL, "prune_regrow: layer %d: n=%lld out of range", i, (long long)l.n);
+    if (l.n > 0) {
+      if (!l.mask_bits) return fail(RIGL_EINVAL, "prune_regrow: layer %d: mask_bits is NULL", i);
+      if (!l.score_drop && !l.w) return fail(RIGL_EINVAL, "prune_regrow: layer %d: w is NULL", i);
+      if (with_grow) {
+        if (!l.w) return fail(RIGL_EINVAL, "prune_regrow: layer %d: w is NULL", i);
+        if (!l.score_grow && !l.dense_grad) return fail(RIGL_EINVAL, "prune_regrow: layer %d: no grow score (dense_grad and score_grow NULL)", i);
+        if (!l.dense_grad && (prm.grow_init_mode == RIGL_GROW_GRAD_SCALE || prm.grow_init_mode == RIGL_GROW_GRAD_SIGN ||
+                              (l.momentum && prm.momentum_reset_mode == RIGL_MOMRESET_GRAD && prm.initial_acc_scale != 0.f)))
+          return fail(RIGL_EINVAL, "prune_regrow: layer %d: mode needs dense_grad", i);
+        if (prm.grow_init_mode == RIGL_GROW_EXPLICIT && !l.grow_values) return fail(RIGL_EINVAL, "prune_regrow: layer %d: grow_values is NULL", i);
+      }
+    }
+    ns[i] = l.n;
+  }
+  Layout lo = make_layout(ns.data(), n_layers);
+  if (!ws || ws_bytes < lo.total) return fail(RIGL_EWORKSPACE, "prune_regrow: workspace %zu < required %zu", ws_bytes, lo.total);
+  char* base = static_cast<char*>(ws);
+  LayerDev* dL = reinterpret_cast<LayerDev*>(base + lo.off_layers);
+  LayerState* dS = reinterpret_cast<LayerState*>(base + lo.off_state);
+  uint32_t* tie_cnt = reinterpret_cast<uint32_t*>(base + lo.off_tiecnt);
+  uint32_t* tie_off = reinterpret_cast<uint32_t*>(base + lo.off_tieoff);
+  uint32_t* mask1 = reinterpret_cast<uint32_t*>(base + lo.off_mask1);
+
+  std::vector<LayerDev> hL(n_layers);
+  uint32_t chunk = 0;
+  size_t mw = 0;
+  for (int i = 0; i < n_layers; ++i) {
+    const RiglPruneRegrowLayer& l = layers[i];
+    LayerDev& d = hL[i];
+    d.n = l.n; d.w = l.w; d.mom = l.momentum; d.mask = l.mask_bits; d.g = l.dense_grad; d.noise = l.drop_noise;
+    d.sdrop = l.score_drop; d.sgrow = l.score_grow; d.gvals = l.grow_values;
+    d.mask1 = (mask1_override && mask1_override[i]) ? mask1_override[i] : mask1 + mw;
+    d.chunk_begin = chunk;
+    d.n_chunks = (uint32_t)ceil_div64(l.n, CHUNK);
+    d.fixed_k = fixed_k ? fixed_k[i] : -1;
+    chunk += d.n_chunks;
+    mw += align_up((size_t)ceil_div64(l.n, 32), 4);
+  }
+  for (int b = 0; b < n_layers; b += TABLE_BATCH) {
+    LayerBatch hb;
+    const int cnt = n_layers - b < TABLE_BATCH ? n_layers - b : TABLE_BATCH;
+    for (int i = 0; i < cnt; ++i) hb.l[i] = hL[b + i];
+    hipLaunchKernelGGL(k_write_table, dim3(1), dim3(TABLE_BATCH), 0, stream, hb, dL, b, cnt);
+  }
+
+  ProfScope prof(PROF_PRUNE_REGROW, stream);
+  const uint32_t C = lo.total_chunks;
+  hipLaunchKernelGGL(k_init_state, dim3(n_layers), dim3(256), 0, stream, dS, n_layers);
+  if (C == 0) { RIGL_CHECK_LAUNCH("k_init_state"); return RIGL_OK; }
+  // ---- drop selection -------------------------------------------------------
+  hipLaunchKernelGGL(k_drop_hist<0>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers);
+  hipLaunchKernelGGL((k_scan<0, 0>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
+  hipLaunchKernelGGL(k_drop_hist<1>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers);
+  hipLaunchKernelGGL((k_scan<0, 1>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
+  hipLaunchKernelGGL(k_drop_hist<2>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers);
+  hipLaunchKernelGGL((k_scan<0, 2>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
+  hipLaunchKernelGGL(k_tiecount<0>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers, tie_cnt);
+  hipLaunchKernelGGL(k_tiescan, dim3(n_layers), dim3(BLOCK), 0, stream, dL, tie_cnt, tie_off);
+  if (!with_grow) {
+    hipLaunchKernelGGL(k_apply1<false>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers, tie_cnt, tie_off);
+    RIGL_CHECK_LAUNCH("topk_mask");
+    return RIGL_OK;
+  }
+  hipLaunchKernelGGL(k_apply1<true>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers, tie_cnt, tie_off);
+  // ---- grow selection -------------------------------------------------------
+  hipLaunchKernelGGL((k_scan<1, 0>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
+  hipLaunchKernelGGL(k_grow_hist<1>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers);
+  hipLaunchKernelGGL((k_scan<1, 1>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
+  hipLaunchKernelGGL(k_grow_hist<2>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers);
+  hipLaunchKernelGGL((k_scan<1, 2>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
+  hipLaunchKernelGGL(k_tiecount<1>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers, tie_cnt);
+  hipLaunchKernelGGL(k_tiescan, dim3(n_layers), dim3(BLOCK), 0, stream, dL, tie_cnt, tie_off);
+  hipLaunchKernelGGL(k_apply2, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers, tie_cnt, tie_off, prm);
+  if (out_counts)
+    hipLaunchKernelGGL(k_counts, dim3((n_layers + 63) / 64), dim3(64), 0, stream, dS, n_layers, out_counts);
+  RIGL_CHECK_LAUNCH("prune_regrow");
+  return RIGL_OK;
+}
+
+}  // namespace k2
+}  // namespace rigl
+
+extern "C" {
+
+size_t rigl_prune_regrow_workspace_bytes(const int64_t* n_per_layer, int32_t n_layers) {
+  if (!n_per_layer || n_layers <= 0) return 0;
+  return rigl::k2::make_layout(n_per_layer, n_layers).total;
+}
+
+int rigl_prune_regrow(const RiglPruneRegrowLayer* layers, int32_t n_layers, const RiglPruneRegrowParams* params,
+                      int32_t* out_counts, void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+  if (!layers || !params) return rigl::fail(RIGL_EINVAL, "rigl_prune_regrow: NULL layers/params");
+  if (n_layers < 0) return rigl::fail(RIGL_EINVAL, "rigl_prune_regrow: n_layers < 0");
+  if (!(params->drop_fraction >= 0.f) || params->drop_fraction > 1.f)
+    return rigl::fail(RIGL_EINVAL, "rigl_prune_regrow: drop_fraction %g not in [0,1]", (double)params->drop_fraction);
+  if (params->grow_init_mode < 0 || params->grow_init_mode > 3)
+    return rigl::fail(RIGL_EINVAL, "rigl_prune_regrow: bad grow_init_mode %d", params->grow_init_mode);
+  rigl::k2::Params p;
+  p.drop_fraction = params->drop_fraction;
+  p.grow_init_mode = params->grow_init_mode;
+  p.grow_init_div = params->grow_init_div;
+  p.momentum_reset_mode = params->momentum_reset_mode;
+  p.initial_acc_scale = params->initial_acc_scale;
+  p.reinit_when_same = params->reinit_when_same;
+  return rigl::k2::run(layers, n_layers, nullptr, p, true, nullptr, out_counts, workspace, workspace_bytes,
+                       rigl::as_stream(stream));
+}
+
+int rigl_topk_mask(const float* score, int64_t n, int64_t n_keep, uint32_t* mask_bits, void* workspace,
+                   size_t workspace_bytes, rigl_stream_t stream) {
+  if (!score || !mask_bits) return rigl::fail(RIGL_EINVAL, "rigl_topk_mask: NULL pointer");
+  if (n_keep < 0) return rigl::fail(RIGL_EINVAL, "rigl_topk_mask: n_keep < 0");
+  RiglPruneRegrowLayer l = {};
+  l.n = n;
+  l.mask_bits = mask_bits;
+  l.score_drop = score;
+  rigl::k2::Params p = {};
+  uint32_t* ov = mask_bits;
+  return rigl::k2::run(&l, 1, &n_keep, p, false, &ov, nullptr, workspace, workspace_bytes, rigl::as_stream(stream));
+}
+
+}  // extern "C"

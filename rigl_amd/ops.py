@@ -1,0 +1,286 @@
+"""Thin tensor-level wrappers over the C ABI (``include/rigl_hip.h``).
+
+PyTorch is used for device memory and streams only: every function here takes
+CUDA(=HIP) tensors, checks dtype/contiguity, and enqueues the hand-written
+gfx950 kernels on ``torch.cuda.current_stream()``.  No function has a CPU or
+PyTorch-op fallback; calling one without a GPU / without the built library
+raises ``RiglError``.
+"""
+import ctypes as C
+
+import torch
+
+from rigl_amd import _lib
+from rigl_amd._lib import (ConvDesc, PackLayer, PruneRegrowLayer,
+                           PruneRegrowParams, RiglError, check)
+
+_workspaces = {}
+
+
+def _stream():
+  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+  return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _req(t, dtype, name, allow_none=False):
+  if t is None:
+    if allow_none:
+      return
+    raise ValueError('%s is None' % name)
+  if not t.is_cuda:
+    raise RiglError(_lib.RIGL_EINVAL,
+                    '%s must live on the GPU (no CPU path exists)' % name)
+  if t.dtype != dtype:
+    raise TypeError('%s: expected %s, got %s' % (name, dtype, t.dtype))
+  if not t.is_contiguous():
+    raise ValueError('%s must be contiguous' % name)
+
+
+def workspace(nbytes, device):
+  """Grow-only scratch buffer per device (stream-ordered reuse)."""
+  key = torch.device(device).index or 0
+  ws = _workspaces.get(key)
+  if ws is None or ws.numel() < nbytes:
+    ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8,
+                     device=device)
+    _workspaces[key] = ws
+  return ws
+
+
+def n_mask_words(n):
+  return (int(n) + 31) // 32
+
+
+# ----------------------------------------------------------------------------
+# mask bitmap
+# ----------------------------------------------------------------------------
+def mask_pack(mask01, out=None):
+  """float 0/1 mask (any shape) -> int32 bitmap words (flat C order)."""
+  _req(mask01, torch.float32, 'mask01')
+  n = mask01.numel()
+  if out is None:
+    out = torch.zeros(n_mask_words(n), dtype=torch.int32, device=mask01.device)
+  _req(out, torch.int32, 'bits')
+  check(_lib.load().rigl_mask_pack(_ptr(mask01), _ptr(out), n, _stream()))
+  return out
+
+
+def mask_unpack(bits, shape):
+  _req(bits, torch.int32, 'bits')
+  out = torch.empty(shape, dtype=torch.float32, device=bits.device)
+  check(_lib.load().rigl_mask_unpack(_ptr(bits), _ptr(out), out.numel(),
+                                     _stream()))
+  return out
+
+
+# ----------------------------------------------------------------------------
+# K2
+# ----------------------------------------------------------------------------
+def prune_regrow(layers, drop_fraction, grow_init_mode=_lib.GROW_ZEROS,
+                 grow_init_div=1.0, momentum_reset_mode=_lib.MOMRESET_GRAD,
+                 initial_acc_scale=0.0, reinit_when_same=False):
+  """Runs the fused prune/regrow update on a list of layers, in place.
+
+  Each layer is a dict with tensors: ``w`` (fp32), ``mask_bits`` (int32),
+  optional ``momentum``, ``dense_grad``, ``drop_noise``, ``score_drop``,
+  ``score_grow``, ``grow_values`` (all fp32, same numel as ``w``).
+  Returns an int32 tensor [n_layers, 8] of counts (see rigl_hip.h).
+  """
+  lib = _lib.load()
+  nl = len(layers)
+  if nl == 0:
+    return torch.zeros((0, _lib.COUNTS_PER_LAYER), dtype=torch.int32)
+  arr = (PruneRegrowLayer * nl)()
+  ns = (C.c_int64 * nl)()
+  dev = None
+  for i, l in enumerate(layers):
+    w = l.get('w')
+    ref = w if w is not None else l['score_drop']
+    n = ref.numel()
+    dev = ref.device
+    for key in ('w', 'momentum', 'dense_grad', 'drop_noise', 'score_drop',
+                'score_grow', 'grow_values'):
+      t = l.get(key)
+      _req(t, torch.float32, key, allow_none=True)
+      if t is not None and t.numel() != n:
+        raise ValueError('layer %d: %s has %d elements, expected %d' %
+                         (i, key, t.numel(), n))
+    _req(l['mask_bits'], torch.int32, 'mask_bits')
+    if l['mask_bits'].numel() < n_mask_words(n):
+      raise ValueError('layer %d: mask_bits too small' % i)
+    arr[i].n = n
+    arr[i].w = w.data_ptr() if w is not None else None
+    for key in ('momentum', 'dense_grad', 'drop_noise', 'score_drop',
+                'score_grow', 'grow_values'):
+      t = l.get(key)
+      setattr(arr[i], key, t.data_ptr() if t is not None else None)
+    arr[i].mask_bits = l['mask_bits'].data_ptr()
+    ns[i] = n
+  prm = PruneRegrowParams(float(drop_fraction), int(grow_init_mode),
+                          float(grow_init_div), int(momentum_reset_mode),
+                          float(initial_acc_scale), int(bool(reinit_when_same)))
+  need = lib.rigl_prune_regrow_workspace_bytes(ns, nl)
+  ws = workspace(need, dev)
+  counts = torch.zeros((nl, _lib.COUNTS_PER_LAYER), dtype=torch.int32,
+                       device=dev)
+  check(lib.rigl_prune_regrow(arr, nl, C.byref(prm), _ptr(counts), _ptr(ws),
+                              ws.numel(), _stream()))
+  return counts
+
+
+def topk_mask(score, n_keep, out=None):
+  """Bitmap of the n_keep largest scores (ties: lower flat index first)."""
+  _req(score, torch.float32, 'score')
+  n = score.numel()
+  if out is None:
+    out = torch.zeros(n_mask_words(n), dtype=torch.int32, device=score.device)
+  lib = _lib.load()
+  ns = (C.c_int64 * 1)(n)
+  ws = workspace(lib.rigl_prune_regrow_workspace_bytes(ns, 1), score.device)
+  check(lib.rigl_topk_mask(_ptr(score), n, int(n_keep), _ptr(out), _ptr(ws),
+                           ws.numel(), _stream()))
+  return out
+
+
+# ----------------------------------------------------------------------------
+# K3
+# ----------------------------------------------------------------------------
+def masked_sgd_momentum(w, grad, lr, momentum=None, mask_bits=None, mu=0.0,
+                        weight_decay=0.0, grad_scale=1.0, nesterov=False,
+                        w_shadow=None):
+  _req(w, torch.float32, 'w')
+  _req(grad, torch.float32, 'grad')
+  _req(momentum, torch.float32, 'momentum', allow_none=True)
+  _req(mask_bits, torch.int32, 'mask_bits', allow_none=True)
+  _req(w_shadow, torch.bfloat16, 'w_shadow', allow_none=True)
+  n = w.numel()
+  if grad.numel() != n or (momentum is not None and momentum.numel() != n):
+    raise ValueError('size mismatch')
+  check(_lib.load().rigl_masked_sgd_momentum(
+      n, _ptr(w), _ptr(momentum), _ptr(grad), _ptr(mask_bits), float(lr),
+      float(mu), float(weight_decay), float(grad_scale), int(bool(nesterov)),
+      _ptr(w_shadow), _stream()))
+
+
+def pack_weights_batched(layers):
+  """layers: list of (w fp32 [k*cout], mask_bits|None, k, cout, hwio|None,
+  ohwi|None)."""
+  nl = len(layers)
+  if nl == 0:
+    return
+  arr = (PackLayer * nl)()
+  for i, (w, bits, k, cout, hwio, ohwi) in enumerate(layers):
+    _req(w, torch.float32, 'w')
+    _req(bits, torch.int32, 'mask_bits', allow_none=True)
+    _req(hwio, torch.bfloat16, 'hwio', allow_none=True)
+    _req(ohwi, torch.bfloat16, 'ohwi', allow_none=True)
+    if w.numel() != k * cout:
+      raise ValueError('pack_weights: w has %d elements, k*cout=%d' %
+                       (w.numel(), k * cout))
+    arr[i].w = w.data_ptr()
+    arr[i].mask_bits = bits.data_ptr() if bits is not None else None
+    arr[i].hwio = hwio.data_ptr() if hwio is not None else None
+    arr[i].ohwi = ohwi.data_ptr() if ohwi is not None else None
+    arr[i].k = k
+    arr[i].cout = cout
+  check(_lib.load().rigl_pack_weights_batched(arr, nl, _stream()))
+
+
+def pack_weights(w, mask_bits, k, cout, hwio=None, ohwi=None):
+  pack_weights_batched([(w, mask_bits, k, cout, hwio, ohwi)])
+
+
+# ----------------------------------------------------------------------------
+# K1
+# ----------------------------------------------------------------------------
+def conv_desc(n, h, w, cin, cout, kh, kw, stride, pad_top, pad_left, ho, wo):
+  sh, sw = (stride, stride) if isinstance(stride, int) else stride
+  return ConvDesc(n, h, w, cin, ho, wo, cout, kh, kw, sh, sw, pad_top,
+                  pad_left)
+
+
+def mfma_supported(d):
+  """Shapes the implicit-GEMM MFMA kernels take (else the direct kernels)."""
+  return d.cout % 8 == 0
+
+
+def mfma_dgrad_supported(d):
+  return d.cout % 8 == 0 and d.cin % 8 == 0
+
+
+def conv_fwd(d, x, w_ohwi, y=None, force_ref=False):
+  """y[N,Ho,Wo,Cout] (bf16, NHWC memory) = conv(x, w)."""
+  _req(x, torch.bfloat16, 'x')
+  _req(w_ohwi, torch.bfloat16, 'w_ohwi')
+  if y is None:
+    y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16,
+                    device=x.device)
+  _req(y, torch.bfloat16, 'y')
+  lib = _lib.load()
+  if force_ref or not mfma_supported(d):
+    check(lib.rigl_conv2d_fwd_ref(C.byref(d), _ptr(x), _ptr(w_ohwi), _ptr(y),
+                                  _stream()))
+    return y
+  need = lib.rigl_conv2d_workspace_bytes(C.byref(d), 0)
+  ws = workspace(need, x.device) if need else None
+  check(lib.rigl_masked_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w_ohwi), _ptr(y),
+                                   _ptr(ws), ws.numel() if ws is not None else 0,
+                                   _stream()))
+  return y
+
+
+def conv_dgrad(d, dy, w_hwio, dx=None, force_ref=False):
+  _req(dy, torch.bfloat16, 'dy')
+  _req(w_hwio, torch.bfloat16, 'w_hwio')
+  if dx is None:
+    dx = torch.empty((d.n, d.h, d.w, d.cin), dtype=torch.bfloat16,
+                     device=dy.device)
+  _req(dx, torch.bfloat16, 'dx')
+  lib = _lib.load()
+  if force_ref or not mfma_dgrad_supported(d):
+    check(lib.rigl_conv2d_dgrad_ref(C.byref(d), _ptr(dy), _ptr(w_hwio),
+                                    _ptr(dx), _stream()))
+    return dx
+  check(lib.rigl_masked_conv2d_dgrad(C.byref(d), _ptr(dy), _ptr(w_hwio),
+                                     _ptr(dx), None, 0, _stream()))
+  return dx
+
+
+def conv_wgrad(d, x, dy, dw=None, force_ref=False):
+  """Dense fp32 dW in HWIO order (flat [kh*kw*cin*cout])."""
+  _req(x, torch.bfloat16, 'x')
+  _req(dy, torch.bfloat16, 'dy')
+  if dw is None:
+    dw = torch.empty(d.kh * d.kw * d.cin * d.cout, dtype=torch.float32,
+                     device=x.device)
+  _req(dw, torch.float32, 'dw')
+  lib = _lib.load()
+  if force_ref or not mfma_supported(d):
+    check(lib.rigl_conv2d_wgrad_ref(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
+                                    _stream()))
+    return dw
+  need = lib.rigl_conv2d_workspace_bytes(C.byref(d), 2)
+  ws = workspace(need, x.device) if need else None
+  check(lib.rigl_masked_conv2d_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
+                                     _ptr(ws),
+                                     ws.numel() if ws is not None else 0,
+                                     _stream()))
+  return dw
+
+
+# ----------------------------------------------------------------------------
+# profiling
+# ----------------------------------------------------------------------------
+def prof_enable(on=True):
+  check(_lib.load().rigl_prof_enable(int(bool(on))))
+
+
+def prof_collect():
+  """{kind: (milliseconds, launches)} accumulated since the last collect."""
+  ms = (C.c_double * len(_lib.PROF_KINDS))()
+  cnt = (C.c_int64 * len(_lib.PROF_KINDS))()
+  check(_lib.load().rigl_prof_collect(ms, cnt))
+  return {k: (ms[i], cnt[i]) for i, k in enumerate(_lib.PROF_KINDS)}

@@ -1,0 +1,247 @@
+"""Parity of K3 (masked SGD-momentum, bit-exact vs the oracle), the weight
+shadow packer, and K1 (MFMA masked conv fwd/dgrad/wgrad vs an fp32 / fp64
+convolution of the same bf16-rounded operands)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+import torch.nn.functional as F  # noqa: E402
+
+from oracle import rigl_oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _t(a):
+  return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32).reshape(-1)).to(DEV)
+
+
+def _bf16_round(a):
+  return torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).float().numpy()
+
+
+# ------------------------------------------------------------------ K3
+@pytest.mark.parametrize('n', [1, 3, 4, 37, 4096, 1000003])
+@pytest.mark.parametrize('nesterov', [True, False])
+def test_masked_momentum_bit_exact(n, nesterov):
+  from rigl_amd import ops
+  rs = np.random.RandomState(n)
+  w = rs.randn(n).astype(np.float32)
+  a = rs.randn(n).astype(np.float32)
+  g = rs.randn(n).astype(np.float32)
+  mask = (rs.rand(n) < 0.2).astype(np.float32)
+  lr, mu, wd = 0.1, 0.9, 1e-4
+  gv = O.masked_grad(g, mask, w, wd)
+  w_ref, a_ref = O.momentum_apply(w, a, gv, lr, mu, nesterov=nesterov)
+  tw, ta, tg = _t(w), _t(a), _t(g)
+  bits = ops.mask_pack(_t(mask))
+  shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+  ops.masked_sgd_momentum(tw, tg, lr, momentum=ta, mask_bits=bits, mu=mu,
+                          weight_decay=wd, nesterov=nesterov, w_shadow=shadow)
+  np.testing.assert_array_equal(tw.cpu().numpy().view(np.uint32), w_ref.view(np.uint32))
+  np.testing.assert_array_equal(ta.cpu().numpy().view(np.uint32), a_ref.view(np.uint32))
+  np.testing.assert_array_equal(shadow.float().cpu().numpy(), _bf16_round(w_ref * mask))
+
+
+def test_dense_sgd_and_grad_scale():
+  from rigl_amd import ops
+  rs = np.random.RandomState(1)
+  n = 5001
+  w, g = rs.randn(n).astype(np.float32), rs.randn(n).astype(np.float32)
+  tw = _t(w)
+  ops.masked_sgd_momentum(tw, _t(g), 0.05)            # plain GD, no mask
+  np.testing.assert_array_equal(tw.cpu().numpy(), O.sgd_apply(w, g, 0.05))
+  # DP mean: grad_scale = 1/world applied before the mask/decay
+  tw, ta = _t(w), _t(np.zeros(n))
+  ops.masked_sgd_momentum(tw, _t(g), 0.05, momentum=ta, mu=0.9, grad_scale=0.125, nesterov=True)
+  w_ref, _ = O.momentum_apply(w, np.zeros(n, np.float32), (g * np.float32(0.125)).astype(np.float32), 0.05, 0.9)
+  np.testing.assert_array_equal(tw.cpu().numpy(), w_ref)
+
+
+def test_trajectory_matches_reference_on_gpu():
+  """The reference's own toy training run (tests/golden/trajectory.npz,
+  produced by executing rigl/sparse_optimizers_base.py) replayed with the HIP
+  kernels: masks, weights, momentum bit-identical at every step."""
+  import os
+  from rigl_amd import ops
+  t = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'trajectory.npz'))
+  for tag, inner, acc in [('rigl_mom', 'mom', 0.0), ('rigl_mom_acc', 'mom', 0.5), ('rigl_sgd', 'sgd', 0.0)]:
+    W, M, GS, FR = t[tag + '__w'], t[tag + '__mask'], t[tag + '__gs'], t[tag + '__frac']
+    n_inp, n_out = W.shape[1:]
+    tw = _t(W[0])
+    bits = ops.mask_pack(_t(M[0]))
+    ta = _t(np.zeros_like(W[0])) if inner == 'mom' else None
+    sched = O.RigLSchedule(1, 17, 4, 0.4, 'cosine')   # scalar host logic only
+    for i in range(len(FR)):
+      gs = sched.global_step
+      dense = np.broadcast_to((np.arange(n_out, dtype=np.float32) * np.float32(gs)).astype(np.float32),
+                              (n_inp, n_out)).astype(np.float32)
+      is_upd, frac = sched.step()
+      if is_upd:
+        ops.prune_regrow([dict(w=tw, momentum=ta, mask_bits=bits, dense_grad=_t(dense))], float(frac),
+                         initial_acc_scale=acc)
+      else:
+        ops.masked_sgd_momentum(tw, _t(dense), 0.01, momentum=ta, mask_bits=bits, mu=0.9, nesterov=True)
+      np.testing.assert_array_equal(ops.mask_unpack(bits, (n_inp * n_out,)).cpu().numpy(),
+                                    M[i + 1].reshape(-1), err_msg='%s step %d' % (tag, i))
+      np.testing.assert_array_equal(tw.cpu().numpy().view(np.uint32), W[i + 1].reshape(-1).view(np.uint32),
+                                    err_msg='%s step %d' % (tag, i))
+      if inner == 'mom':
+        np.testing.assert_array_equal(ta.cpu().numpy(), t[tag + '__mom'][i].reshape(-1))
+
+
+# ------------------------------------------------------------------ pack
+@pytest.mark.parametrize('k,cout', [(64, 64), (147, 64), (9 * 64, 64), (2048, 1000), (100, 10), (1, 8), (4608, 512)])
+def test_pack_weights(k, cout):
+  from rigl_amd import ops
+  rs = np.random.RandomState(k + cout)
+  w = rs.randn(k, cout).astype(np.float32)
+  mask = (rs.rand(k, cout) < 0.3).astype(np.float32)
+  tw = _t(w)
+  bits = ops.mask_pack(_t(mask))
+  hwio = torch.empty(k * cout, dtype=torch.bfloat16, device=DEV)
+  ohwi = torch.empty(k * cout, dtype=torch.bfloat16, device=DEV)
+  ops.pack_weights(tw, bits, k, cout, hwio, ohwi)
+  ref = _bf16_round(w * mask)
+  np.testing.assert_array_equal(hwio.float().cpu().numpy().reshape(k, cout), ref)
+  np.testing.assert_array_equal(ohwi.float().cpu().numpy().reshape(cout, k), ref.T)
+  ops.pack_weights(tw, None, k, cout, hwio, None)       # no mask = dense
+  np.testing.assert_array_equal(hwio.float().cpu().numpy().reshape(k, cout), _bf16_round(w))
+
+
+# ------------------------------------------------------------------ K1
+def _ref_conv(x, w_hwio, dy, stride, pt, pl, ho, wo, dtype=torch.float64, dev='cpu'):
+  """fp64 (or fp32 on GPU) convolution of the bf16-rounded operands.
+  x [N,H,W,C], w [kh,kw,ci,co], dy [N,Ho,Wo,Co] -> y, dx, dw (same layouts)."""
+  N, H, W, C = x.shape
+  kh, kw = w_hwio.shape[:2]
+  pb = max((ho - 1) * stride + kh - H - pt, 0)
+  pr = max((wo - 1) * stride + kw - W - pl, 0)
+  xr = x.to(dev, dtype).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+  wr = w_hwio.to(dev, dtype).permute(3, 2, 0, 1).contiguous().requires_grad_(True)
+  xp = F.pad(xr, (pl, pr, pt, pb))
+  y = F.conv2d(xp, wr, stride=stride)[:, :, :ho, :wo]
+  y.backward(dy.to(dev, dtype).permute(0, 3, 1, 2))
+  return (y.detach().permute(0, 2, 3, 1), xr.grad.permute(0, 2, 3, 1), wr.grad.permute(2, 3, 1, 0))
+
+
+def _check(name, got, ref, scale_ref, rel):
+  """|got - ref| <= rel * scale, scale = sum |a||b| per output (error model of
+  an fp32-accumulated dot product) or the bf16 output rounding."""
+  got = got.double().cpu()
+  ref = ref.double().cpu()
+  err = (got - ref).abs()
+  tol = rel * scale_ref.double().cpu() + 1e-30
+  bad = err > tol
+  if bad.any():
+    idx = bad.nonzero()[:6]
+    raise AssertionError('%s: %d/%d outside tolerance; worst ratio %.3g; first idx %s got %s ref %s' % (
+        name, int(bad.sum()), bad.numel(), float((err / tol).max()), idx.tolist(),
+        got[tuple(idx.T)].tolist(), ref[tuple(idx.T)].tolist()))
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad_top, pad_left, Ho, Wo
+    (2, 14, 14, 64, 64, 1, 1, 0, 0, 14, 14),        # 1x1
+    (2, 14, 14, 64, 256, 1, 1, 0, 0, 14, 14),       # 1x1 expand
+    (2, 14, 14, 256, 64, 1, 1, 0, 0, 14, 14),       # 1x1 reduce
+    (3, 14, 14, 256, 512, 1, 2, 0, 0, 7, 7),        # projection shortcut, stride 2 (fixed_padding k=1 -> none)
+    (2, 14, 14, 64, 64, 3, 1, 1, 1, 14, 14),        # 3x3 SAME
+    (2, 14, 14, 128, 128, 3, 2, 1, 1, 7, 7),        # 3x3 stride 2, fixed_padding (1,1) + VALID
+    (2, 16, 16, 32, 32, 3, 2, 0, 0, 8, 8),          # TF SAME stride 2: pads (0,1) -- WRN
+    (2, 9, 11, 16, 48, 3, 1, 1, 1, 9, 11),          # odd sizes, small channels (BK=16)
+    (2, 32, 32, 3, 64, 7, 2, 3, 3, 16, 16),         # 7x7/2 stem, Cin=3 -> im2col path
+    (2, 32, 32, 3, 16, 3, 1, 1, 1, 32, 32),         # WRN stem
+    (5, 1, 1, 2048, 1000, 1, 1, 0, 0, 1, 1),        # final_dense as 1x1 conv
+    (1, 7, 7, 512, 512, 3, 1, 1, 1, 7, 7),          # late 3x3
+    (2, 10, 10, 40, 72, 3, 1, 1, 1, 10, 10),        # channels % 8 == 0 but not % 16/32/64
+    (130, 4, 4, 64, 64, 3, 1, 1, 1, 4, 4),          # many images, M not a tile multiple
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case):
+  from rigl_amd import ops
+  N, H, W, Cin, Cout, k, stride, pt, pl, Ho, Wo = case
+  g = torch.Generator().manual_seed(sum(case))
+  x = torch.randn(N, H, W, Cin, generator=g).to(torch.bfloat16)
+  dy = torch.randn(N, Ho, Wo, Cout, generator=g).to(torch.bfloat16)
+  w = torch.randn(k, k, Cin, Cout, generator=g) * (2.0 / (k * k * Cin)) ** 0.5
+  mask = (torch.rand(k, k, Cin, Cout, generator=g) < 0.3).float()
+  d = ops.conv_desc(N, H, W, Cin, Cout, k, k, stride, pt, pl, Ho, Wo)
+  n = k * k * Cin * Cout
+  tw = w.reshape(-1).contiguous().to(DEV)
+  bits = ops.mask_pack(mask.reshape(-1).contiguous().to(DEV))
+  hwio = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+  ohwi = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+  ops.pack_weights(tw, bits, k * k * Cin, Cout, hwio, ohwi)
+  wm = hwio.float().cpu().reshape(k, k, Cin, Cout)          # bf16(mask*w), the operand actually used
+  yr, dxr, dwr = _ref_conv(x.float(), wm, dy.float(), stride, pt, pl, Ho, Wo)
+  ya, dxa, dwa = _ref_conv(x.float().abs(), wm.abs(), dy.float().abs(), stride, pt, pl, Ho, Wo)
+  xd, dyd = x.to(DEV), dy.to(DEV)
+  # fwd / dgrad: bf16 outputs -> half-ulp of bf16 on the result + fp32 accumulation noise
+  y = ops.conv_fwd(d, xd, ohwi)
+  _check('fwd', y.float(), yr, yr.abs() * 2.0**-8 + ya * 1e-5, 1.0)
+  if Cin % 8 == 0:
+    dx = ops.conv_dgrad(d, dyd, hwio)
+    _check('dgrad', dx.float(), dxr, dxr.abs() * 2.0**-8 + dxa * 1e-5, 1.0)
+  # wgrad: fp32 output, tolerance 1e-5 relative to sum|x||dy| (north-star: 1e-5 fp32)
+  dw = ops.conv_wgrad(d, xd, dyd).reshape(k, k, Cin, Cout)
+  _check('wgrad', dw, dwr, dwa, 1e-5)
+  # the direct kernels must agree too (independent on-device cross-check)
+  y2 = ops.conv_fwd(d, xd, ohwi, force_ref=True)
+  _check('fwd_ref', y2.float(), yr, yr.abs() * 2.0**-8 + ya * 1e-5, 1.0)
+  if N * H * W * Cin <= 200000:
+    dx2 = ops.conv_dgrad(d, dyd, hwio, force_ref=True)
+    _check('dgrad_ref', dx2.float(), dxr, dxr.abs() * 2.0**-8 + dxa * 1e-5, 1.0)
+    dw2 = ops.conv_wgrad(d, xd, dyd, force_ref=True).reshape(k, k, Cin, Cout)
+    _check('wgrad_ref', dw2, dwr, dwa, 1e-5)
+
+
+def test_conv_asymmetric_b_detects_transposes():
+  """A = identity-like activations, asymmetric weights: catches swapped
+  rows/cols in the MFMA C/D mapping (guide rule 16)."""
+  from rigl_amd import ops
+  N, H, W, Cin, Cout = 1, 8, 16, 128, 128
+  x = torch.zeros(N, H, W, Cin)
+  for p in range(H * W):
+    x.view(-1, Cin)[p, p % Cin] = 1.0
+  w = (torch.arange(Cin).view(Cin, 1) * 3 + torch.arange(Cout).view(1, Cout) * 7).float() % 61 - 30
+  d = ops.conv_desc(N, H, W, Cin, Cout, 1, 1, 1, 0, 0, H, W)
+  ohwi = w.t().contiguous().to(torch.bfloat16).to(DEV).reshape(-1)
+  y = ops.conv_fwd(d, x.to(torch.bfloat16).to(DEV), ohwi).float().cpu().view(-1, Cout)
+  ref = x.view(-1, Cin) @ w
+  assert torch.equal(y, ref)
+
+
+@pytest.mark.parametrize('shape', [
+    (32, 56, 56, 64, 64, 3, 1, 1, 1, 56, 56),
+    (32, 56, 56, 256, 128, 1, 1, 0, 0, 56, 56),
+    (32, 28, 28, 512, 1024, 1, 2, 0, 0, 14, 14),
+    (32, 14, 14, 256, 256, 3, 1, 1, 1, 14, 14),
+    (32, 224, 224, 3, 64, 7, 2, 3, 3, 112, 112),
+])
+def test_conv_resnet50_sizes_vs_gpu_fp32(shape):
+  """ResNet-50 layer shapes at batch 32 against torch's fp32 convolution on the
+  same GPU (independent implementation), same bf16-rounded operands."""
+  from rigl_amd import ops
+  N, H, W, Cin, Cout, k, stride, pt, pl, Ho, Wo = shape
+  g = torch.Generator(device=DEV).manual_seed(1)
+  x = torch.randn(N, H, W, Cin, generator=g, device=DEV).to(torch.bfloat16)
+  dy = torch.randn(N, Ho, Wo, Cout, generator=g, device=DEV).to(torch.bfloat16)
+  w = (torch.randn(k, k, Cin, Cout, generator=g, device=DEV) * (2.0 / (k * k * Cin)) ** 0.5)
+  d = ops.conv_desc(N, H, W, Cin, Cout, k, k, stride, pt, pl, Ho, Wo)
+  n = w.numel()
+  hwio = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+  ohwi = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+  ops.pack_weights(w.reshape(-1).contiguous(), None, k * k * Cin, Cout, hwio, ohwi)
+  wm = hwio.float().reshape(k, k, Cin, Cout)
+  yr, dxr, dwr = _ref_conv(x.float(), wm, dy.float(), stride, pt, pl, Ho, Wo, dtype=torch.float32, dev=DEV)
+  y = ops.conv_fwd(d, x, ohwi).float()
+  assert (y - yr).abs().max() <= 2.0**-7 * yr.abs().max()
+  dw = ops.conv_wgrad(d, x, dy).reshape(k, k, Cin, Cout)
+  assert (dw - dwr).abs().max() <= 2e-4 * dwr.abs().max()      # both sides are fp32 accumulations
+  if Cin % 8 == 0:
+    dx = ops.conv_dgrad(d, dy, hwio).float()
+    assert (dx - dxr).abs().max() <= 2.0**-7 * dxr.abs().max()
