@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the ResNet-50 80 %-ERK RigL training step
+(BASELINE.json metric) on N MI355X of one node, synthetic ImageNet-shaped data.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one call of ``SparseRigLOptimizer.minimize`` on a per-GPU batch of
+128 images: masked-conv forward + backward (HIP MFMA kernels), DP all-reduce of
+the dense gradient arena (RCCL), then either the fused masked Nesterov update
+(K3) or -- every 100th step -- the fused prune/regrow mask update (K2).
+Nothing is skipped inside the timed region; inputs are resident in HBM.
+
+Rank 0 prints ONE JSON line (contract in the task statement) that also carries
+  "roofline":     achieved dense-equivalent conv TFLOP/s vs the 2.5 PF bf16 MFMA
+                  peak, from HIP events recorded around every K1 launch on the
+                  launch stream during the timed region (rigl_prof_*);
+  "cpu_baseline": the fp32 CPU restatement of the same step (oracle/, "port"),
+                  timed on a bounded sample on this host's cores (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=100)
+  ap.add_argument('--warmup', type=int, default=20)
+  ap.add_argument('--batch', type=int, default=128, help='per-GPU batch')
+  ap.add_argument('--sparsity', type=float, default=0.8)
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-prof', action='store_true')
+  args = ap.parse_args()
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', device_id=dev)
+  assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+
+  import numpy as np
+  from rigl_amd import ops, sparse_optimizers, sparse_utils, train, variables
+  from rigl_amd.dist import GradSync
+  from rigl_amd.workloads import resnet50, shapes
+
+  # ---- build: ResNet-50, all 54 kernels masked, ERK(-kernel) 0.8 (README.md:84-90)
+  g = variables.reset_default_graph(dev)
+  model = resnet50.ResNet50(g, seed=0)
+  np.random.seed(0)                       # identical masks on every rank
+  sparse_utils.get_mask_init_fn(g.get_masks(), 'erdos_renyi_kernel', args.sparsity, {})()
+  sync = GradSync(g) if world > 1 else None
+  global_batch = args.batch * world
+  lr = 0.1 * global_batch / 256.0          # imagenet_train_eval.py:317-330 (peak LR)
+  inner = train.MomentumOptimizer(lr, 0.9, use_nesterov=True, graph=g, grad_sync=sync)
+  opt = sparse_optimizers.SparseRigLOptimizer(
+      inner, begin_step=0, end_step=25000, frequency=100, drop_fraction=0.3,
+      drop_fraction_anneal='cosine', grow_init='zeros', initial_acc_scale=0.0,
+      use_tpu=world > 1)
+  gs = g.get_or_create_global_step()
+  images, labels = resnet50.synthetic_batch(args.batch, dev, seed=1234 + rank)
+
+  def step():
+    loss = model.loss(images, labels, label_smoothing=0.1)
+    opt.minimize(loss, gs)
+    return loss
+
+  def fence():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    step()
+  fence()
+  if not args.no_prof:
+    ops.prof_collect()
+    ops.prof_enable(True)
+  updates_before = None
+  t0 = time.perf_counter()
+  n_updates = 0
+  for _ in range(args.steps):
+    before = gs.value
+    step()
+    n_updates += int(gs.value == before)
+  fence()
+  dt = time.perf_counter() - t0
+  prof = None
+  if not args.no_prof:
+    ops.prof_enable(False)
+    prof = ops.prof_collect()
+  t = torch.tensor([dt], dtype=torch.float64, device=dev)
+  if world > 1:
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  dt = float(t.item())
+  ms_per_step = dt / args.steps * 1e3
+  value = global_batch * args.steps / dt
+
+  if rank == 0:
+    fwd_macs, dgrad_macs = shapes.resnet50_macs_per_image()
+    flops_per_step = 2.0 * (2 * fwd_macs + dgrad_macs) * args.batch   # per GPU, dense-equivalent
+    out = {
+        'metric': 'images/sec/node, ResNet-50 80% ERK RigL step',
+        'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'ResNet-50 v1.5, ERK(kernel) %.2f sparse, 54 masked tensors, RigL dT=100 '
+                               'drop 0.3 cosine, Nesterov 0.9, wd 1e-4, label smoothing 0.1, 224x224x3 NHWC'
+                               % args.sparsity,
+                   'global_batch': global_batch, 'per_gpu_batch': args.batch,
+                   'parallelism': 'dp%d' % world, 'mask_updates_in_timed_region': n_updates},
+    }
+    if prof is not None:
+      conv_ms = sum(prof[k][0] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad'))
+      launches = sum(prof[k][1] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad'))
+      n_fwd_bwd = args.steps               # every step (update or not) runs fwd + bwd
+      achieved = flops_per_step * n_fwd_bwd / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+      out['roofline'] = {
+          'bound': 'mfma', 'achieved': achieved, 'peak': 2500.0, 'unit': 'TFLOP/s',
+          'frac': achieved / 2500.0, 'traffic': None,
+          'kernel': 'K1 masked conv implicit-GEMM (fwd+dgrad+wgrad), all %d launches of the timed region' % launches,
+          'algorithmic_gflop_per_image': flops_per_step / args.batch / 1e9,
+          'avg_launch_ms': conv_ms / max(launches, 1),
+          'conv_ms_per_step': conv_ms / n_fwd_bwd,
+          'by_kind_ms_per_step': {k: prof[k][0] / n_fwd_bwd for k in prof},
+          'conv_share_of_step': (conv_ms / n_fwd_bwd) / ms_per_step,
+      }
+    if world == 1 and not args.no_cpu_baseline:
+      try:
+        from oracle import resnet_cpu
+        out['cpu_baseline'] = resnet_cpu.time_cpu_baseline(batch=8, steps=2)
+      except Exception as e:  # pylint: disable=broad-except
+        out['cpu_baseline'] = {'value': None, 'unit': 'images/sec', 'cores': os.cpu_count(), 'kind': 'port',
+                               'sample': 'failed: %r' % (e,)}
+    print(json.dumps(out))
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

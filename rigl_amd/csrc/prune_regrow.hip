@@ -16,6 +16,11 @@
 
 #include "common.hpp"
 
+// Bit-exact parity with the reference arithmetic: every fp32 product / sum is
+// rounded separately.  HIP's __fmul_rn/__fadd_rn are plain operators, so the
+// default -ffp-contract=fast would fuse them into v_fma (1-ulp differences).
+#pragma clang fp contract(off)
+
 namespace rigl {
 namespace k2 {
 

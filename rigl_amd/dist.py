@@ -1,0 +1,118 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL over xGMI via
+``torch.distributed`` (backend "nccl" IS RCCL on ROCm; "gloo" in CPU tests).
+
+What the reference does: ``CrossShardOptimizer`` sums every
+variable gradient over replicas with the loss pre-divided by the replica count
+(imagenet_train_eval.py:363-365) and RigL sums the DENSE masked-weight
+gradients (``cross_replica_sum``, sparse_optimizers_base.py:472-473) so every
+replica derives the same mask with no mask traffic.
+
+MI355X-first design: both exchanges are the SAME buffer here -- the dense
+gradient arena ``Graph.G`` -- so one all-reduce per step serves the weight
+update and (on update steps) the grow scores.  The arena is reduced in a few
+large buckets (default 32 MB: xGMI is point-to-point, large messages amortise
+per-link latency) launched from inside the backward pass as soon as the
+layers of a bucket have produced their gradients (backward walks the arena
+from its end to its start), so communication overlaps the remaining backward
+kernels.  The mean (1/world) is folded into the update kernel's ``grad_scale``;
+the mask update consumes the raw sum, like the reference.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+
+  def __init__(self, graph, bucket_bytes=32 << 20, group=None, enabled=None):
+    self.graph = graph
+    self.group = group
+    self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+    self.enabled = (self.world > 1) if enabled is None else enabled
+    self.grad_scale = 1.0 / self.world
+    self.bucket_elems = max(int(bucket_bytes) // 4, 1)
+    self._handles = []
+    self._hi = None       # arena index above which everything is already sent
+    self._vars = None     # kernel variables sorted by arena offset
+    self._ptr = -1        # highest-offset variable not yet produced
+    self._ready = set()
+    self.n_buckets_last = 0
+    graph.grad_sync = self
+
+  def _kernel_end(self):
+    from rigl_amd import variables as V  # pylint: disable=import-outside-toplevel
+    return self.graph.seg[V.KIND_DENSE][1] if self.graph.finalized else 0
+
+  def _begin_step(self):
+    from rigl_amd import variables as V  # pylint: disable=import-outside-toplevel
+    self._vars = sorted((v for v in self.graph.trainable_variables()
+                         if v.kind in (V.KIND_MASKED, V.KIND_DENSE)),
+                        key=lambda v: v.offset)
+    self._ptr = len(self._vars) - 1
+    self._ready = set()
+    self._hi = self._kernel_end()
+    self._handles = []
+
+  def _reset(self):
+    self._hi = None
+    self._handles = []
+
+  # called by the masked-layer autograd bridge right after wgrad is enqueued
+  def notify_layer_grad_ready(self, var):
+    """Backward produces kernel gradients from the end of the arena towards
+    its start; a bucket is sent as soon as a contiguous tail of at least
+    ``bucket_elems`` has been produced (out-of-order arrivals just wait)."""
+    if not self.enabled:
+      return
+    if self._hi is None:
+      self._begin_step()
+    self._ready.add(var.offset)
+    lo = None
+    while self._ptr >= 0 and self._vars[self._ptr].offset in self._ready:
+      lo = self._vars[self._ptr].offset
+      self._ptr -= 1
+    if lo is not None and self._hi - lo >= self.bucket_elems:
+      self._launch(lo, self._hi)
+      self._hi = lo
+
+  def _launch(self, lo, hi):
+    if hi > lo:
+      self._handles.append(dist.all_reduce(self.graph.G[lo:hi], group=self.group, async_op=True))
+
+  def all_reduce(self, graph=None):
+    """Called once after backward: flushes what is left (the head of the kernel
+    segment, the BN/bias segment) and makes the compute stream wait."""
+    del graph
+    if not self.enabled:
+      self._reset()
+      return
+    g = self.graph
+    kend = self._kernel_end()
+    hi = self._hi if self._hi is not None else kend
+    self._launch(0, hi)                                   # remaining kernels
+    self._launch(kend, g.G.numel())                       # BN / bias segment
+    self.n_buckets_last = len(self._handles)
+    for h in self._handles:
+      h.wait()                                            # stream-level wait on GPU
+    self._reset()
+
+  def check_masks_identical(self):
+    """Debug guard: every rank must hold the same bitmap."""
+    if self.world <= 1:
+      return True
+    bits = self.graph.BITS.to(torch.int64)
+    chk = (bits * torch.arange(1, bits.numel() + 1, device=bits.device)).sum().reshape(1)
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+    return bool((lo == hi).item())
+
+
+def broadcast_drop_fraction(value, src=0, group=None):
+  """The drop fraction is a pure function of global_step; this 4-byte broadcast
+  is the safety net the north star asks for (rank 0 is authoritative)."""
+  if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    return float(value)
+  dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+  t = torch.tensor([float(value)], dtype=torch.float32, device=dev)
+  dist.broadcast(t, src=src, group=group)
+  return float(t.item())

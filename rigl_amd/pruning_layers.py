@@ -1,0 +1,299 @@
+"""The masked-layer boundary: ``sparse_conv2d`` / ``sparse_fully_connected``.
+
+Mirrors rigl/imagenet_resnet/pruning_layers.py:72-248 (same argument names,
+same ``sparsity_technique`` values, same ValueErrors) on top of the HIP
+kernels: ``sparsity_technique='threshold'`` creates `{scope}/weights` and
+`{scope}/mask` exactly like contrib's ``masked_conv2d`` (mask initialised to
+ones, y = conv(x, mask * W)); ``'baseline'`` creates a dense layer.
+
+Activations are NHWC bf16 tensors ([N,H,W,C] contiguous) -- the reference's
+``channels_last`` default and bfloat16 scope (imagenet_train_eval.py:92-98,
+549-552).  Weights are fp32 HWIO variables of the graph (variables.py).  The
+autograd bridge calls the C ABI: forward = rigl_masked_conv2d_fwd, backward =
+rigl_masked_conv2d_dgrad + rigl_masked_conv2d_wgrad; the DENSE dW goes
+straight into the layer's slice of the gradient arena (RigL needs it dense,
+sparse_optimizers_base.py:478-485) -- there is no PyTorch fallback.
+"""
+import math
+
+import numpy as np
+import torch
+
+from rigl_amd import ops
+from rigl_amd import variables as V
+
+
+def _same_pad(size, k, stride):
+  """TF 'SAME': out = ceil(size/stride), pad_total = max((out-1)*s + k - size, 0),
+  pad_begin = pad_total // 2 (the extra pixel goes at the end)."""
+  out = -(-size // stride)
+  total = max((out - 1) * stride + k - size, 0)
+  return out, total // 2
+
+
+def _valid_out(size, k, stride):
+  return (size - k) // stride + 1
+
+
+class _MaskedConvFn(torch.autograd.Function):
+  """y = conv(x, mask*W) with dense dW written into lv.weights.grad."""
+
+  @staticmethod
+  def forward(ctx, x, lv, desc, need_dx):
+    ctx.lv, ctx.desc, ctx.need_dx = lv, desc, need_dx
+    ctx.save_for_backward(x)
+    return ops.conv_fwd(desc, x, lv.ohwi)
+
+  @staticmethod
+  def backward(ctx, dy):
+    (x,) = ctx.saved_tensors
+    lv, d = ctx.lv, ctx.desc
+    dy = dy.contiguous()
+    # dense dL/d(mask*W), fp32 HWIO, into this layer's slice of the G arena
+    ops.conv_wgrad(d, x, dy, lv.weights.grad.view(-1))
+    sync = getattr(lv.weights.graph, 'grad_sync', None)
+    if sync is not None:
+      sync.notify_layer_grad_ready(lv.weights)   # DP: overlap the all-reduce
+    dx = None
+    if ctx.need_dx:
+      dx = ops.conv_dgrad(d, dy, lv.hwio)
+    return dx, None, None, None
+
+
+class _Layer:
+  """Common part of MaskedConv2d / MaskedDense."""
+
+  def __init__(self, graph, scope, shape, sparsity_technique, weight_decay,
+               kernel_initializer):
+    if sparsity_technique not in ('threshold', 'baseline'):
+      raise ValueError(
+          'Unsupported sparsity technique {}'.format(sparsity_technique))
+    self.graph = graph
+    self.scope = scope
+    self.masked = sparsity_technique == 'threshold'
+    init = kernel_initializer(shape) if kernel_initializer is not None else \
+        variance_scaling_initializer()(shape)
+    self.vars = graph.add_masked_layer(scope, shape, self.masked, weight_decay,
+                                       init)
+    self.bias = None
+
+  @property
+  def weights(self):
+    return self.vars.weights
+
+  @property
+  def mask(self):
+    return self.vars.mask
+
+
+class MaskedConv2d(_Layer):
+  """masked_conv2d / tf.layers.conv2d twin (pruning_layers.py:139-169)."""
+
+  def __init__(self, graph, scope, cin, units, kernel_size, strides=(1, 1),
+               padding='SAME', sparsity_technique='baseline', weight_decay=0.0,
+               kernel_initializer=None, need_input_grad=True):
+    kh, kw = kernel_size
+    super().__init__(graph, scope, (kh, kw, cin, units), sparsity_technique,
+                     weight_decay, kernel_initializer)
+    if padding not in ('SAME', 'VALID'):
+      raise ValueError('padding must be SAME or VALID')
+    self.cin, self.units, self.kh, self.kw = cin, units, kh, kw
+    self.strides = tuple(strides)
+    self.padding = padding
+    self.need_input_grad = need_input_grad
+    self._descs = {}
+
+  def desc_for(self, n, h, w):
+    key = (n, h, w)
+    d = self._descs.get(key)
+    if d is None:
+      sh, sw = self.strides
+      if self.padding == 'SAME':
+        ho, pt = _same_pad(h, self.kh, sh)
+        wo, pl = _same_pad(w, self.kw, sw)
+      else:
+        ho, pt = _valid_out(h, self.kh, sh), 0
+        wo, pl = _valid_out(w, self.kw, sw), 0
+      d = ops.conv_desc(n, h, w, self.cin, self.units, self.kh, self.kw,
+                        (sh, sw), pt, pl, ho, wo)
+      self._descs[key] = d
+    return d
+
+  def __call__(self, x):
+    if x.dim() != 4:
+      raise ValueError('Rank not supported {}'.format(x.dim()))
+    if x.shape[-1] != self.cin:
+      raise ValueError('expected %d input channels, got %d' %
+                       (self.cin, x.shape[-1]))
+    self.graph.refresh_shadows()
+    n, h, w, _ = x.shape
+    d = self.desc_for(n, h, w)
+    need_dx = self.need_input_grad and x.requires_grad
+    if not x.requires_grad:
+      x = x.detach().requires_grad_(True)  # keep the node so wgrad runs
+    return _MaskedConvFn.apply(x.contiguous(), self.vars, d, need_dx)
+
+
+class MaskedDense(_Layer):
+  """masked_fully_connected / tf.layers.dense twin (pruning_layers.py:222-245):
+  y = x @ (mask*W) + b, weights [in, out]; runs as a 1x1 conv."""
+
+  def __init__(self, graph, scope, n_in, units, use_bias=True,
+               sparsity_technique='baseline', weight_decay=0.0,
+               kernel_initializer=None, activation=None):
+    super().__init__(graph, scope, (n_in, units), sparsity_technique,
+                     weight_decay, kernel_initializer)
+    self.n_in, self.units = n_in, units
+    self.activation = activation
+    self._descs = {}
+    if use_bias:
+      b = graph.add_variable(scope + '/biases', (units,), V.KIND_OTHER, 0.0)
+      b.data.requires_grad_(True)
+      self.bias = b
+
+  def __call__(self, x):
+    if x.shape[-1] != self.n_in:
+      raise ValueError('expected %d inputs, got %d' % (self.n_in, x.shape[-1]))
+    self.graph.refresh_shadows()
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, 1, 1, self.n_in)
+    b = x2.shape[0]
+    d = self._descs.get(b)
+    if d is None:
+      d = ops.conv_desc(b, 1, 1, self.n_in, self.units, 1, 1, 1, 0, 0, 1, 1)
+      self._descs[b] = d
+    need_dx = x2.requires_grad
+    if not x2.requires_grad:
+      x2 = x2.detach().requires_grad_(True)
+    y = _MaskedConvFn.apply(x2.contiguous(), self.vars, d, need_dx)
+    y = y.reshape(*lead, self.units)
+    if self.bias is not None:
+      y = y + bias_tensor(self.bias).to(y.dtype)
+    if self.activation is not None:
+      y = self.activation(y)
+    return y
+
+
+def bias_tensor(var):
+  """A leaf tensor aliasing the variable's storage whose .grad IS the
+  variable's slice of the gradient arena (autograd accumulates in place)."""
+  t = var.data
+  if not t.requires_grad:
+    t.requires_grad_(True)
+  if t.grad is None or t.grad.data_ptr() != var.grad.data_ptr():
+    t.grad = var.grad
+  return t
+
+
+# ----------------------------------------------------------------------------
+# initializers (host side, NumPy; shapes are HWIO / [in, out])
+# ----------------------------------------------------------------------------
+_init_rng = np.random.RandomState(0)
+
+
+def set_init_seed(seed):
+  global _init_rng
+  _init_rng = np.random.RandomState(seed)
+
+
+def variance_scaling_initializer(scale=1.0):
+  """tf.variance_scaling_initializer(scale): fan_in, truncated normal
+  (resnet_model.py:283)."""
+
+  def init(shape):
+    fan_in = int(np.prod(shape[:-1]))
+    std = math.sqrt(scale / max(1.0, fan_in)) / .87962566103423978
+    v = _init_rng.randn(*shape)
+    bad = np.abs(v) > 2
+    while bad.any():
+      v[bad] = _init_rng.randn(int(bad.sum()))
+      bad = np.abs(v) > 2
+    return (v * std).astype(np.float32)
+
+  return init
+
+
+def random_normal_initializer(stddev=0.01):
+  return lambda shape: (_init_rng.randn(*shape) * stddev).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------
+# the reference's functional API
+# ----------------------------------------------------------------------------
+def _regularizer_scale(reg):
+  """kernel_regularizer may be a float (l2 scale) or an object with .scale."""
+  if reg is None:
+    return 0.0
+  if isinstance(reg, (int, float)):
+    return float(reg)
+  return float(getattr(reg, 'scale'))
+
+
+class l2_regularizer:  # pylint: disable=invalid-name
+  """contrib_layers.l2_regularizer(scale): scale * sum(w^2) / 2; its gradient
+  (scale * w) is applied inside the fused update kernel (K3)."""
+
+  def __init__(self, scale):
+    self.scale = float(scale)
+
+
+def sparse_conv2d(x, units, kernel_size, activation=None, use_bias=False,
+                  kernel_initializer=None, kernel_regularizer=None,
+                  bias_initializer=None, biases_regularizer=None,
+                  sparsity_technique='baseline', normalizer_fn=None,
+                  strides=(1, 1), padding='SAME', data_format='channels_last',
+                  name=None, graph=None):
+  """rigl/imagenet_resnet/pruning_layers.py:72-172.  Variables are created on
+  the first call for a scope and reused afterwards (tf.variable_scope)."""
+  del bias_initializer, biases_regularizer
+  if data_format == 'channels_last':
+    pass
+  elif data_format == 'channels_first':
+    raise ValueError('channels_first is not supported by the NHWC kernels')
+  else:
+    raise ValueError('Not a valid channel string:', data_format)
+  if x.dim() != 4:
+    raise ValueError('Rank not supported {}'.format(x.dim()))
+  if sparsity_technique not in ('threshold', 'baseline'):
+    raise ValueError(
+        'Unsupported sparsity technique {}'.format(sparsity_technique))
+  if use_bias:
+    raise ValueError('use_bias=True is not used by the reference models')
+  g = graph or V.get_default_graph()
+  key = name
+  layer = g.modules.get(key) if key is not None else None
+  if layer is None:
+    scope = g.unique_scope(name, 'Conv')
+    layer = MaskedConv2d(g, scope, x.shape[-1], units, tuple(kernel_size),
+                         tuple(strides), padding, sparsity_technique,
+                         _regularizer_scale(kernel_regularizer),
+                         kernel_initializer)
+    g.modules[scope] = layer
+  y = layer(x)
+  if normalizer_fn is not None:
+    y = normalizer_fn(y)
+  if activation is not None:
+    y = activation(y)
+  return y
+
+
+def sparse_fully_connected(x, units, activation=None, use_bias=True,
+                           kernel_initializer=None, kernel_regularizer=None,
+                           bias_initializer=None, biases_regularizer=None,
+                           sparsity_technique='baseline', name=None,
+                           graph=None):
+  """rigl/imagenet_resnet/pruning_layers.py:175-248."""
+  del bias_initializer, biases_regularizer
+  if sparsity_technique not in ('threshold', 'baseline'):
+    raise ValueError(
+        'Unsupported sparsity technique {}'.format(sparsity_technique))
+  g = graph or V.get_default_graph()
+  layer = g.modules.get(name) if name is not None else None
+  if layer is None:
+    scope = g.unique_scope(name, 'Dense')
+    layer = MaskedDense(g, scope, x.shape[-1], units, use_bias,
+                        sparsity_technique,
+                        _regularizer_scale(kernel_regularizer),
+                        kernel_initializer, activation)
+    g.modules[scope] = layer
+  return layer(x)

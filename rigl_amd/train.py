@@ -1,0 +1,170 @@
+"""Inner optimizers with the tf.train.Optimizer surface the reference wraps
+(``compute_gradients`` / ``apply_gradients`` / ``minimize`` / slots), executing
+on the fused HIP update kernel (K3, rigl_masked_sgd_momentum).
+
+  tf.train.MomentumOptimizer(lr, momentum, use_nesterov=True)
+      rigl/imagenet_resnet/imagenet_train_eval.py:360-361,
+      rigl/cifar_resnet/resnet_train_eval.py:202-203, mnist_train_eval.py:263
+  tf.train.GradientDescentOptimizer(lr)      rigl/sparse_optimizers_test.py:44
+
+Eager twin of the TF1 graph API: ``compute_gradients(loss)`` runs the backward
+pass (the masked-layer autograd bridge deposits DENSE kernel gradients in the
+gradient arena); ``apply_gradients`` enqueues one update launch per arena
+segment:  masked kernels (bitmap, weight decay) | dense kernels | BN & biases.
+The l2 regulariser's gradient (scale * w on the raw variable) is
+applied inside the kernel rather than through the loss.
+"""
+import torch
+
+from rigl_amd import ops
+from rigl_amd import variables as V
+
+
+def get_or_create_global_step(graph=None):
+  return (graph or V.get_default_graph()).get_or_create_global_step()
+
+
+def _lr_value(lr, global_step):
+  if callable(lr):
+    return float(lr(int(global_step.value) if global_step is not None else 0))
+  return float(lr)
+
+
+class Optimizer:
+  """Minimal tf.train.Optimizer base."""
+
+  def __init__(self, use_locking=False, name='Optimizer', graph=None):
+    self._use_locking = use_locking
+    self._name = name
+    self._graph = graph
+
+  @property
+  def graph(self):
+    return self._graph or V.get_default_graph()
+
+  def get_slot_names(self):
+    return []
+
+  def get_slot(self, var, name):
+    raise KeyError(name)
+
+  def minimize(self, loss, global_step=None, var_list=None, **kwargs):
+    grads_and_vars = self.compute_gradients(loss, var_list=var_list, **kwargs) \
+        if var_list is not None else self.compute_gradients(loss, **kwargs)
+    return self.apply_gradients(grads_and_vars, global_step=global_step)
+
+
+class GradientDescentOptimizer(Optimizer):
+  """w -= lr * g  (g = mask * dense_grad + wd * w for masked kernels)."""
+
+  def __init__(self, learning_rate, use_locking=False,
+               name='GradientDescent', graph=None, grad_sync=None):
+    super().__init__(use_locking, name, graph)
+    self._lr = learning_rate
+    self._momentum = None
+    self._nesterov = False
+    self._slot = None              # flat momentum arena (same layout as W)
+    self._grad_sync = grad_sync    # rigl_amd.dist.GradSync or None
+    self._backward_done_for = None
+
+  # ---- gradients -------------------------------------------------------------
+  def compute_gradients(self, loss, var_list=None, **kwargs):
+    """Returns [(grad, var)].  With ``var_list`` = the masked weights (RigL's
+    second call, sparse_optimizers_base.py:481-482) the DENSE gradients are
+    returned -- they are a by-product of the same backward pass."""
+    del kwargs
+    g = self.graph
+    g.finalize()
+    if loss is not None and self._backward_done_for is not loss:
+      g.zero_other_grads()
+      loss.backward()
+      self._backward_done_for = loss
+      if self._grad_sync is not None:
+        self._grad_sync.all_reduce(g)
+    if var_list is not None:
+      return [(v.grad, v) for v in var_list]
+    return [(v.grad, v) for v in g.trainable_variables()]
+
+  # ---- update ----------------------------------------------------------------
+  def _ensure_slots(self):
+    pass
+
+  def apply_gradients(self, grads_and_vars, global_step=None, name=None):
+    del grads_and_vars, name  # gradients live in the arena the kernels read
+    g = self.graph
+    g.finalize()
+    self._ensure_slots()
+    lr = _lr_value(self._lr, global_step)
+    scale = self._grad_sync.grad_scale if self._grad_sync is not None else 1.0
+    mu = float(self._momentum) if self._momentum is not None else 0.0
+    # one launch per segment; weight decay is uniform inside a kernel segment
+    for kind in (V.KIND_MASKED, V.KIND_DENSE):
+      b, e = g.seg[kind]
+      if e <= b:
+        continue
+      wds = {v.weight_decay for v in g.trainable_variables() if v.kind == kind}
+      if len(wds) > 1:
+        self._apply_per_variable(kind, lr, mu, scale)
+        continue
+      wd = wds.pop() if wds else 0.0
+      ops.masked_sgd_momentum(
+          g.W[b:e], g.G[b:e], lr,
+          momentum=self._slot[b:e] if self._slot is not None else None,
+          mask_bits=g.BITS[b // 32:e // 32] if kind == V.KIND_MASKED else None,
+          mu=mu, weight_decay=wd, grad_scale=scale, nesterov=self._nesterov)
+    b, e = g.seg[V.KIND_OTHER]
+    if e > b:
+      ops.masked_sgd_momentum(
+          g.W[b:e], g.G[b:e], lr,
+          momentum=self._slot[b:e] if self._slot is not None else None,
+          mu=mu, weight_decay=0.0, grad_scale=scale, nesterov=self._nesterov)
+    g.shadows_dirty = True
+    self._backward_done_for = None
+    if global_step is not None:
+      global_step.value += 1
+    return None
+
+  def _apply_per_variable(self, kind, lr, mu, scale):
+    g = self.graph
+    for l in g.layers:
+      v = l.weights
+      if v.kind != kind:
+        continue
+      o, n = v.offset, v.numel
+      n4 = (n + 3) // 4 * 4  # padding inside the 64-aligned slot is harmless
+      ops.masked_sgd_momentum(
+          g.W[o:o + n4], g.G[o:o + n4], lr,
+          momentum=self._slot[o:o + n4] if self._slot is not None else None,
+          mask_bits=l.mask.bits if l.mask is not None else None, mu=mu,
+          weight_decay=v.weight_decay, grad_scale=scale,
+          nesterov=self._nesterov)
+
+
+class MomentumOptimizer(GradientDescentOptimizer):
+  """TF ApplyMomentum: accum = accum*momentum + g;
+  w -= lr*g + lr*momentum*accum (use_nesterov) | w -= lr*accum."""
+
+  def __init__(self, learning_rate, momentum, use_locking=False,
+               name='Momentum', use_nesterov=False, graph=None, grad_sync=None):
+    super().__init__(learning_rate, use_locking, name, graph, grad_sync)
+    self._momentum = momentum
+    self._nesterov = use_nesterov
+
+  def get_slot_names(self):
+    return ['momentum']
+
+  def _ensure_slots(self):
+    g = self.graph
+    if self._slot is None or self._slot.numel() != g.W.numel():
+      old = self._slot
+      self._slot = torch.zeros_like(g.W)
+      if old is not None:
+        raise RuntimeError('variables were added after the momentum slots '
+                           'were created')
+
+  def get_slot(self, var, name):
+    if name != 'momentum':
+      raise KeyError(name)
+    self.graph.finalize()
+    self._ensure_slots()
+    return self._slot[var.offset:var.offset + var.numel].view(var.shape)

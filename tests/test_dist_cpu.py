@@ -1,0 +1,100 @@
+"""The N > 1 path on CPU: world_size-2 `gloo` processes exercise the bucketed
+gradient-arena all-reduce (ordering, bucketing, out-of-order notifications,
+1/world scaling) and the drop-fraction broadcast.  No device compute."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+import torch.multiprocessing as mp  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _worker(rank, world, port, q):
+  sys.path.insert(0, ROOT)
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  import torch.distributed as dist
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from rigl_amd import variables as V
+    from rigl_amd.dist import GradSync, broadcast_drop_fraction
+    g = V.Graph('cpu')
+    shapes = [(3, 3, 8, 16), (1, 1, 16, 32), (3, 3, 32, 32), (1, 1, 32, 64), (64, 10)]
+    vs = []
+    for i, s in enumerate(shapes):
+      vs.append(g.add_variable('l%d/weights' % i, s, V.KIND_MASKED if i != 1 else V.KIND_DENSE, 1e-4))
+    bn = g.add_variable('bn/gamma', (64,), V.KIND_OTHER)
+    g.finalize()
+    # tiny buckets so that several are launched mid-"backward"
+    sync = GradSync(g, bucket_bytes=4 * 4000)
+    assert sync.world == world and sync.grad_scale == 1.0 / world
+    ordered = sorted(vs, key=lambda v: v.offset)
+    for trial, order in enumerate([list(reversed(ordered)),                       # normal backward order
+                                   [ordered[4], ordered[2], ordered[3], ordered[0], ordered[1]]]):  # out of order
+      g.G.zero_()
+      for v in order:
+        v.grad.fill_(float(rank + 1) * (1 + vs.index(v)))                        # "wgrad"
+        sync.notify_layer_grad_ready(v)
+      bn.grad.fill_(10.0 * (rank + 1))
+      sync.all_reduce(g)
+      tot = sum(r + 1 for r in range(world))
+      for i, v in enumerate(vs):
+        assert torch.all(v.grad == tot * (1 + i)), (trial, i, v.grad.flatten()[:3])
+      assert torch.all(bn.grad == 10.0 * tot)
+      # alignment padding between tensors stays zero
+      used = torch.zeros_like(g.G, dtype=torch.bool)
+      for v in vs + [bn]:
+        used[v.offset:v.offset + v.numel] = True
+      assert torch.all(g.G[~used] == 0)
+      if trial == 0:
+        assert sync.n_buckets_last >= 3          # really bucketed, not one flush
+    f = broadcast_drop_fraction(0.3 if rank == 0 else 0.9)
+    assert abs(f - 0.3) < 1e-7
+    q.put((rank, 'ok'))
+  except Exception as e:  # pylint: disable=broad-except
+    import traceback
+    q.put((rank, 'FAIL %s\n%s' % (e, traceback.format_exc())))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_grad_sync_world2_gloo():
+  world = 2
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  res = [q.get(timeout=120) for _ in range(world)]
+  for p in procs:
+    p.join(timeout=60)
+  assert all(r[1] == 'ok' for r in res), res
+
+
+def test_grad_sync_single_process_is_noop():
+  sys.path.insert(0, ROOT)
+  from rigl_amd import variables as V
+  from rigl_amd.dist import GradSync
+  g = V.Graph('cpu')
+  v = g.add_variable('a/weights', (4, 4), V.KIND_MASKED)
+  g.finalize()
+  s = GradSync(g)
+  assert not s.enabled and s.grad_scale == 1.0
+  v.grad.fill_(2.0)
+  s.notify_layer_grad_ready(v)
+  s.all_reduce(g)
+  assert torch.all(v.grad == 2.0)

@@ -1,0 +1,254 @@
+"""End-to-end parity on the GPU through the reference-shaped API.
+
+Part 1 re-states rigl/sparse_optimizers_test.py (same toy graphs, same
+assertions) on the HIP-backed optimizers.  Part 2 checks one real ResNet-50
+RigL step: forward/backward against the fp32 CPU restatement of the reference
+model (oracle/resnet_cpu.py), then the optimizer update and the mask update
+bit-exactly against the oracle fed with the SAME gradients."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+
+from oracle import rigl_oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _setup(kind, n_inp, n_out, drop_frac, start_iter=1, end_iter=4, freq_iter=2, lr=0.1, x_ones=False,
+           scale_by_step=False, **kw):
+  """The `_setup_graph` of the reference tests (sparse_optimizers_test.py:40-69,
+  :299-328): one masked FC layer, loss = mean(y) | sum(y * arange * step)."""
+  from rigl_amd import pruning, pruning_layers as PL, sparse_optimizers as SO, train, variables as V
+  g = V.reset_default_graph(DEV)
+  inner = train.GradientDescentOptimizer(lr)
+  cls = {'set': SO.SparseSETOptimizer, 'static': SO.SparseStaticOptimizer,
+         'momentum': SO.SparseMomentumOptimizer, 'rigl': SO.SparseRigLOptimizer}[kind]
+  opt = cls(inner, start_iter, end_iter, freq_iter, drop_fraction=drop_frac, **kw)
+  gs = train.get_or_create_global_step()
+  rs = np.random.RandomState(0)
+
+  def loss_fn():
+    x = torch.ones(1, n_inp) if x_ones else torch.from_numpy(rs.rand(1, n_inp).astype(np.float32))
+    y = PL.sparse_fully_connected(x.to(DEV, torch.bfloat16), n_out, sparsity_technique='threshold',
+                                  use_bias=True, name='fully_connected').float()
+    if scale_by_step:
+      scale = torch.arange(n_out, device=DEV, dtype=torch.float32) * float(gs.value)
+      return (y * scale).sum(), scale
+    if x_ones:
+      return (y * torch.arange(n_out, device=DEV, dtype=torch.float32)).sum(), None
+    return y.mean(), None
+
+  loss_fn()                                    # creates the variables
+  weight, mask = pruning.get_weights()[0], pruning.get_masks()[0]
+  mask.assign(np.random.RandomState(1).choice([0, 1], size=(n_inp, n_out), p=[0.5, 0.5]).astype(np.float32))
+  return opt, loss_fn, mask, weight, gs
+
+
+@pytest.mark.parametrize('n_inp,n_out,drop_frac', [(15, 25, 0.5), (15, 25, 0.2), (3, 5, 0.2)])
+def test_set_mask_non_update_iterations(n_inp, n_out, drop_frac):
+  # sparse_optimizers_test.py:71-92
+  opt, loss_fn, mask, _, gs = _setup('set', n_inp, n_out, drop_frac)
+  for i in range(1, 6):
+    m0 = mask.numpy()
+    opt.minimize(loss_fn()[0], gs)
+    if i not in (1, 3):
+      np.testing.assert_array_equal(m0, mask.numpy())
+
+
+@pytest.mark.parametrize('n_inp,n_out,drop_frac', [(15, 25, 0.5), (15, 25, 0.7), (30, 10, 0.9)])
+def test_set_update_iterations(n_inp, n_out, drop_frac):
+  # :94-118
+  opt, loss_fn, mask, _, gs = _setup('set', n_inp, n_out, drop_frac)
+  for i in range(1, 5):
+    m0 = mask.numpy()
+    opt.minimize(loss_fn()[0], gs)
+    m1 = mask.numpy()
+    if i in (1, 3):
+      assert m0.sum() == m1.sum()
+      assert not np.array_equal(m0, m1)
+
+
+@pytest.mark.parametrize('start_iter,end_iter,freq_iter', [(3, 7, 2), (1, 5, 3), (0, 4, 1)])
+def test_set_no_drop(start_iter, end_iter, freq_iter):
+  # :120-139
+  opt, loss_fn, mask, _, gs = _setup('set', 3, 5, 0, start_iter, end_iter, freq_iter)
+  for _ in range(end_iter + 2):
+    m0 = mask.numpy()
+    opt.minimize(loss_fn()[0], gs)
+    np.testing.assert_array_equal(m0, mask.numpy())
+
+
+def test_set_new_connection_zero_init():
+  # :141-156
+  opt, loss_fn, mask, weight, gs = _setup('set', 3, 5, 0.5, 0, 4, 1)
+  for _ in range(5):
+    m0 = mask.numpy()
+    opt.minimize(loss_fn()[0], gs)
+    m1, w1 = mask.numpy(), weight.numpy()
+    assert np.all(w1[np.logical_and(m0 == 0, m1 == 1)] == 0)
+
+
+@pytest.mark.parametrize('n_inp,n_out,drop_frac', [(15, 25, 0.5), (15, 25, 0.2), (3, 5, 0.2)])
+def test_static_mask_never_changes(n_inp, n_out, drop_frac):
+  # :225-244
+  opt, loss_fn, mask, _, gs = _setup('static', n_inp, n_out, drop_frac)
+  for _ in range(5):
+    m0 = mask.numpy()
+    opt.minimize(loss_fn()[0], gs)
+    np.testing.assert_array_equal(m0, mask.numpy())
+
+
+@pytest.mark.parametrize('n_inp,n_out,momentum', [(3, 4, 0.5), (5, 2, 0.), (2, 5, 1.)])
+def test_momentum_ema_update(n_inp, n_out, momentum):
+  # :275-294
+  opt, loss_fn, _, weight, gs = _setup('momentum', n_inp, n_out, 0.5, x_ones=True, momentum=momentum)
+  cur = np.zeros((n_inp, n_out), np.float32)
+  for _ in range(6):
+    opt.minimize(loss_fn()[0], gs)
+    cur = (cur * np.float32(momentum) + np.float32(1 - momentum) * np.arange(n_out, dtype=np.float32)).astype(np.float32)
+    np.testing.assert_allclose(opt.ema_average(weight).cpu().numpy(), cur, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('n_inp,n_out', [(3, 4), (5, 2), (2, 5)])
+def test_rigl_masked_gradient_is_dense(n_inp, n_out):
+  # :330-347 -- _weight2masked_grads equals the dense analytic gradient
+  opt, loss_fn, _, weight, gs = _setup('rigl', n_inp, n_out, 0., 0, 3, 1, lr=1e-3, x_ones=True, scale_by_step=True)
+  for i in range(6):
+    loss, scale = loss_fn()
+    opt.minimize(loss, gs)
+    if i % 2 == 0:
+      expected = scale.unsqueeze(0).expand(n_inp, n_out).cpu().numpy()
+      np.testing.assert_array_equal(opt._weight2masked_grads[weight.name].cpu().numpy(), expected)
+      from rigl_amd.sparse_optimizers import get_grow_grads
+      np.testing.assert_array_equal(get_grow_grads(opt)[0].cpu().numpy(), expected)
+
+
+@pytest.mark.parametrize('start_iter,end_iter,freq_iter,is_incremented', [
+    (3, 7, 2, [1, 1, 1, 0, 1, 1, 0, 1, 1, 0, 1]),
+    (1, 5, 3, [1, 0, 1, 1, 1, 0, 1, 1, 1, 1, 1]),
+    (0, 4, 1, [0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 1])])
+def test_rigl_apply_gradients_golden(start_iter, end_iter, freq_iter, is_incremented):
+  # :349-367
+  opt, loss_fn, _, _, gs = _setup('rigl', 3, 5, .5, start_iter, end_iter, freq_iter, lr=1e-3, x_ones=True,
+                                  scale_by_step=True)
+  for one in is_incremented:
+    before = gs.value
+    opt.minimize(loss_fn()[0], gs)
+    assert gs.value == before + one
+
+
+# ---------------------------------------------------------------------------- ResNet-50
+@pytest.fixture(scope='module')
+def rn50():
+  from rigl_amd import sparse_optimizers as SO, sparse_utils, train, variables as V
+  from rigl_amd.workloads import resnet50
+  g = V.reset_default_graph(DEV)
+  model = resnet50.ResNet50(g, seed=0)
+  np.random.seed(0)
+  sparse_utils.get_mask_init_fn(g.get_masks(), 'erdos_renyi_kernel', 0.8, {})()
+  inner = train.MomentumOptimizer(0.05, 0.9, use_nesterov=True, graph=g)
+  opt = SO.SparseRigLOptimizer(inner, 1, 25000, 100, drop_fraction=0.3, drop_fraction_anneal='cosine',
+                               noise_std=0.0)
+  images, labels = resnet50.synthetic_batch(8, DEV, seed=5)
+  return g, model, opt, images, labels
+
+
+def test_resnet50_structure_and_sparsity(rn50):
+  g = rn50[0]
+  from rigl_amd.workloads import shapes as WS
+  assert [m.name for m in g.get_masks()] == list(WS.resnet50_masks().keys())
+  assert sum(m.numel for m in g.get_masks()) == 25502912
+  assert sum(m.sum() for m in g.get_masks()) == 5100630        # ERK 0.8 non-zeros
+
+
+def test_resnet50_forward_backward_vs_cpu_oracle(rn50):
+  g, model, opt, images, labels = rn50
+  from oracle.resnet_cpu import ResNet50CPU
+  g.refresh_shadows(force=True)
+  cpu = ResNet50CPU(seed=0)
+  assert len(cpu.w) == len(g.layers)
+  for i, l in enumerate(g.layers):
+    cpu.w[i] = l.hwio.float().cpu().reshape(l.weights.shape).requires_grad_(True)   # bf16(mask*W), mask folded in
+    cpu.m[i] = torch.ones(l.weights.shape)
+  cpu.w[-1] = cpu.w[-1].detach().reshape(1, 1, 2048, 1000).requires_grad_(True)
+  cpu.m[-1] = torch.ones(1, 1, 2048, 1000)
+  # non-degenerate BN scales (gamma=0 on the last BN of each block would hide the residual branch)
+  for v in g.variables.values():
+    if v.name.endswith('bn3/gamma:0'):
+      v.data.fill_(0.5)
+  for b in cpu.blocks:
+    cpu.bn[b['c3'][1]][0].data.fill_(0.5)
+  loss = model.loss(images, labels, label_smoothing=0.1)
+  opt.compute_gradients(loss)
+  x_cpu = images.float().cpu().permute(0, 3, 1, 2)
+  loss_cpu = torch.nn.functional.cross_entropy(cpu.forward(x_cpu), labels.cpu(), label_smoothing=0.1)
+  loss_cpu.backward()
+  assert abs(float(loss) - float(loss_cpu)) < 3e-2 * abs(float(loss_cpu))
+  cos = []
+  for i, l in enumerate(g.layers):
+    a = l.weights.grad.float().cpu().reshape(-1)
+    b = cpu.w[i].grad.reshape(-1)
+    cos.append(float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)))
+  assert min(cos) > 0.97, 'dense kernel gradients disagree with the CPU model: %s' % cos
+  assert np.mean(cos) > 0.99
+
+
+def test_resnet50_optimizer_and_mask_update_bit_exact(rn50):
+  """gs=0 is not an update step (begin=1): apply; gs=1 is: prune/regrow.
+  Both compared bit-for-bit with the oracle fed the device's own gradients."""
+  g, model, opt, images, labels = rn50
+  gs = g.get_or_create_global_step()
+  gs.value = 0
+  opt._last_update_step = -100
+  from rigl_amd import variables as V
+  # ---- step A: masked Nesterov momentum (K3) over the arenas
+  loss = model.loss(images, labels, label_smoothing=0.1)
+  gv = opt.compute_gradients(loss)
+  inner = opt._optimizer
+  inner._ensure_slots()
+  W0, G0, A0 = g.W.cpu().numpy(), g.G.cpu().numpy(), inner._slot.cpu().numpy()
+  bits = g.BITS.cpu().numpy().view(np.uint32)
+  opt.apply_gradients(gv, gs)
+  assert gs.value == 1
+  b, e = g.seg[V.KIND_MASKED]
+  m = np.unpackbits(bits.view(np.uint8), bitorder='little')[:e - b].astype(np.float32)
+  w_ref, a_ref = O.momentum_apply(W0[b:e], A0[b:e], O.masked_grad(G0[b:e], m, W0[b:e], 1e-4), 0.05, 0.9)
+  np.testing.assert_array_equal(g.W[b:e].cpu().numpy().view(np.uint32), w_ref.view(np.uint32))
+  np.testing.assert_array_equal(inner._slot[b:e].cpu().numpy().view(np.uint32), a_ref.view(np.uint32))
+  b, e = g.seg[V.KIND_OTHER]
+  w_ref, a_ref = O.momentum_apply(W0[b:e], A0[b:e], G0[b:e], 0.05, 0.9)
+  np.testing.assert_array_equal(g.W[b:e].cpu().numpy().view(np.uint32), w_ref.view(np.uint32))
+  # ---- step B: mask update (K2), all 54 layers in one call
+  loss = model.loss(images, labels, label_smoothing=0.1)
+  gv = opt.compute_gradients(loss)
+  layers = g.masked_layers()
+  before = [(l.mask.numpy().copy(), l.weights.numpy().copy(), l.weights.grad.cpu().numpy().copy(),
+             inner.get_slot(l.weights, 'momentum').cpu().numpy().copy()) for l in layers]
+  opt.apply_gradients(gv, gs)
+  assert gs.value == 1                      # update iterations do not advance global_step (F9)
+  frac = O.get_drop_fraction('cosine', 0.3, 1, 1, 25000, True)
+  assert np.float32(opt.drop_fraction) == np.float32(frac)
+  counts = opt.last_counts.cpu().numpy()
+  for i, (l, (m0, w0, g0, a0)) in enumerate(zip(layers, before)):
+    r = O.rigl_mask_update(m0, w0, g0, frac, momentum=a0)
+    np.testing.assert_array_equal(l.mask.numpy(), r['mask'], err_msg=l.scope)
+    np.testing.assert_array_equal(l.weights.numpy().view(np.uint32), r['weights'].view(np.uint32), err_msg=l.scope)
+    np.testing.assert_array_equal(inner.get_slot(l.weights, 'momentum').cpu().numpy(), r['momentum'])
+    assert tuple(counts[i][:3]) == (r['n_ones'], r['n_prune'], r['n_keep'])
+  assert sum(m.sum() for m in g.get_masks()) == 5100630        # connections conserved
+
+
+def test_resnet50_training_reduces_loss(rn50):
+  g, model, opt, images, labels = rn50
+  gs = g.get_or_create_global_step()
+  first = last = None
+  for i in range(12):
+    loss = model.loss(images, labels, label_smoothing=0.1)
+    opt.minimize(loss, gs)
+    v = float(loss)
+    assert np.isfinite(v)
+    first = v if first is None else first
+    last = v
+  assert last < first
