@@ -147,9 +147,7 @@ class MaskedDense(_Layer):
     self.activation = activation
     self._descs = {}
     if use_bias:
-      b = graph.add_variable(scope + '/biases', (units,), V.KIND_OTHER, 0.0)
-      b.data.requires_grad_(True)
-      self.bias = b
+      self.bias = graph.add_variable(scope + '/biases', (units,), V.KIND_OTHER, 0.0)
 
   def __call__(self, x):
     if x.shape[-1] != self.n_in:
@@ -175,14 +173,17 @@ class MaskedDense(_Layer):
 
 
 def bias_tensor(var):
-  """A leaf tensor aliasing the variable's storage whose .grad IS the
-  variable's slice of the gradient arena (autograd accumulates in place)."""
-  t = var.data
-  if not t.requires_grad:
-    t.requires_grad_(True)
-  if t.grad is None or t.grad.data_ptr() != var.grad.data_ptr():
-    t.grad = var.grad
-  return t
+  """An autograd leaf aliasing the variable's storage whose .grad IS the
+  variable's slice of the gradient arena (autograd accumulates in place).
+  The variable's own ``data`` tensor never requires grad, so the arenas stay
+  outside any autograd graph; the kernels update them in place."""
+  leaf = getattr(var, '_leaf', None)
+  if leaf is None or leaf.data_ptr() != var.data.data_ptr():
+    leaf = var.data.detach().requires_grad_(True)
+    var._leaf = leaf
+  if leaf.grad is None or leaf.grad.data_ptr() != var.grad.data_ptr():
+    leaf.grad = var.grad
+  return leaf
 
 
 # ----------------------------------------------------------------------------

@@ -271,8 +271,10 @@ class Graph:
     for v in order:
       o = v._new_offset
       view = W[o:o + v.numel].view(v.shape)
-      view.copy_(v.data)
+      with torch.no_grad():
+        view.copy_(v.data.detach())
       v.data = view
+      v._leaf = None
       gview = G[o:o + v.numel].view(v.shape)
       v.grad = gview
       v.offset = o

@@ -255,3 +255,23 @@ def test_extract_number():
 def test_topk_order_ties_lower_index_first():
   x = np.array([1., 3., 3., 0., -0., 3., 1.], np.float32)
   assert O.topk_order(x).tolist() == [1, 2, 5, 0, 6, 3, 4]
+
+
+def test_c_oracle_agrees_with_numpy_oracle_and_reference():
+  """oracle/c (qsort, full-sort form) vs oracle/rigl_oracle.py vs the
+  reference-generated goldens."""
+  from oracle import c_oracle
+  z, names = _cases(lambda n: not n.startswith('generic_'))
+  for n in names:
+    g = lambda k: z['%s__%s' % (n, k)] if '%s__%s' % (n, k) in z.files else None
+    if str(g('grow_init')) != 'zeros':
+      continue
+    sd, sg = O.rigl_scores(g('mask'), g('w'), g('g'), g('noise'))
+    mv = None if g('mom') is None else (g('g') * np.float32(g('acc_scale'))).astype(np.float32)
+    nm, nw, nmom, counts = c_oracle.update(sd, sg, g('mask'), g('w'), float(g('frac')), momentum=g('mom'),
+                                           momentum_values=mv)
+    np.testing.assert_array_equal(nm, g('new_mask').reshape(-1), err_msg=n)
+    np.testing.assert_array_equal(nw.view(np.uint32), g('new_w').reshape(-1).view(np.uint32), err_msg=n)
+    if g('mom') is not None:
+      np.testing.assert_array_equal(nmom, g('new_mom').reshape(-1), err_msg=n)
+    assert counts[4] == 0
