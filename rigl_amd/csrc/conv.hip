@@ -48,6 +48,20 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// Buffer loads (SRD in SGPRs): lanes that must read zero get an offset beyond
+// num_records and the hardware returns 0 -- no branch, no select, and the
+// compiler keeps all loads of a tile in flight behind one counted vmcnt
+// (conditional `if (ok) v = *p` loads were serialised by a vmcnt(0) each).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+constexpr uint32_t OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ uint32_t dword_of(const uint4& v, int d) {
   return d == 0 ? v.x : (d == 1 ? v.y : (d == 2 ? v.z : v.w));
 }
@@ -64,6 +78,7 @@ struct IgemmArgs {
   int b_row_stride, b_tap_stride;
   int ldc;
   int tiles_n;
+  uint32_t a_bytes, b_bytes;   // sizes of A / B in bytes (< 2^31) for the buffer descriptors
 };
 
 template <int TM, int TN, int BK, int MODE /*0 fwd, 1 dgrad*/, bool OUT_F32>
@@ -107,6 +122,7 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
   const int kc_tiles = (P.Cred + BK - 1) / BK;
   const int KT = P.KH * P.KW * kc_tiles;
   uint4 ra[APASS], rb[BPASS];
+  const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.A, P.a_bytes), rsrcB = make_rsrc(P.B, P.b_bytes);
 
   // (macros, not lambdas: by-reference lambda captures of the staging arrays
   //  kept them in scratch memory instead of registers)
@@ -127,16 +143,12 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
       }                                                                                               \
       ok = ok && (unsigned)gh < (unsigned)P.GH && (unsigned)gw < (unsigned)P.GW;                      \
       const int off = (a_pix[p] + gh * P.GW + gw) * P.Cred + cofs;                                    \
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);                                                           \
-      if (ok) v = *reinterpret_cast<const uint4*>(P.A + off);                                         \
-      ra[p] = v;                                                                                      \
+      ra[p] = buf_load16(rsrcA, ok ? (uint32_t)off * 2u : OOB);                                       \
     }                                                                                                 \
     const int tap = (r_) * P.KW + (s_);                                                               \
     _Pragma("unroll") for (int p = 0; p < BPASS; ++p) {                                               \
       const int off = b_off[p] + tap * P.b_tap_stride + cofs;                                         \
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);                                                           \
-      if (b_ok[p] && c_ok) v = *reinterpret_cast<const uint4*>(P.B + off);                            \
-      rb[p] = v;                                                                                      \
+      rb[p] = buf_load16(rsrcB, (b_ok[p] && c_ok) ? (uint32_t)off * 2u : OOB);                        \
     }                                                                                                 \
   }
 #define RIGL_STORE_TILE(buf_)                                                                         \
@@ -248,6 +260,7 @@ struct WgradArgs {
   int tiles_ci, tiles_co;
   int splits;
   int64_t slab_elems;  // KH*KW*Cin*Cout
+  uint32_t x_bytes, dy_bytes;
 };
 
 template <int TM, int TN>
@@ -275,6 +288,7 @@ __global__ __launch_bounds__(THREADS) void k_wgrad(WgradArgs P) {
   const bool direct = P.KH == 1 && P.KW == 1 && P.sh == 1 && P.sw == 1 && P.ph == 0 && P.pw == 0;
 
   uint4 rg[NPASS][8];
+  const __amdgpu_buffer_rsrc_t rsrcX = make_rsrc(P.X, P.x_bytes), rsrcY = make_rsrc(P.DY, P.dy_bytes);
 
   // Each thread owns 8x8 blocks: 8 consecutive pixels x one 8-channel chunk.
   // (macros rather than lambdas so that rg[][] stays in registers)
@@ -283,7 +297,6 @@ __global__ __launch_bounds__(THREADS) void k_wgrad(WgradArgs P) {
     const int mbase = (kt_) * BK;                                                                     \
     _Pragma("unroll") for (int q = 0; q < NPASS; ++q) {                                               \
       const int blk = q * THREADS + tid;                                                              \
-      _Pragma("unroll") for (int i = 0; i < 8; ++i) rg[q][i] = make_uint4(0u, 0u, 0u, 0u);            \
       if (blk < A_BLOCKS) {                                                                           \
         const int cc = blk % (BM / 8), pg = blk / (BM / 8);                                           \
         const int ch = ci0 + cc * 8;                                                                  \
@@ -291,14 +304,13 @@ __global__ __launch_bounds__(THREADS) void k_wgrad(WgradArgs P) {
         const int m = mbase + pg * 8;                                                                 \
         if (direct) {                                                                                 \
           _Pragma("unroll") for (int i = 0; i < 8; ++i)                                               \
-            if (c_ok && m + i < P.M)                                                                  \
-              rg[q][i] = *reinterpret_cast<const uint4*>(P.X + (int64_t)(m + i) * P.Cin + ch);        \
+            rg[q][i] = buf_load16(rsrcX, (c_ok && m + i < P.M) ? (uint32_t)((m + i) * P.Cin + ch) * 2u : OOB); \
         } else {                                                                                      \
           int wo = m % P.Wo, t = m / P.Wo, ho = t % P.Ho, n = t / P.Ho;                               \
           _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                             \
             const int hi = ho * P.sh - P.ph + r, wi = wo * P.sw - P.pw + s;                           \
-            if (c_ok && (m + i) < P.M && (unsigned)hi < (unsigned)P.H && (unsigned)wi < (unsigned)P.W) \
-              rg[q][i] = *reinterpret_cast<const uint4*>(P.X + ((int64_t)(n * P.H + hi) * P.W + wi) * P.Cin + ch); \
+            const bool ok = c_ok && (m + i) < P.M && (unsigned)hi < (unsigned)P.H && (unsigned)wi < (unsigned)P.W; \
+            rg[q][i] = buf_load16(rsrcX, ok ? (uint32_t)(((n * P.H + hi) * P.W + wi) * P.Cin + ch) * 2u : OOB); \
             if (++wo == P.Wo) { wo = 0; if (++ho == P.Ho) { ho = 0; ++n; } }                          \
           }                                                                                           \
         }                                                                                             \
@@ -309,8 +321,7 @@ __global__ __launch_bounds__(THREADS) void k_wgrad(WgradArgs P) {
         const bool c_ok = ch < P.Cout;                                                                \
         const int m = mbase + pg * 8;                                                                 \
         _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                 \
-          if (c_ok && m + i < P.M)                                                                    \
-            rg[q][i] = *reinterpret_cast<const uint4*>(P.DY + (int64_t)(m + i) * P.Cout + ch);        \
+          rg[q][i] = buf_load16(rsrcY, (c_ok && m + i < P.M) ? (uint32_t)((m + i) * P.Cout + ch) * 2u : OOB); \
       }                                                                                               \
     }                                                                                                 \
   }
@@ -476,10 +487,10 @@ static int check_desc(const RiglConvDesc* d, const char* who) {
   // every output pixel's window must start inside the padded image
   if ((d->ho - 1) * d->stride_h - d->pad_top >= d->h || (d->wo - 1) * d->stride_w - d->pad_left >= d->w)
     return fail(RIGL_EINVAL, "%s: output size inconsistent with input/stride/pad", who);
-  const int64_t lim = (int64_t(1) << 31) - 1;
+  const int64_t lim = (int64_t(1) << 30) - 1;   // bf16 tensors stay below 2^31 bytes (buffer descriptors)
   if ((int64_t)d->n * d->h * d->w * d->cin > lim || (int64_t)d->n * d->ho * d->wo * d->cout > lim ||
       (int64_t)d->kh * d->kw * d->cin * d->cout > lim)
-    return fail(RIGL_EUNSUPPORTED, "%s: tensor exceeds 2^31 elements", who);
+    return fail(RIGL_EUNSUPPORTED, "%s: tensor exceeds 2^30 elements", who);
   return RIGL_OK;
 }
 
@@ -560,6 +571,8 @@ int rigl_masked_conv2d_fwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl
     a.GH = d->h; a.GW = d->w; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
     a.b_row_stride = d->kh * d->kw * d->cin; a.b_tap_stride = d->cin;
   }
+  a.a_bytes = (uint32_t)((size_t)a.M * 0 + (small_cin(d) ? (size_t)a.M * kpad(d) : (size_t)d->n * d->h * d->w * d->cin) * 2);
+  a.b_bytes = (uint32_t)((small_cin(d) ? (size_t)d->cout * kpad(d) : (size_t)d->kh * d->kw * d->cin * d->cout) * 2);
   launch_igemm<0, false>(a, st);
   RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
   return RIGL_OK;
@@ -582,6 +595,8 @@ int rigl_masked_conv2d_dgrad(const RiglConvDesc* d, const rigl_bf16* dy, const r
   a.KH = d->kh; a.KW = d->kw; a.RH = d->h; a.RW = d->w; a.GH = d->ho; a.GW = d->wo;
   a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
   a.b_row_stride = d->cout; a.b_tap_stride = d->cin * d->cout;
+  a.a_bytes = (uint32_t)((size_t)d->n * d->ho * d->wo * d->cout * 2);
+  a.b_bytes = (uint32_t)((size_t)d->kh * d->kw * d->cin * d->cout * 2);
   launch_igemm<1, false>(a, st);
   RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
   return RIGL_OK;
@@ -616,6 +631,8 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
     n_out = (int64_t)d->kh * d->kw * d->cin * d->cout;
   }
+  a.x_bytes = (uint32_t)((small_cin(d) ? (size_t)a.M * a.Cin : (size_t)d->n * d->h * d->w * d->cin) * 2);
+  a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
   WgradPlan p = plan_wgrad(a.M, a.Cin, a.Cout, a.KH * a.KW);
   a.tiles_ci = p.tiles_ci; a.tiles_co = p.tiles_co; a.splits = p.splits; a.slab_elems = p.slab;
   const bool two_pass = p.splits > 1 || small_cin(d);

@@ -163,36 +163,71 @@ def test_resnet50_structure_and_sparsity(rn50):
   assert sum(m.sum() for m in g.get_masks()) == 5100630        # ERK 0.8 non-zeros
 
 
-def test_resnet50_forward_backward_vs_cpu_oracle(rn50):
+def test_resnet50_every_conv_in_situ_and_loss_vs_cpu_oracle(rn50):
+  """(a) Every one of the 54 masked layers, with the operands it actually sees
+  inside the network (real shapes, strides, paddings, bf16 activations), against
+  torch's fp32 convolution of the same operands on the GPU.  (b) The loss against
+  the fp32 CPU restatement of the reference model.  A whole-network gradient
+  comparison is meaningless here: at initialisation a 50-layer BN network with
+  batch 8 amplifies bf16 rounding chaotically (fp32 vs bf16-rounded CPU models
+  decorrelate to cos 0.6 in the first layers with no kernel involved)."""
+  import torch.nn.functional as F
   g, model, opt, images, labels = rn50
+  from rigl_amd import pruning_layers as PL
   from oracle.resnet_cpu import ResNet50CPU
   g.refresh_shadows(force=True)
-  cpu = ResNet50CPU(seed=0)
-  assert len(cpu.w) == len(g.layers)
-  for i, l in enumerate(g.layers):
-    cpu.w[i] = l.hwio.float().cpu().reshape(l.weights.shape).requires_grad_(True)   # bf16(mask*W), mask folded in
-    cpu.m[i] = torch.ones(l.weights.shape)
-  cpu.w[-1] = cpu.w[-1].detach().reshape(1, 1, 2048, 1000).requires_grad_(True)
-  cpu.m[-1] = torch.ones(1, 1, 2048, 1000)
-  # non-degenerate BN scales (gamma=0 on the last BN of each block would hide the residual branch)
   for v in g.variables.values():
     if v.name.endswith('bn3/gamma:0'):
       v.data.fill_(0.5)
+  rec = []
+  fwd0, bwd0 = PL._MaskedConvFn.forward, PL._MaskedConvFn.backward
+
+  def fwd(ctx, x, lv, desc, need_dx):
+    y = fwd0(ctx, x, lv, desc, need_dx)
+    rec.append(dict(lv=lv, d=desc, x=x.detach().clone(), y=y.detach().clone()))
+    ctx.rec = rec[-1]
+    return y
+
+  def bwd(ctx, dy):
+    out = bwd0(ctx, dy)
+    ctx.rec.update(dy=dy.detach().clone(), dx=None if out[0] is None else out[0].detach().clone(),
+                   dw=ctx.lv.weights.grad.detach().clone())
+    return out
+
+  PL._MaskedConvFn.forward, PL._MaskedConvFn.backward = staticmethod(fwd), staticmethod(bwd)
+  try:
+    loss = model.loss(images, labels, label_smoothing=0.1)
+    opt.compute_gradients(loss)
+  finally:
+    PL._MaskedConvFn.forward, PL._MaskedConvFn.backward = staticmethod(fwd0), staticmethod(bwd0)
+  assert len(rec) == 54
+  for r in rec:
+    d, lv = r['d'], r['lv']
+    w = lv.hwio.float().reshape(d.kh, d.kw, d.cin, d.cout).permute(3, 2, 0, 1).contiguous().requires_grad_(True)
+    x = r['x'].float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    pb = max((d.ho - 1) * d.stride_h + d.kh - d.h - d.pad_top, 0)
+    pr = max((d.wo - 1) * d.stride_w + d.kw - d.w - d.pad_left, 0)
+    y = F.conv2d(F.pad(x, (d.pad_left, pr, d.pad_top, pb)), w, stride=(d.stride_h, d.stride_w))[:, :, :d.ho, :d.wo]
+    y.backward(r['dy'].float().permute(0, 3, 1, 2))
+    yr = y.detach().permute(0, 2, 3, 1)
+    tag = lv.scope
+    assert (r['y'].float() - yr).abs().max() <= 2.0**-7 * yr.abs().max() + 1e-6, tag
+    dwr = w.grad.permute(2, 3, 1, 0)
+    assert (r['dw'].reshape(dwr.shape) - dwr).abs().max() <= 3e-4 * dwr.abs().max() + 1e-9, tag
+    if r['dx'] is not None:
+      dxr = x.grad.permute(0, 2, 3, 1)
+      assert (r['dx'].float() - dxr).abs().max() <= 2.0**-7 * dxr.abs().max() + 1e-9, tag
+  # (b) loss vs the CPU model with the same (bf16-rounded, masked) weights
+  cpu = ResNet50CPU(seed=0)
+  for i, l in enumerate(g.layers):
+    cpu.w[i] = l.hwio.float().cpu().reshape(l.weights.shape if len(l.weights.shape) == 4 else (1, 1) + tuple(l.weights.shape))
+    cpu.m[i] = torch.ones_like(cpu.w[i])
   for b in cpu.blocks:
     cpu.bn[b['c3'][1]][0].data.fill_(0.5)
-  loss = model.loss(images, labels, label_smoothing=0.1)
-  opt.compute_gradients(loss)
-  x_cpu = images.float().cpu().permute(0, 3, 1, 2)
-  loss_cpu = torch.nn.functional.cross_entropy(cpu.forward(x_cpu), labels.cpu(), label_smoothing=0.1)
-  loss_cpu.backward()
-  assert abs(float(loss) - float(loss_cpu)) < 3e-2 * abs(float(loss_cpu))
-  cos = []
-  for i, l in enumerate(g.layers):
-    a = l.weights.grad.float().cpu().reshape(-1)
-    b = cpu.w[i].grad.reshape(-1)
-    cos.append(float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)))
-  assert min(cos) > 0.97, 'dense kernel gradients disagree with the CPU model: %s' % cos
-  assert np.mean(cos) > 0.99
+  torch.set_num_threads(min(torch.get_num_threads(), 32))
+  with torch.no_grad():
+    loss_cpu = F.cross_entropy(cpu.forward(images.float().cpu().permute(0, 3, 1, 2)), labels.cpu(), label_smoothing=0.1)
+  assert abs(float(loss.detach()) - float(loss_cpu)) < 2e-2 * abs(float(loss_cpu))
 
 
 def test_resnet50_optimizer_and_mask_update_bit_exact(rn50):
@@ -244,11 +279,12 @@ def test_resnet50_training_reduces_loss(rn50):
   g, model, opt, images, labels = rn50
   gs = g.get_or_create_global_step()
   first = last = None
-  for i in range(12):
+  opt._optimizer._lr = 0.004            # batch 8: momentum 0.9 makes 0.05 unstable
+  for i in range(40):
     loss = model.loss(images, labels, label_smoothing=0.1)
     opt.minimize(loss, gs)
-    v = float(loss)
+    v = float(loss.detach())
     assert np.isfinite(v)
     first = v if first is None else first
     last = v
-  assert last < first
+  assert last < first - 0.5, (first, last)     # memorising 8 images
