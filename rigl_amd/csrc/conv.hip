@@ -76,37 +76,61 @@ struct IgemmArgs {
   int GH, GW;          // spatial size of the gathered tensor
   int sh, sw, ph, pw;
   int b_row_stride, b_tap_stride;
+  int a_pix_stride;    // elements between consecutive gathered pixels (== Cred except on the tiny-Cin path)
   int ldc;
   int tiles_n;
   uint32_t a_bytes, b_bytes;   // sizes of A / B in bytes (< 2^31) for the buffer descriptors
+  // strided dgrad, class-major tiling: rows are enumerated per stride-parity
+  // class (h % sh, w % sw); a tile never mixes classes, so it only visits the
+  // filter taps that can reach its pixels (3x3/2: 1, 2, 2 or 4 taps, not 9).
+  int cls_tile_begin[5];       // tile_m prefix per class (sh*sw <= 4 classes)
+  int cls_cnt[4], cls_hc[4], cls_wc[4];
 };
 
-template <int TM, int TN, int BK, int MODE /*0 fwd, 1 dgrad*/, bool OUT_F32>
+template <int TM, int TN, int BK, int MODE /*0 fwd, 1 dgrad*/, bool OUT_F32, bool CLS>
 __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
   constexpr int BM = 64 * TM, BN = 64 * TN, CPR = BK / 8, RPP = THREADS / CPR;
   constexpr int APASS = (BM + RPP - 1) / RPP, BPASS = (BN + RPP - 1) / RPP;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int CS_LD = BN + 8;
   constexpr int EPI = OUT_F32 ? 0 : BM * CS_LD * 2;
-  constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+  constexpr int EPI_ALL = EPI + (CLS ? BM * 4 : 0);       // + per-row output pixel table
+  constexpr int SMEM = (2 * STAGE > EPI_ALL) ? 2 * STAGE : EPI_ALL;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (int)(tile / (uint32_t)P.tiles_n) * BM, n0 = (int)(tile % (uint32_t)P.tiles_n) * BN;
+  const int tile_m = (int)(tile / (uint32_t)P.tiles_n);
+  const int n0 = (int)(tile % (uint32_t)P.tiles_n) * BN;
+  int m0 = tile_m * BM;
+  int c_ph = 0, c_pw = 0, c_cnt = P.M, c_hc = 1, c_wc = 1;
+  if (CLS) {
+    int c = 0;
+    while (c < 3 && tile_m >= P.cls_tile_begin[c + 1]) ++c;
+    m0 = (tile_m - P.cls_tile_begin[c]) * BM;           // index inside the class
+    c_ph = c / P.sw; c_pw = c % P.sw;
+    c_cnt = P.cls_cnt[c]; c_hc = P.cls_hc[c]; c_wc = P.cls_wc[c];
+  }
   const int lrow = tid / CPR, lchunk = tid % CPR;
 
   // ---- per-thread gather rows (fixed for the whole K loop) ------------------
-  int a_pix[APASS], a_c0[APASS], a_c1[APASS];
+  int a_pix[APASS], a_c0[APASS], a_c1[APASS], a_out[APASS];
   bool a_ok[APASS];
 #pragma unroll
   for (int p = 0; p < APASS; ++p) {
     const int row = p * RPP + lrow, m = m0 + row;
-    a_ok[p] = row < BM && m < P.M;
+    a_ok[p] = row < BM && m < (CLS ? c_cnt : P.M);
     const int mm = a_ok[p] ? m : 0;
-    const int rw = mm % P.RW, t = mm / P.RW, rh = t % P.RH, n = t / P.RH;
+    int rw, rh, n;
+    if (CLS) {
+      const int w2 = mm % c_wc, t = mm / c_wc;
+      rw = w2 * P.sw + c_pw; rh = (t % c_hc) * P.sh + c_ph; n = t / c_hc;
+    } else {
+      rw = mm % P.RW; const int t = mm / P.RW; rh = t % P.RH; n = t / P.RH;
+    }
     a_pix[p] = n * P.GH * P.GW;
+    a_out[p] = a_ok[p] ? (n * P.RH + rh) * P.RW + rw : -1;
     if (MODE == 0) { a_c0[p] = rh * P.sh - P.ph; a_c1[p] = rw * P.sw - P.pw; }
     else { a_c0[p] = rh + P.ph; a_c1[p] = rw + P.pw; }
   }
@@ -120,7 +144,12 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
   }
 
   const int kc_tiles = (P.Cred + BK - 1) / BK;
-  const int KT = P.KH * P.KW * kc_tiles;
+  // taps visited: all of them, or (class mode) only r = r0, r0+sh, ... and s = s0, s0+sw, ...
+  const int r0 = CLS ? (c_ph + P.ph) % P.sh : 0, s0 = CLS ? (c_pw + P.pw) % P.sw : 0;
+  const int r_step = CLS ? P.sh : 1, s_step = CLS ? P.sw : 1;
+  const int n_r = r0 < P.KH ? (P.KH - r0 + r_step - 1) / r_step : 0;
+  const int n_s = s0 < P.KW ? (P.KW - s0 + s_step - 1) / s_step : 0;
+  const int KT = n_r * n_s * kc_tiles;
   uint4 ra[APASS], rb[BPASS];
   const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.A, P.a_bytes), rsrcB = make_rsrc(P.B, P.b_bytes);
 
@@ -142,7 +171,7 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
         if (P.sw == 1) gw = tw; else { gw = tw / P.sw; ok = ok && (tw - gw * P.sw) == 0; }            \
       }                                                                                               \
       ok = ok && (unsigned)gh < (unsigned)P.GH && (unsigned)gw < (unsigned)P.GW;                      \
-      const int off = (a_pix[p] + gh * P.GW + gw) * P.Cred + cofs;                                    \
+      const int off = (a_pix[p] + gh * P.GW + gw) * P.a_pix_stride + cofs;                            \
       ra[p] = buf_load16(rsrcA, ok ? (uint32_t)off * 2u : OOB);                                       \
     }                                                                                                 \
     const int tap = (r_) * P.KW + (s_);                                                               \
@@ -174,11 +203,13 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // ---- main loop ------------------------------------------------------------
-  int r = 0, s = 0, cb = 0;
-#define RIGL_ADVANCE() { if (++cb == kc_tiles) { cb = 0; if (++s == P.KW) { s = 0; ++r; } } }
-  RIGL_LOAD_TILE(r, s, cb);
-  RIGL_STORE_TILE(0);
-  RIGL_ADVANCE();
+  int r = r0, s = s0, cb = 0;
+#define RIGL_ADVANCE() { if (++cb == kc_tiles) { cb = 0; s += s_step; if (s >= P.KW) { s = s0; r += r_step; } } }
+  if (KT > 0) {
+    RIGL_LOAD_TILE(r, s, cb);
+    RIGL_STORE_TILE(0);
+    RIGL_ADVANCE();
+  }
   __syncthreads();
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
@@ -225,6 +256,14 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
         }
   } else {
     uint16_t* Cs = reinterpret_cast<uint16_t*>(smem);
+    int* rowpix = reinterpret_cast<int*>(smem + EPI);
+    if (CLS && lchunk == 0) {
+#pragma unroll
+      for (int p = 0; p < APASS; ++p) {
+        const int row = p * RPP + lrow;
+        if (row < BM) rowpix[row] = a_out[p];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -240,8 +279,8 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
     constexpr int CH = BN / 8;
     for (int idx = tid; idx < BM * CH; idx += THREADS) {
       const int row = idx / CH, ch = idx % CH;
-      const int m = m0 + row, n = n0 + ch * 8;
-      if (m < P.M && n < P.N)
+      const int m = CLS ? rowpix[row] : m0 + row, n = n0 + ch * 8;
+      if (m >= 0 && m < P.M && n < P.N)
         *reinterpret_cast<uint4*>(C + (int64_t)m * P.ldc + n) = *reinterpret_cast<const uint4*>(Cs + row * CS_LD + ch * 8);
     }
   }
@@ -261,6 +300,7 @@ struct WgradArgs {
   int splits;
   int64_t slab_elems;  // KH*KW*Cin*Cout
   uint32_t x_bytes, dy_bytes;
+  int x_pix_stride;    // elements between consecutive pixels of X (== Cin except on the tiny-Cin path)
 };
 
 template <int TM, int TN>
@@ -304,13 +344,13 @@ __global__ __launch_bounds__(THREADS) void k_wgrad(WgradArgs P) {
         const int m = mbase + pg * 8;                                                                 \
         if (direct) {                                                                                 \
           _Pragma("unroll") for (int i = 0; i < 8; ++i)                                               \
-            rg[q][i] = buf_load16(rsrcX, (c_ok && m + i < P.M) ? (uint32_t)((m + i) * P.Cin + ch) * 2u : OOB); \
+            rg[q][i] = buf_load16(rsrcX, (c_ok && m + i < P.M) ? (uint32_t)((m + i) * P.x_pix_stride + ch) * 2u : OOB); \
         } else {                                                                                      \
           int wo = m % P.Wo, t = m / P.Wo, ho = t % P.Ho, n = t / P.Ho;                               \
           _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                             \
             const int hi = ho * P.sh - P.ph + r, wi = wo * P.sw - P.pw + s;                           \
             const bool ok = c_ok && (m + i) < P.M && (unsigned)hi < (unsigned)P.H && (unsigned)wi < (unsigned)P.W; \
-            rg[q][i] = buf_load16(rsrcX, ok ? (uint32_t)(((n * P.H + hi) * P.W + wi) * P.Cin + ch) * 2u : OOB); \
+            rg[q][i] = buf_load16(rsrcX, ok ? (uint32_t)(((n * P.H + hi) * P.W + wi) * P.x_pix_stride + ch) * 2u : OOB); \
             if (++wo == P.Wo) { wo = 0; if (++ho == P.Ho) { ho = 0; ++n; } }                          \
           }                                                                                           \
         }                                                                                             \
@@ -403,15 +443,46 @@ __global__ __launch_bounds__(THREADS) void k_wgrad(WgradArgs P) {
       }
 }
 
-// dw[i] = sum_s slab[s][i], s ascending (deterministic).  n_out <= slab_elems
-// lets the small-Cin (im2col) path drop its zero padding rows.
+// dw[i] = sum_s slab[s][i] in a FIXED order (deterministic => identical masks
+// run to run).  A workgroup owns 64 consecutive outputs; its 256 threads are 16
+// float4 columns x 16 split-groups, so 16 independent 256-B reads are in flight
+// per step instead of one thread walking all splits serially; group partials are
+// combined through LDS in ascending group order.  n_out <= slab_elems lets the
+// small-Cin (im2col) path drop its zero padding rows.
 __global__ __launch_bounds__(THREADS) void k_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw,
                                                            int64_t n_out, int64_t slab_elems, int splits) {
-  const int64_t stride = (int64_t)gridDim.x * THREADS;
-  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n_out; i += stride) {
-    float a = slabs[i];
-    for (int s2 = 1; s2 < splits; ++s2) a += slabs[(int64_t)s2 * slab_elems + i];
-    dw[i] = a;
+  __shared__ float4 part[16][16];
+  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int64_t i0 = (int64_t)blockIdx.x * 64 + col * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i0 + 3 < slab_elems && (slab_elems & 3) == 0) {
+#pragma unroll 4
+    for (int s2 = grp; s2 < splits; s2 += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(slabs + (int64_t)s2 * slab_elems + i0);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  } else {
+    for (int s2 = grp; s2 < splits; s2 += 16) {
+      const float* p = slabs + (int64_t)s2 * slab_elems;
+      if (i0 + 0 < slab_elems) acc.x += p[i0 + 0];
+      if (i0 + 1 < slab_elems) acc.y += p[i0 + 1];
+      if (i0 + 2 < slab_elems) acc.z += p[i0 + 2];
+      if (i0 + 3 < slab_elems) acc.w += p[i0 + 3];
+    }
+  }
+  part[grp][col] = acc;
+  __syncthreads();
+  if (grp == 0) {
+    float4 r = part[0][col];
+#pragma unroll
+    for (int g2 = 1; g2 < 16; ++g2) {
+      const float4 v = part[g2][col];
+      r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+    }
+    if (i0 + 0 < n_out) dw[i0 + 0] = r.x;
+    if (i0 + 1 < n_out) dw[i0 + 1] = r.y;
+    if (i0 + 2 < n_out) dw[i0 + 2] = r.z;
+    if (i0 + 3 < n_out) dw[i0 + 3] = r.w;
   }
 }
 
@@ -457,26 +528,108 @@ __global__ __launch_bounds__(THREADS) void k_pad_rows(const uint16_t* __restrict
   }
 }
 
+// ------------------------------------------------------------------ tiny-Cin (stem) path
+// Cin <= 4 (the 7x7x3 ImageNet stem, the 3x3x3 CIFAR stem).  Instead of an
+// explicit im2col (513 MB at batch 128) the image is copied once into a
+// zero-bordered, 4-channel NHWC buffer; one filter ROW then is KW*4 contiguous
+// bf16 in memory, so the conv runs on the ordinary kernels as a KHx1 conv with
+// "channel" count Cred = roundup(KW*4, 8) and pixel stride 4.  The surplus
+// elements of a row window (4th channel, pixels beyond KW) meet zero weights.
+struct PadArgs {
+  const uint16_t* X; uint16_t* XP;
+  int N, H, W, Cin, Hp, Wp, pt, pl;
+};
+__global__ __launch_bounds__(THREADS) void k_pad_input4(PadArgs P) {
+  const int64_t total = (int64_t)P.N * P.Hp * P.Wp;
+  const int64_t stride = (int64_t)gridDim.x * THREADS;
+  for (int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x; idx < total; idx += stride) {
+    const int xw = (int)(idx % P.Wp);
+    int64_t t = idx / P.Wp;
+    const int yh = (int)(t % P.Hp), n = (int)(t / P.Hp);
+    const int hi = yh - P.pt, wi = xw - P.pl;
+    uint16_t v[4] = {0, 0, 0, 0};
+    if ((unsigned)hi < (unsigned)P.H && (unsigned)wi < (unsigned)P.W) {
+      const uint16_t* src = P.X + ((int64_t)(n * P.H + hi) * P.W + wi) * P.Cin;
+      for (int c = 0; c < P.Cin; ++c) v[c] = src[c];
+    }
+    *reinterpret_cast<uint2*>(P.XP + idx * 4) = *reinterpret_cast<const uint2*>(v);
+  }
+}
+// wp[co][r][j], j = s*4 + c  <-  w_ohwi[co][(r*KW + s)*Cin + c]   (0 outside)
+__global__ __launch_bounds__(THREADS) void k_stem_weights(const uint16_t* __restrict__ w, uint16_t* __restrict__ wp,
+                                                           int cout, int KH, int KW, int Cin, int Cred) {
+  const int total = cout * KH * Cred;
+  for (int i = blockIdx.x * THREADS + threadIdx.x; i < total; i += gridDim.x * THREADS) {
+    const int j = i % Cred, r = (i / Cred) % KH, co = i / (Cred * KH);
+    const int s2 = j >> 2, c = j & 3;
+    wp[i] = (s2 < KW && c < Cin) ? w[(int64_t)co * KH * KW * Cin + (r * KW + s2) * Cin + c] : (uint16_t)0;
+  }
+}
+// dw[(r*KW+s)*Cin + c][co]  <-  t[r][s*4 + c][co]
+__global__ __launch_bounds__(THREADS) void k_stem_unpack(const float* __restrict__ t, float* __restrict__ dw, int KH,
+                                                          int KW, int Cin, int Cred, int cout) {
+  const int total = KH * KW * Cin * cout;
+  for (int i = blockIdx.x * THREADS + threadIdx.x; i < total; i += gridDim.x * THREADS) {
+    const int co = i % cout;
+    int k = i / cout;
+    const int c = k % Cin; k /= Cin;
+    const int s2 = k % KW, r = k / KW;
+    dw[i] = t[((int64_t)r * Cred + s2 * 4 + c) * cout + co];
+  }
+}
+struct TinyGeom { int cred, hp, wp; };
+static inline bool tiny_cin(const RiglConvDesc* d) { return d->cin <= 4; }
+static TinyGeom tiny_geom(const RiglConvDesc* d) {
+  TinyGeom g;
+  g.cred = (d->kw * 4 + 7) / 8 * 8;
+  const int need_h = (d->ho - 1) * d->stride_h + d->kh, need_w = (d->wo - 1) * d->stride_w + g.cred / 4;
+  g.hp = need_h > d->h + d->pad_top ? need_h : d->h + d->pad_top;
+  g.wp = need_w > d->w + d->pad_left ? need_w : d->w + d->pad_left;
+  return g;
+}
+
 // ------------------------------------------------------------------ dispatch
+template <int MODE, bool F32, bool CLS>
+static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, int bk, hipStream_t st) {
+  dim3 blk(THREADS);
+  if (wide_n) {
+    if (bk == 64) hipLaunchKernelGGL((k_igemm<2, 2, 64, MODE, F32, CLS>), grid, blk, 0, st, a);
+    else if (bk == 32) hipLaunchKernelGGL((k_igemm<2, 2, 32, MODE, F32, CLS>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((k_igemm<2, 2, 16, MODE, F32, CLS>), grid, blk, 0, st, a);
+  } else {
+    if (bk == 64) hipLaunchKernelGGL((k_igemm<2, 1, 64, MODE, F32, CLS>), grid, blk, 0, st, a);
+    else if (bk == 32) hipLaunchKernelGGL((k_igemm<2, 1, 32, MODE, F32, CLS>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((k_igemm<2, 1, 16, MODE, F32, CLS>), grid, blk, 0, st, a);
+  }
+}
+
 template <int MODE, bool F32>
 static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
   IgemmArgs a = a0;
   const bool wide_n = a.N > 64;
   const int BM = 128;
   const int BN = wide_n ? 128 : 64;
-  const int tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
-  dim3 grid((unsigned)(tiles_m * a.tiles_n)), blk(THREADS);
   const int bk = a.Cred >= 64 ? 64 : (a.Cred >= 32 ? 32 : 16);
-  if (wide_n) {
-    if (bk == 64) hipLaunchKernelGGL((k_igemm<2, 2, 64, MODE, F32>), grid, blk, 0, st, a);
-    else if (bk == 32) hipLaunchKernelGGL((k_igemm<2, 2, 32, MODE, F32>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((k_igemm<2, 2, 16, MODE, F32>), grid, blk, 0, st, a);
-  } else {
-    if (bk == 64) hipLaunchKernelGGL((k_igemm<2, 1, 64, MODE, F32>), grid, blk, 0, st, a);
-    else if (bk == 32) hipLaunchKernelGGL((k_igemm<2, 1, 32, MODE, F32>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((k_igemm<2, 1, 16, MODE, F32>), grid, blk, 0, st, a);
+  if (MODE == 1 && (a.sh > 1 || a.sw > 1) && a.sh <= 2 && a.sw <= 2) {
+    // class-major rows: class c = (h % sh) * sw + (w % sw)
+    const int n_img = a.M / (a.RH * a.RW);
+    int tiles = 0;
+    for (int c = 0; c < 4; ++c) {
+      const int ph = c / a.sw, pw = c % a.sw;
+      int hc = 0, wc = 0;
+      if (ph < a.sh && c < a.sh * a.sw) { hc = (a.RH - ph + a.sh - 1) / a.sh; wc = (a.RW - pw + a.sw - 1) / a.sw; }
+      a.cls_hc[c] = hc > 0 ? hc : 1; a.cls_wc[c] = wc > 0 ? wc : 1;
+      a.cls_cnt[c] = hc > 0 && wc > 0 ? n_img * hc * wc : 0;
+      a.cls_tile_begin[c] = tiles;
+      tiles += (a.cls_cnt[c] + BM - 1) / BM;
+    }
+    a.cls_tile_begin[4] = tiles;
+    launch_igemm_t<MODE, F32, true>(a, dim3((unsigned)(tiles * a.tiles_n)), wide_n, bk, st);
+    return;
   }
+  const int tiles_m = (a.M + BM - 1) / BM;
+  launch_igemm_t<MODE, F32, false>(a, dim3((unsigned)(tiles_m * a.tiles_n)), wide_n, bk, st);
 }
 
 static int check_desc(const RiglConvDesc* d, const char* who) {
@@ -494,7 +647,7 @@ static int check_desc(const RiglConvDesc* d, const char* who) {
   return RIGL_OK;
 }
 
-static inline bool small_cin(const RiglConvDesc* d) { return (d->cin % 8) != 0; }
+static inline bool small_cin(const RiglConvDesc* d) { return (d->cin % 8) != 0 && d->cin > 4; }
 static inline int kpad(const RiglConvDesc* d) { return (d->kh * d->kw * d->cin + 31) / 32 * 32; }
 
 struct WgradPlan { int tm, tn, tiles_ci, tiles_co, splits; int64_t slab; };
@@ -525,6 +678,16 @@ size_t rigl_conv2d_workspace_bytes(const RiglConvDesc* d, int32_t which) {
   using namespace rigl::k1;
   if (!d) return 0;
   const int64_t M = (int64_t)d->n * d->ho * d->wo;
+  if (tiny_cin(d)) {
+    const TinyGeom tg = tiny_geom(d);
+    const size_t xp = align_up((size_t)d->n * tg.hp * tg.wp * 4 * 2, 256);
+    if (which == 0) return xp + align_up((size_t)d->cout * d->kh * tg.cred * 2, 256);
+    if (which == 2) {
+      WgradPlan p = plan_wgrad((int)M, tg.cred, d->cout, d->kh);
+      return xp + align_up((size_t)p.slab * 4, 256) + align_up((size_t)p.splits * p.slab * 4, 256);
+    }
+    return 0;
+  }
   if (small_cin(d)) {
     const int Kp = kpad(d);
     size_t col = align_up((size_t)M * Kp * 2, 256);
@@ -554,25 +717,39 @@ int rigl_masked_conv2d_fwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl
   ProfScope prof(PROF_CONV_FWD, st);
   IgemmArgs a = {};
   a.C = y; a.M = d->n * d->ho * d->wo; a.N = d->cout; a.ldc = d->cout;
-  if (small_cin(d)) {
+  const size_t need = rigl_conv2d_workspace_bytes(d, 0);
+  if (need && (!workspace || workspace_bytes < need))
+    return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_fwd: workspace %zu < %zu", workspace_bytes, need);
+  if (tiny_cin(d)) {
+    const TinyGeom tg = tiny_geom(d);
+    const size_t xp_bytes = (size_t)d->n * tg.hp * tg.wp * 4 * 2;
+    uint16_t* xp = static_cast<uint16_t*>(workspace);
+    uint16_t* wp = reinterpret_cast<uint16_t*>(static_cast<char*>(workspace) + align_up(xp_bytes, 256));
+    PadArgs pa = {x, xp, d->n, d->h, d->w, d->cin, tg.hp, tg.wp, d->pad_top, d->pad_left};
+    hipLaunchKernelGGL(k_pad_input4, dim3(2048), dim3(THREADS), 0, st, pa);
+    hipLaunchKernelGGL(k_stem_weights, dim3(64), dim3(THREADS), 0, st, w_ohwi, wp, d->cout, d->kh, d->kw, d->cin, tg.cred);
+    a.A = xp; a.B = wp; a.Cred = tg.cred; a.a_pix_stride = 4; a.KH = d->kh; a.KW = 1; a.RH = d->ho; a.RW = d->wo;
+    a.GH = tg.hp; a.GW = tg.wp; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = a.pw = 0;
+    a.b_row_stride = d->kh * tg.cred; a.b_tap_stride = tg.cred;
+    a.a_bytes = (uint32_t)xp_bytes; a.b_bytes = (uint32_t)((size_t)d->cout * d->kh * tg.cred * 2);
+  } else if (small_cin(d)) {
     const int K = d->kh * d->kw * d->cin, Kp = kpad(d);
-    const size_t need = rigl_conv2d_workspace_bytes(d, 0);
-    if (!workspace || workspace_bytes < need) return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_fwd: workspace %zu < %zu", workspace_bytes, need);
     uint16_t* col = static_cast<uint16_t*>(workspace);
     uint16_t* wp = reinterpret_cast<uint16_t*>(static_cast<char*>(workspace) + align_up((size_t)a.M * Kp * 2, 256));
     Im2colArgs ia = {x, col, a.M, d->cin, d->kh, d->kw, d->h, d->w, d->ho, d->wo, d->stride_h, d->stride_w, d->pad_top, d->pad_left, K, Kp};
     hipLaunchKernelGGL(k_im2col, dim3(2048), dim3(THREADS), 0, st, ia);
     hipLaunchKernelGGL(k_pad_rows, dim3(64), dim3(THREADS), 0, st, w_ohwi, wp, d->cout, K, Kp);
-    a.A = col; a.B = wp; a.Cred = Kp; a.KH = a.KW = 1; a.RH = 1; a.RW = a.M; a.GH = 1; a.GW = a.M;
-    a.sh = a.sw = 1; a.ph = a.pw = 0; a.b_row_stride = Kp; a.b_tap_stride = 0;
     // row space = one long row of M pixels in a single "image"
+    a.A = col; a.B = wp; a.Cred = Kp; a.a_pix_stride = Kp; a.KH = a.KW = 1; a.RH = 1; a.RW = a.M; a.GH = 1; a.GW = a.M;
+    a.sh = a.sw = 1; a.ph = a.pw = 0; a.b_row_stride = Kp; a.b_tap_stride = 0;
+    a.a_bytes = (uint32_t)((size_t)a.M * Kp * 2); a.b_bytes = (uint32_t)((size_t)d->cout * Kp * 2);
   } else {
-    a.A = x; a.B = w_ohwi; a.Cred = d->cin; a.KH = d->kh; a.KW = d->kw; a.RH = d->ho; a.RW = d->wo;
+    a.A = x; a.B = w_ohwi; a.Cred = d->cin; a.a_pix_stride = d->cin; a.KH = d->kh; a.KW = d->kw; a.RH = d->ho; a.RW = d->wo;
     a.GH = d->h; a.GW = d->w; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
     a.b_row_stride = d->kh * d->kw * d->cin; a.b_tap_stride = d->cin;
+    a.a_bytes = (uint32_t)((size_t)d->n * d->h * d->w * d->cin * 2);
+    a.b_bytes = (uint32_t)((size_t)d->kh * d->kw * d->cin * d->cout * 2);
   }
-  a.a_bytes = (uint32_t)((size_t)a.M * 0 + (small_cin(d) ? (size_t)a.M * kpad(d) : (size_t)d->n * d->h * d->w * d->cin) * 2);
-  a.b_bytes = (uint32_t)((small_cin(d) ? (size_t)d->cout * kpad(d) : (size_t)d->kh * d->kw * d->cin * d->cout) * 2);
   launch_igemm<0, false>(a, st);
   RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
   return RIGL_OK;
@@ -594,7 +771,7 @@ int rigl_masked_conv2d_dgrad(const RiglConvDesc* d, const rigl_bf16* dy, const r
   a.M = d->n * d->h * d->w; a.N = d->cin; a.Cred = d->cout; a.ldc = d->cin;
   a.KH = d->kh; a.KW = d->kw; a.RH = d->h; a.RW = d->w; a.GH = d->ho; a.GW = d->wo;
   a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
-  a.b_row_stride = d->cout; a.b_tap_stride = d->cin * d->cout;
+  a.b_row_stride = d->cout; a.b_tap_stride = d->cin * d->cout; a.a_pix_stride = d->cout;
   a.a_bytes = (uint32_t)((size_t)d->n * d->ho * d->wo * d->cout * 2);
   a.b_bytes = (uint32_t)((size_t)d->kh * d->kw * d->cin * d->cout * 2);
   launch_igemm<1, false>(a, st);
@@ -616,26 +793,43 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   ProfScope prof(PROF_CONV_WGRAD, st);
   WgradArgs a = {};
   a.DY = dy; a.M = d->n * d->ho * d->wo; a.Cout = d->cout;
+  a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
   int64_t n_out;
   char* ws = static_cast<char*>(workspace);
-  if (small_cin(d)) {
+  float* tiny_tmp = nullptr;          // [kh][cred][cout] reduced result of the tiny-Cin path
+  TinyGeom tg = {0, 0, 0};
+  if (tiny_cin(d)) {
+    tg = tiny_geom(d);
+    const size_t xp_bytes = (size_t)d->n * tg.hp * tg.wp * 4 * 2;
+    uint16_t* xp = reinterpret_cast<uint16_t*>(ws);
+    ws += align_up(xp_bytes, 256);
+    PadArgs pa = {x, xp, d->n, d->h, d->w, d->cin, tg.hp, tg.wp, d->pad_top, d->pad_left};
+    hipLaunchKernelGGL(k_pad_input4, dim3(2048), dim3(THREADS), 0, st, pa);
+    a.X = xp; a.Cin = tg.cred; a.x_pix_stride = 4; a.KH = d->kh; a.KW = 1; a.H = tg.hp; a.W = tg.wp;
+    a.Ho = d->ho; a.Wo = d->wo; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = a.pw = 0;
+    a.x_bytes = (uint32_t)xp_bytes;
+    n_out = (int64_t)d->kh * tg.cred * d->cout;
+    tiny_tmp = reinterpret_cast<float*>(ws);
+    ws += align_up((size_t)n_out * 4, 256);
+  } else if (small_cin(d)) {
     const int K = d->kh * d->kw * d->cin, Kp = kpad(d);
     uint16_t* col = reinterpret_cast<uint16_t*>(ws);
     ws += align_up((size_t)a.M * Kp * 2, 256);
     Im2colArgs ia = {x, col, a.M, d->cin, d->kh, d->kw, d->h, d->w, d->ho, d->wo, d->stride_h, d->stride_w, d->pad_top, d->pad_left, K, Kp};
     hipLaunchKernelGGL(k_im2col, dim3(2048), dim3(THREADS), 0, st, ia);
-    a.X = col; a.Cin = Kp; a.KH = a.KW = 1; a.H = 1; a.W = a.M; a.Ho = 1; a.Wo = a.M; a.sh = a.sw = 1; a.ph = a.pw = 0;
+    a.X = col; a.Cin = Kp; a.x_pix_stride = Kp; a.KH = a.KW = 1; a.H = 1; a.W = a.M; a.Ho = 1; a.Wo = a.M;
+    a.sh = a.sw = 1; a.ph = a.pw = 0;
+    a.x_bytes = (uint32_t)((size_t)a.M * Kp * 2);
     n_out = (int64_t)K * d->cout;
   } else {
-    a.X = x; a.Cin = d->cin; a.KH = d->kh; a.KW = d->kw; a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo;
-    a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
+    a.X = x; a.Cin = d->cin; a.x_pix_stride = d->cin; a.KH = d->kh; a.KW = d->kw; a.H = d->h; a.W = d->w;
+    a.Ho = d->ho; a.Wo = d->wo; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
+    a.x_bytes = (uint32_t)((size_t)d->n * d->h * d->w * d->cin * 2);
     n_out = (int64_t)d->kh * d->kw * d->cin * d->cout;
   }
-  a.x_bytes = (uint32_t)((small_cin(d) ? (size_t)a.M * a.Cin : (size_t)d->n * d->h * d->w * d->cin) * 2);
-  a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
   WgradPlan p = plan_wgrad(a.M, a.Cin, a.Cout, a.KH * a.KW);
   a.tiles_ci = p.tiles_ci; a.tiles_co = p.tiles_co; a.splits = p.splits; a.slab_elems = p.slab;
-  const bool two_pass = p.splits > 1 || small_cin(d);
+  const bool two_pass = p.splits > 1 || small_cin(d) || tiny_cin(d);
   a.OUT = two_pass ? reinterpret_cast<float*>(ws) : dw;
   dim3 grid((unsigned)((int64_t)p.tiles_ci * p.tiles_co * a.KH * a.KW * p.splits)), blk(THREADS);
   if (p.tm == 2 && p.tn == 2) hipLaunchKernelGGL((k_wgrad<2, 2>), grid, blk, 0, st, a);
@@ -643,10 +837,12 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   else if (p.tn == 2) hipLaunchKernelGGL((k_wgrad<1, 2>), grid, blk, 0, st, a);
   else hipLaunchKernelGGL((k_wgrad<1, 1>), grid, blk, 0, st, a);
   if (two_pass) {
-    int64_t blocks = ceil_div64(n_out, THREADS);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)blocks), blk, 0, st, reinterpret_cast<const float*>(ws), dw, n_out, p.slab, p.splits);
+    const int64_t blocks = ceil_div64(n_out, 64);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)blocks), blk, 0, st, reinterpret_cast<const float*>(ws),
+                       tiny_tmp ? tiny_tmp : dw, n_out, p.slab, p.splits);
   }
+  if (tiny_tmp)
+    hipLaunchKernelGGL(k_stem_unpack, dim3(64), blk, 0, st, tiny_tmp, dw, d->kh, d->kw, d->cin, tg.cred, d->cout);
   RIGL_CHECK_LAUNCH("rigl_masked_conv2d_wgrad");
   return RIGL_OK;
 }

@@ -1,0 +1,79 @@
+"""CIFAR WideResNet (pre-activation, depth = 6n+4) from the masked layers --
+rigl/cifar_resnet/resnet_model.py:70-235.  BASELINE config 2 ("CIFAR-10
+ResNet-20") is depth 22, width 1.
+
+Kept from the reference: every 3x3 conv uses TF 'SAME' even at stride 2
+(asymmetric (0,1) padding on 32->16 and 16->8); the 1x1 skip conv is 'VALID'
+with the block's stride and takes the pre-activated tensor; the stem is dense
+unless ``prune_first_layer``; final BN-ReLU -> avg-pool 8 -> masked logits;
+l2 5e-4 on kernels; dropout is a no-op here (deterministic parity runs).
+"""
+import torch
+
+from rigl_amd import pruning_layers as PL
+from rigl_amd import variables as V
+from rigl_amd.workloads import nn as gnn
+from rigl_amd.workloads import shapes as WS
+
+
+class WideResNet:
+
+  def __init__(self, graph=None, depth=22, width=1, num_classes=10,
+               pruning_method='threshold', prune_first_layer=False,
+               prune_last_layer=True, weight_decay=5e-4, seed=0):
+    self.graph = g = graph or V.get_default_graph()
+    PL.set_init_seed(seed)
+    tech = pruning_method
+
+    def conv(name, k, cin, cout, stride, padding, technique, need_dx=True):
+      scope = WS.SCOPE + '/' + name
+      layer = PL.MaskedConv2d(g, scope, cin, cout, (k, k), (stride, stride), padding, technique, weight_decay,
+                              PL.variance_scaling_initializer(), need_dx)
+      g.modules[scope] = layer
+      return layer
+
+    self.stem = conv('conv_1', 3, 3, 16, 1, 'SAME', tech if prune_first_layer else 'baseline', need_dx=False)
+    self.blocks = []
+    cur = None
+    for name, k, cin, cout, stride, kind in WS.wide_resnet_convs(depth, width):
+      if kind == 'skip':
+        cur = dict(skip=conv(name, 1, cin, cout, stride, 'VALID', tech))
+      elif kind == 'conv1':
+        cur = cur if (cur is not None and 'conv1' not in cur) else {}
+        cur['bn_a'] = gnn.BatchNorm(g, '%s/%s_bn_a' % (WS.SCOPE, name), cin)
+        cur['conv1'] = conv(name, 3, cin, cout, stride, 'SAME', tech)
+        cur['bn_b'] = gnn.BatchNorm(g, '%s/%s_bn_b' % (WS.SCOPE, name), cout)
+      else:
+        cur['conv2'] = conv(name, 3, cout, cout, 1, 'SAME', tech)
+        self.blocks.append(cur)
+        cur = None
+    self.final_bn = gnn.BatchNorm(g, WS.SCOPE + '/final_bn', 64 * width)
+    self.logits = PL.MaskedDense(g, WS.SCOPE + '/logits', 64 * width, num_classes, True,
+                                 tech if prune_last_layer else 'baseline', weight_decay)
+    g.modules[WS.SCOPE + '/logits'] = self.logits
+    g.finalize()
+
+  def __call__(self, images, is_training=True):
+    net = self.stem(images)
+    for b in self.blocks:
+      skip = net
+      net = b['bn_a'](net, is_training, relu=True)
+      if 'skip' in b:
+        skip = b['skip'](net)
+      net = b['conv1'](net)
+      net = b['bn_b'](net, is_training, relu=True)
+      net = b['conv2'](net)
+      net = net + skip
+    net = self.final_bn(net, is_training, relu=True)
+    net = gnn.global_avg_pool(net)            # 8x8 map, pool_size 8
+    return self.logits(net)
+
+  def loss(self, images, labels, is_training=True):
+    return gnn.softmax_cross_entropy(self(images, is_training), labels, 0.0)
+
+
+def synthetic_batch(batch, device, seed=1234, num_classes=10):
+  gen = torch.Generator(device=device).manual_seed(seed)
+  images = torch.randn(batch, 32, 32, 3, generator=gen, device=device).to(torch.bfloat16)
+  labels = torch.randint(0, num_classes, (batch,), generator=gen, device=device)
+  return images, labels

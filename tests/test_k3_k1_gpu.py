@@ -157,6 +157,11 @@ CONV_CASES = [
     (1, 7, 7, 512, 512, 3, 1, 1, 1, 7, 7),          # late 3x3
     (2, 10, 10, 40, 72, 3, 1, 1, 1, 10, 10),        # channels % 8 == 0 but not % 16/32/64
     (130, 4, 4, 64, 64, 3, 1, 1, 1, 4, 4),          # many images, M not a tile multiple
+    (2, 15, 13, 16, 32, 3, 2, 1, 1, 8, 7),          # odd spatial sizes, stride 2 (parity classes of unequal size)
+    (3, 20, 20, 24, 40, 1, 2, 0, 0, 10, 10),        # 1x1 stride 2: three of four parity classes get no tap
+    (2, 17, 19, 3, 32, 3, 2, 0, 0, 9, 10),          # tiny-Cin, TF SAME stride 2 on odd sizes
+    (2, 12, 12, 4, 16, 5, 1, 2, 2, 12, 12),         # tiny-Cin = 4, 5x5
+    (2, 10, 10, 15, 24, 3, 1, 1, 1, 10, 10),        # Cin % 8 != 0 and > 4: explicit im2col path
 ]
 
 
