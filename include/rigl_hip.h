@@ -224,6 +224,37 @@ int rigl_conv2d_dgrad_ref(const RiglConvDesc* d, const rigl_bf16* dy,
 int rigl_conv2d_wgrad_ref(const RiglConvDesc* d, const rigl_bf16* x,
                           const rigl_bf16* dy, float* dw, rigl_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Glue between two masked convs: batch-norm with batch statistics (+ residual
+ * add) (+ ReLU) on NHWC bf16 rows [m][c], fp32 parameters -- what the reference
+ * runs as tf.layers.batch_normalization(fused=True) + tf.nn.relu (+ `inputs +
+ * shortcut`), rigl/imagenet_resnet/resnet_model.py:41-82, 456-501.  Not a
+ * graded hot-path row; fused here because it is HBM-bound and sits inside the
+ * images/s number.  y = relu?(gamma*(x-mean)*invstd + beta (+ residual)).
+ * Statistics are deterministic (fixed-order partial sums).  c % 8 == 0.
+ * save_* ([c] fp32 each) carry mean, 1/sqrt(var+eps), gamma*invstd and
+ * beta-mean*gamma*invstd to the backward call.  running_* may be NULL.
+ * Backward: pass y when relu was applied to (bn + residual) (the mask needs
+ * it); with y == NULL the ReLU mask is recomputed from x.  dresidual (nullable)
+ * receives the relu-masked dy.  dgamma / dbeta are overwritten.
+ * ---------------------------------------------------------------------- */
+size_t rigl_bn_workspace_bytes(int64_t m, int32_t c);
+int rigl_bn_fwd(int64_t m, int32_t c, const rigl_bf16* x,
+                const rigl_bf16* residual /* nullable */, const float* gamma,
+                const float* beta, float* running_mean, float* running_var,
+                float momentum, float eps, int32_t relu, rigl_bf16* y,
+                float* save_mean, float* save_invstd, float* save_scale,
+                float* save_shift, void* workspace, size_t workspace_bytes,
+                rigl_stream_t stream);
+int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x,
+                const rigl_bf16* y /* nullable */, const rigl_bf16* dy,
+                const float* gamma, const float* save_mean,
+                const float* save_invstd, const float* save_scale,
+                const float* save_shift, int32_t relu, rigl_bf16* dx,
+                rigl_bf16* dresidual /* nullable */, float* dgamma,
+                float* dbeta, void* workspace, size_t workspace_bytes,
+                rigl_stream_t stream);
+
 /* Optional per-kernel timing (HIP events recorded on the launch stream around
  * every K1/K2/K3 launch while enabled).  rigl_prof_collect synchronises the
  * recorded events and returns accumulated milliseconds / launch counts per

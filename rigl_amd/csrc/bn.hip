@@ -1,0 +1,332 @@
+// Fused batch-norm (+ residual add) (+ ReLU), forward and backward, for NHWC
+// bf16 activations with fp32 parameters / statistics.
+//
+// Not one of the graded hot-path rows but inside the images/s
+// number: between two masked convs the reference runs
+// tf.layers.batch_normalization(fused=True) + tf.nn.relu (+ the residual add)
+// (rigl/imagenet_resnet/resnet_model.py:41-82, 456-501).  Doing that with
+// stock ops costs ~13 full passes over the activation per layer; here it is
+//   forward : statistics (1 read) + apply (1 read [+1 residual], 1 write)
+//   backward: reductions (reads dy, x [,y]) + apply (reads dy, x [,y], writes dx [,dres])
+// All kernels are HBM-bound streams: 16 B per lane, channel-group-major thread
+// layout so every row access is one contiguous C*2-byte segment, per-block
+// partial sums combined in a FIXED order (deterministic statistics).
+#include "common.hpp"
+
+namespace rigl {
+namespace kbn {
+
+constexpr int THREADS = 256;
+constexpr int MAX_PARTS = 512;
+
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+__device__ __forceinline__ uint32_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return f2bf(a) | (f2bf(b) << 16); }
+__device__ __forceinline__ void unpack8(const uint4& v, float f[8]) {
+  f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
+  f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+}
+
+struct Geom {
+  int64_t M;
+  int C, cg;          // channels, 8-channel groups
+  int tpr, rpb;       // threads per row (pow2 >= min(cg,256)), rows per pass
+  int parts;          // row partitions (= gridDim.x of the reduction kernels)
+  int64_t rows_per_part;
+};
+
+// Reduction over rows of up to two per-channel quantities.
+//   MODE 0 (fwd stats): q0 = sum x, q1 = sum x^2
+//   MODE 1 (bwd)      : q0 = sum dz, q1 = sum dz * xhat,  dz = relu-masked dy
+template <int MODE, bool RELU, bool HAS_Y>
+__global__ __launch_bounds__(THREADS) void k_reduce(Geom G, const uint16_t* __restrict__ x, const uint16_t* __restrict__ y,
+                                                    const uint16_t* __restrict__ dy, const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, float* __restrict__ partial) {
+  __shared__ float red[THREADS][17];
+  const int tx = threadIdx.x % G.tpr, ty = threadIdx.x / G.tpr;
+  const int cgi = blockIdx.y * G.tpr + tx;
+  const bool c_ok = cgi < G.cg;
+  const int64_t r0 = (int64_t)blockIdx.x * G.rows_per_part;
+  int64_t r1 = r0 + G.rows_per_part;
+  if (r1 > G.M) r1 = G.M;
+  float q0[8], q1[8], mu[8], is[8], sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { q0[j] = q1[j] = 0.f; mu[j] = is[j] = sc[j] = sh[j] = 0.f; }
+  if (MODE == 1 && c_ok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mu[j] = mean[cgi * 8 + j]; is[j] = invstd[cgi * 8 + j];
+      if (RELU && !HAS_Y) { sc[j] = scale[cgi * 8 + j]; sh[j] = shift[cgi * 8 + j]; }
+    }
+  }
+  if (c_ok) {
+#pragma unroll 2
+    for (int64_t r = r0 + ty; r < r1; r += G.rpb) {
+      const int64_t off = r * G.C + (int64_t)cgi * 8;
+      float xv[8];
+      unpack8(*reinterpret_cast<const uint4*>(x + off), xv);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { q0[j] += xv[j]; q1[j] = fmaf(xv[j], xv[j], q1[j]); }
+      } else {
+        float dv[8], yv[8];
+        unpack8(*reinterpret_cast<const uint4*>(dy + off), dv);
+        if (RELU && HAS_Y) unpack8(*reinterpret_cast<const uint4*>(y + off), yv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          bool on = true;
+          if (RELU) on = HAS_Y ? (yv[j] > 0.f) : (fmaf(xv[j], sc[j], sh[j]) > 0.f);
+          const float dz = on ? dv[j] : 0.f;
+          q0[j] += dz;
+          q1[j] = fmaf(dz, (xv[j] - mu[j]) * is[j], q1[j]);
+        }
+      }
+    }
+  }
+  // combine the `rpb` row-lanes of each channel group (fixed tree order)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = q0[j]; red[threadIdx.x][8 + j] = q1[j]; }
+  __syncthreads();
+  for (int s = G.rpb >> 1; s > 0; s >>= 1) {
+    if (ty < s) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) red[threadIdx.x][j] += red[threadIdx.x + s * G.tpr][j];
+    }
+    __syncthreads();
+  }
+  if (ty == 0 && c_ok) {
+    float* p = partial + ((int64_t)blockIdx.x * 2) * G.C + cgi * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { p[j] = red[threadIdx.x][j]; p[G.C + j] = red[threadIdx.x][8 + j]; }
+  }
+}
+
+// Forward finalize: mean / invstd, running statistics, fused scale & shift.
+__global__ __launch_bounds__(THREADS) void k_fwd_finalize(Geom G, const float* __restrict__ partial,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float momentum, float eps, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd, float* __restrict__ scale,
+                                                           float* __restrict__ shift) {
+  const int c = blockIdx.x * THREADS + threadIdx.x;
+  if (c >= G.C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int p = 0; p < G.parts; ++p) {
+    s0 += (double)partial[((int64_t)p * 2) * G.C + c];
+    s1 += (double)partial[((int64_t)p * 2 + 1) * G.C + c];
+  }
+  const double m = (double)G.M;
+  const double mean = s0 / m;
+  double var = s1 / m - mean * mean;           // biased variance normalises (TF fused BN)
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  save_mean[c] = (float)mean;
+  save_invstd[c] = invstd;
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  if (running_mean) {
+    const double unbiased = G.M > 1 ? var * m / (m - 1.0) : var;   // moving variance uses Bessel's correction
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// y = relu?(x * scale + shift (+ residual))
+template <bool RELU, bool HAS_RES>
+__global__ __launch_bounds__(THREADS) void k_fwd_apply(Geom G, const uint16_t* __restrict__ x, const uint16_t* __restrict__ res,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        uint16_t* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float prm[];   // [2][C]
+  for (int i = threadIdx.x; i < G.C; i += THREADS) { prm[i] = scale[i]; prm[G.C + i] = shift[i]; }
+  __syncthreads();
+  const int64_t total = G.M * G.cg;
+  const int64_t stride = (int64_t)gridDim.x * THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += stride) {
+    const int cgi = (int)(i % G.cg);
+    float xv[8], rv[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + i * 8), xv);
+    if (HAS_RES) unpack8(*reinterpret_cast<const uint4*>(res + i * 8), rv);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = fmaf(xv[j], prm[cgi * 8 + j], prm[G.C + cgi * 8 + j]);
+      if (HAS_RES) v += rv[j];
+      o[j] = RELU ? fmaxf(v, 0.f) : v;
+    }
+    uint4 out;
+    out.x = pack2(o[0], o[1]); out.y = pack2(o[2], o[3]); out.z = pack2(o[4], o[5]); out.w = pack2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(y + i * 8) = out;
+  }
+}
+
+// Backward finalize: dgamma, dbeta and the per-channel coefficients of dx.
+__global__ __launch_bounds__(THREADS) void k_bwd_finalize(Geom G, const float* __restrict__ partial,
+                                                           const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ coef /*[3][C]: a, b, c*/) {
+  const int c = blockIdx.x * THREADS + threadIdx.x;
+  if (c >= G.C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int p = 0; p < G.parts; ++p) {
+    s0 += (double)partial[((int64_t)p * 2) * G.C + c];
+    s1 += (double)partial[((int64_t)p * 2 + 1) * G.C + c];
+  }
+  dbeta[c] = (float)s0;
+  dgamma[c] = (float)s1;
+  coef[c] = gamma[c] * invstd[c];
+  coef[G.C + c] = (float)(s0 / (double)G.M);
+  coef[2 * G.C + c] = (float)(s1 / (double)G.M);
+}
+
+// dx = a * (dz - b - xhat * c);  dres = dz
+template <bool RELU, bool HAS_Y, bool HAS_DRES>
+__global__ __launch_bounds__(THREADS) void k_bwd_apply(Geom G, const uint16_t* __restrict__ x, const uint16_t* __restrict__ y,
+                                                        const uint16_t* __restrict__ dy, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, const float* __restrict__ coef,
+                                                        uint16_t* __restrict__ dx, uint16_t* __restrict__ dres) {
+  extern __shared__ __attribute__((aligned(16))) float prm[];   // [7][C]: mean, invstd, a, b, c, scale, shift
+  for (int i = threadIdx.x; i < G.C; i += THREADS) {
+    prm[i] = mean[i]; prm[G.C + i] = invstd[i];
+    prm[2 * G.C + i] = coef[i]; prm[3 * G.C + i] = coef[G.C + i]; prm[4 * G.C + i] = coef[2 * G.C + i];
+    if (RELU && !HAS_Y) { prm[5 * G.C + i] = scale[i]; prm[6 * G.C + i] = shift[i]; }
+  }
+  __syncthreads();
+  const int64_t total = G.M * G.cg;
+  const int64_t stride = (int64_t)gridDim.x * THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += stride) {
+    const int c0 = (int)(i % G.cg) * 8;
+    float xv[8], dv[8], yv[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + i * 8), xv);
+    unpack8(*reinterpret_cast<const uint4*>(dy + i * 8), dv);
+    if (RELU && HAS_Y) unpack8(*reinterpret_cast<const uint4*>(y + i * 8), yv);
+    float o[8], z[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bool on = true;
+      if (RELU) on = HAS_Y ? (yv[j] > 0.f) : (fmaf(xv[j], prm[5 * G.C + c0 + j], prm[6 * G.C + c0 + j]) > 0.f);
+      const float dz = on ? dv[j] : 0.f;
+      const float xh = (xv[j] - prm[c0 + j]) * prm[G.C + c0 + j];
+      o[j] = prm[2 * G.C + c0 + j] * (dz - prm[3 * G.C + c0 + j] - xh * prm[4 * G.C + c0 + j]);
+      z[j] = dz;
+    }
+    uint4 out;
+    out.x = pack2(o[0], o[1]); out.y = pack2(o[2], o[3]); out.z = pack2(o[4], o[5]); out.w = pack2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(dx + i * 8) = out;
+    if (HAS_DRES) {
+      out.x = pack2(z[0], z[1]); out.y = pack2(z[2], z[3]); out.z = pack2(z[4], z[5]); out.w = pack2(z[6], z[7]);
+      *reinterpret_cast<uint4*>(dres + i * 8) = out;
+    }
+  }
+}
+
+static Geom make_geom(int64_t m, int c) {
+  Geom g;
+  g.M = m; g.C = c; g.cg = c / 8;
+  int tpr = 1;
+  while (tpr < g.cg && tpr < THREADS) tpr <<= 1;
+  g.tpr = tpr; g.rpb = THREADS / tpr;
+  int64_t parts = (m + (int64_t)g.rpb * 16 - 1) / ((int64_t)g.rpb * 16);   // >= 16 rows per row-lane
+  if (parts > MAX_PARTS) parts = MAX_PARTS;
+  if (parts < 1) parts = 1;
+  int64_t rpp = (m + parts - 1) / parts;
+  rpp = (rpp + g.rpb - 1) / g.rpb * g.rpb;
+  g.rows_per_part = rpp;
+  g.parts = (int)((m + rpp - 1) / rpp);
+  return g;
+}
+
+static unsigned apply_grid(const Geom& g) {
+  int64_t b = (g.M * g.cg + THREADS * 4 - 1) / (THREADS * 4);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace kbn
+}  // namespace rigl
+
+extern "C" {
+
+size_t rigl_bn_workspace_bytes(int64_t m, int32_t c) {
+  if (m <= 0 || c <= 0) return 0;
+  rigl::kbn::Geom g = rigl::kbn::make_geom(m, c);
+  // partial sums [parts][2][C] + scale/shift or coef [3][C]
+  return rigl::align_up((size_t)g.parts * 2 * c * 4, 256) + rigl::align_up((size_t)3 * c * 4, 256);
+}
+
+int rigl_bn_fwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* residual, const float* gamma,
+                const float* beta, float* running_mean, float* running_var, float momentum, float eps, int32_t relu,
+                rigl_bf16* y, float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
+                void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+  using namespace rigl;
+  using namespace rigl::kbn;
+  if (m <= 0 || c <= 0 || !x || !gamma || !beta || !y || !save_mean || !save_invstd || !save_scale || !save_shift)
+    return fail(RIGL_EINVAL, "rigl_bn_fwd: bad arguments");
+  if (c % 8) return fail(RIGL_EUNSUPPORTED, "rigl_bn_fwd: channels %% 8 != 0");
+  if (2 * (size_t)c * 4 > 65536) return fail(RIGL_EUNSUPPORTED, "rigl_bn_fwd: too many channels for the LDS parameter cache");
+  const size_t need = rigl_bn_workspace_bytes(m, c);
+  if (!workspace || workspace_bytes < need) return fail(RIGL_EWORKSPACE, "rigl_bn_fwd: workspace %zu < %zu", workspace_bytes, need);
+  hipStream_t st = as_stream(stream);
+  Geom g = make_geom(m, c);
+  float* partial = static_cast<float*>(workspace);
+  dim3 rgrid((unsigned)g.parts, (unsigned)((g.cg + g.tpr - 1) / g.tpr));
+  hipLaunchKernelGGL((k_reduce<0, false, false>), rgrid, dim3(THREADS), 0, st, g, x, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, partial);
+  hipLaunchKernelGGL(k_fwd_finalize, dim3((unsigned)((c + THREADS - 1) / THREADS)), dim3(THREADS), 0, st, g, partial, gamma,
+                     beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale, save_shift);
+  const size_t lds = (size_t)2 * c * 4;
+  dim3 agrid(apply_grid(g));
+  if (relu && residual) hipLaunchKernelGGL((k_fwd_apply<true, true>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y);
+  else if (relu) hipLaunchKernelGGL((k_fwd_apply<true, false>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y);
+  else if (residual) hipLaunchKernelGGL((k_fwd_apply<false, true>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y);
+  else hipLaunchKernelGGL((k_fwd_apply<false, false>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y);
+  RIGL_CHECK_LAUNCH("rigl_bn_fwd");
+  return RIGL_OK;
+}
+
+int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* y, const rigl_bf16* dy, const float* gamma,
+                const float* save_mean, const float* save_invstd, const float* save_scale, const float* save_shift,
+                int32_t relu, rigl_bf16* dx, rigl_bf16* dresidual, float* dgamma, float* dbeta, void* workspace,
+                size_t workspace_bytes, rigl_stream_t stream) {
+  using namespace rigl;
+  using namespace rigl::kbn;
+  if (m <= 0 || c <= 0 || !x || !dy || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta)
+    return fail(RIGL_EINVAL, "rigl_bn_bwd: bad arguments");
+  if (c % 8) return fail(RIGL_EUNSUPPORTED, "rigl_bn_bwd: channels %% 8 != 0");
+  if (relu && !y && (!save_scale || !save_shift)) return fail(RIGL_EINVAL, "rigl_bn_bwd: relu needs y or scale/shift");
+  if (7 * (size_t)c * 4 > 65536) return fail(RIGL_EUNSUPPORTED, "rigl_bn_bwd: too many channels for the LDS parameter cache");
+  const size_t need = rigl_bn_workspace_bytes(m, c);
+  if (!workspace || workspace_bytes < need) return fail(RIGL_EWORKSPACE, "rigl_bn_bwd: workspace %zu < %zu", workspace_bytes, need);
+  hipStream_t st = as_stream(stream);
+  Geom g = make_geom(m, c);
+  float* partial = static_cast<float*>(workspace);
+  float* coef = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)g.parts * 2 * c * 4, 256));
+  dim3 rgrid((unsigned)g.parts, (unsigned)((g.cg + g.tpr - 1) / g.tpr));
+  const bool has_y = y != nullptr;
+  if (!relu) hipLaunchKernelGGL((k_reduce<1, false, false>), rgrid, dim3(THREADS), 0, st, g, x, y, dy, save_mean, save_invstd, save_scale, save_shift, partial);
+  else if (has_y) hipLaunchKernelGGL((k_reduce<1, true, true>), rgrid, dim3(THREADS), 0, st, g, x, y, dy, save_mean, save_invstd, save_scale, save_shift, partial);
+  else hipLaunchKernelGGL((k_reduce<1, true, false>), rgrid, dim3(THREADS), 0, st, g, x, y, dy, save_mean, save_invstd, save_scale, save_shift, partial);
+  hipLaunchKernelGGL(k_bwd_finalize, dim3((unsigned)((c + THREADS - 1) / THREADS)), dim3(THREADS), 0, st, g, partial, gamma,
+                     save_invstd, dgamma, dbeta, coef);
+  const size_t lds = (size_t)7 * c * 4;
+  dim3 agrid(apply_grid(g));
+#define RIGL_BWD_APPLY(R, Y, D) hipLaunchKernelGGL((k_bwd_apply<R, Y, D>), agrid, dim3(THREADS), lds, st, g, x, y, dy, save_mean, save_invstd, save_scale, save_shift, coef, dx, dresidual)
+  const bool dres = dresidual != nullptr;
+  if (!relu) { if (dres) RIGL_BWD_APPLY(false, false, true); else RIGL_BWD_APPLY(false, false, false); }
+  else if (has_y) { if (dres) RIGL_BWD_APPLY(true, true, true); else RIGL_BWD_APPLY(true, true, false); }
+  else { if (dres) RIGL_BWD_APPLY(true, false, true); else RIGL_BWD_APPLY(true, false, false); }
+#undef RIGL_BWD_APPLY
+  RIGL_CHECK_LAUNCH("rigl_bn_bwd");
+  return RIGL_OK;
+}
+
+}  // extern "C"

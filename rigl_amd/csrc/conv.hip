@@ -85,6 +85,7 @@ struct IgemmArgs {
   // filter taps that can reach its pixels (3x3/2: 1, 2, 2 or 4 taps, not 9).
   int cls_tile_begin[5];       // tile_m prefix per class (sh*sw <= 4 classes)
   int cls_cnt[4], cls_hc[4], cls_wc[4];
+  int cls_n, cls_ids[4], cls_interleave;   // non-empty classes and the common tile count they interleave over
 };
 
 template <int TM, int TN, int BK, int MODE /*0 fwd, 1 dgrad*/, bool OUT_F32, bool CLS>
@@ -106,9 +107,26 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
   int m0 = tile_m * BM;
   int c_ph = 0, c_pw = 0, c_cnt = P.M, c_hc = 1, c_wc = 1;
   if (CLS) {
-    int c = 0;
-    while (c < 3 && tile_m >= P.cls_tile_begin[c + 1]) ++c;
-    m0 = (tile_m - P.cls_tile_begin[c]) * BM;           // index inside the class
+    // Classes differ in work (3x3/2: 4, 2, 2, 1 taps; 1x1/2: 1, 0, 0, 0), and the
+    // XCD remap hands each XCD a contiguous range of tile_m -- so interleave the
+    // classes over tile_m (round-robin while every class still has tiles, the
+    // few left-over tiles class by class) to keep the 8 XCDs evenly loaded.
+    int c, local;
+    const int il = P.cls_interleave * P.cls_n;           // tiles covered by the round-robin part
+    if (tile_m < il) {
+      c = P.cls_ids[tile_m % P.cls_n]; local = tile_m / P.cls_n;
+    } else {
+      int rest = tile_m - il;
+      c = 0; local = 0;
+      for (int k = 0; k < 4; ++k) {
+        const int tc = P.cls_tile_begin[k + 1] - P.cls_tile_begin[k];
+        const int extra = tc > P.cls_interleave ? tc - P.cls_interleave : (P.cls_cnt[k] > 0 ? 0 : 0);
+        const int have = P.cls_cnt[k] > 0 ? extra : tc;  // empty classes own no tiles
+        if (rest < have) { c = k; local = (P.cls_cnt[k] > 0 ? P.cls_interleave : 0) + rest; break; }
+        rest -= have;
+      }
+    }
+    m0 = local * BM;                                     // index inside the class
     c_ph = c / P.sw; c_pw = c % P.sw;
     c_cnt = P.cls_cnt[c]; c_hc = P.cls_hc[c]; c_wc = P.cls_wc[c];
   }
@@ -625,6 +643,12 @@ static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
       tiles += (a.cls_cnt[c] + BM - 1) / BM;
     }
     a.cls_tile_begin[4] = tiles;
+    a.cls_n = 0; a.cls_interleave = 1 << 30;
+    for (int c = 0; c < 4; ++c) {
+      const int tc = a.cls_tile_begin[c + 1] - a.cls_tile_begin[c];
+      if (tc > 0) { a.cls_ids[a.cls_n++] = c; if (tc < a.cls_interleave) a.cls_interleave = tc; }
+    }
+    if (a.cls_n == 0) { a.cls_n = 1; a.cls_ids[0] = 0; a.cls_interleave = 0; }
     launch_igemm_t<MODE, F32, true>(a, dim3((unsigned)(tiles * a.tiles_n)), wide_n, bk, st);
     return;
   }

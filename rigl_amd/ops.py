@@ -272,6 +272,50 @@ def conv_wgrad(d, x, dy, dw=None, force_ref=False):
 
 
 # ----------------------------------------------------------------------------
+# fused batch-norm (+ residual) (+ ReLU)
+# ----------------------------------------------------------------------------
+def bn_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu,
+           residual=None):
+  """x [..., C] bf16 contiguous.  Returns (y, saved) with saved = fp32 [4, C]
+  (mean, invstd, scale, shift)."""
+  _req(x, torch.bfloat16, 'x')
+  _req(residual, torch.bfloat16, 'residual', allow_none=True)
+  for t, nm in ((gamma, 'gamma'), (beta, 'beta')):
+    _req(t, torch.float32, nm)
+  c = x.shape[-1]
+  m = x.numel() // c
+  lib = _lib.load()
+  y = torch.empty_like(x)
+  saved = torch.empty((4, c), dtype=torch.float32, device=x.device)
+  ws = workspace(lib.rigl_bn_workspace_bytes(m, c), x.device)
+  check(lib.rigl_bn_fwd(m, c, _ptr(x), _ptr(residual), _ptr(gamma), _ptr(beta),
+                        _ptr(running_mean), _ptr(running_var), float(momentum),
+                        float(eps), int(bool(relu)), _ptr(y), _ptr(saved[0]),
+                        _ptr(saved[1]), _ptr(saved[2]), _ptr(saved[3]), _ptr(ws),
+                        ws.numel(), _stream()))
+  return y, saved
+
+
+def bn_bwd(x, y, dy, gamma, saved, relu, dgamma, dbeta, want_dres=False):
+  """Returns (dx, dres|None); dgamma / dbeta (fp32 [C]) are overwritten."""
+  _req(x, torch.bfloat16, 'x')
+  _req(dy, torch.bfloat16, 'dy')
+  _req(y, torch.bfloat16, 'y', allow_none=True)
+  c = x.shape[-1]
+  m = x.numel() // c
+  lib = _lib.load()
+  dx = torch.empty_like(x)
+  dres = torch.empty_like(x) if want_dres else None
+  ws = workspace(lib.rigl_bn_workspace_bytes(m, c), x.device)
+  check(lib.rigl_bn_bwd(m, c, _ptr(x), _ptr(y), _ptr(dy), _ptr(gamma),
+                        _ptr(saved[0]), _ptr(saved[1]), _ptr(saved[2]),
+                        _ptr(saved[3]), int(bool(relu)), _ptr(dx), _ptr(dres),
+                        _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(),
+                        _stream()))
+  return dx, dres
+
+
+# ----------------------------------------------------------------------------
 # profiling
 # ----------------------------------------------------------------------------
 def prof_enable(on=True):

@@ -26,13 +26,50 @@ def nhwc_view(x):
   return x.permute(0, 2, 3, 1)
 
 
+class _FusedBNFn(torch.autograd.Function):
+  """y = relu?(bn(x) (+ residual)) through rigl_bn_fwd / rigl_bn_bwd.  The
+  parameter gradients go straight into the gradient arena (overwrite), like
+  the conv kernels' dW; autograd only routes dx (and the residual's grad)."""
+
+  @staticmethod
+  def forward(ctx, x, residual, bn, relu):
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    x = x.contiguous()
+    res = residual.contiguous() if residual is not None else None
+    y, saved = ops.bn_fwd(x, bn.gamma.data, bn.beta.data, bn.moving_mean,
+                          bn.moving_variance, 1.0 - bn.decay, bn.eps, relu, res)
+    ctx.bn, ctx.relu, ctx.has_res = bn, relu, res is not None
+    # the ReLU mask of bn+residual needs y; without a residual it is recomputed from x
+    if relu and res is not None:
+      ctx.save_for_backward(x, saved, y)
+    else:
+      ctx.save_for_backward(x, saved)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    bn = ctx.bn
+    if ctx.relu and ctx.has_res:
+      x, saved, y = ctx.saved_tensors
+    else:
+      (x, saved), y = ctx.saved_tensors, None
+    dx, dres = ops.bn_bwd(x, y, dy.contiguous(), bn.gamma.data, saved, ctx.relu,
+                          bn.gamma.grad, bn.beta.grad,
+                          want_dres=ctx.has_res and ctx.needs_input_grad[1])
+    return dx, dres, None, None
+
+
 class BatchNorm:
   """tf.layers.batch_normalization(momentum=0.9, eps=1e-5, fused) over the
-  channel axis (resnet_model.py:41-82).  gamma/beta live in the graph's
-  BN/bias arena segment; moving statistics are plain buffers."""
+  channel axis (resnet_model.py:41-82), optionally fused with the residual add
+  and the ReLU that follow it.  gamma/beta live in the graph's BN/bias arena
+  segment; moving statistics are plain buffers.  Training mode with
+  channels % 8 == 0 runs the fused HIP kernels (bn.hip); anything else falls
+  back to the stock PyTorch ops (this is glue, not the graded path)."""
 
   def __init__(self, graph, scope, channels, init_zero=False,
-               decay=BATCH_NORM_DECAY, eps=BATCH_NORM_EPSILON):
+               decay=BATCH_NORM_DECAY, eps=BATCH_NORM_EPSILON, fused=True):
     self.gamma = graph.add_variable(scope + '/gamma', (channels,), V.KIND_OTHER,
                                     0.0, init=None)
     if not init_zero:
@@ -41,14 +78,24 @@ class BatchNorm:
     self.moving_mean = torch.zeros(channels, device=graph.device)
     self.moving_variance = torch.ones(channels, device=graph.device)
     self.decay, self.eps = decay, eps
+    self.channels = channels
+    self.fused = fused
 
-  def __call__(self, x, is_training=True, relu=False):
+  def __call__(self, x, is_training=True, relu=False, residual=None):
+    if (self.fused and is_training and x.is_cuda and self.channels % 8 == 0
+        and x.dtype == torch.bfloat16):
+      if not x.requires_grad:
+        x = x.detach().requires_grad_(True)
+      return _FusedBNFn.apply(x, residual, self, relu)
     y = F.batch_norm(nchw_view(x), self.moving_mean, self.moving_variance,
                      bias_tensor(self.gamma), bias_tensor(self.beta),
                      is_training, 1.0 - self.decay, self.eps)
+    y = nhwc_view(y)
+    if residual is not None:
+      y = y + residual
     if relu:
-      y = F.relu(y, inplace=True)
-    return nhwc_view(y)
+      y = F.relu(y)
+    return y
 
 
 def max_pool_3x3_s2_same(x):

@@ -72,8 +72,7 @@ class _Bottleneck:
       shortcut = self.proj_bn(self.proj(x), is_training, relu=False)
     y = self.bn1(self.c1(x), is_training, relu=True)
     y = self.bn2(self.c2(y), is_training, relu=True)
-    y = self.bn3(self.c3(y), is_training, relu=False)
-    return torch.relu_(y + shortcut)
+    return self.bn3(self.c3(y), is_training, relu=True, residual=shortcut)   # relu(bn3 + shortcut)
 
 
 class ResNet50:

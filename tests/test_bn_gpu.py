@@ -1,0 +1,74 @@
+"""Fused BN (+residual) (+ReLU) glue kernels vs PyTorch's batch_norm / relu in
+fp32 on the same bf16 operands (forward, backward, running statistics)."""
+import pytest
+
+torch = pytest.importorskip('torch')
+import torch.nn.functional as F  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _ref(x, res, gamma, beta, relu, dy, eps=1e-5):
+  xr = x.float().requires_grad_(True)
+  rr = res.float().requires_grad_(True) if res is not None else None
+  g = gamma.clone().requires_grad_(True)
+  b = beta.clone().requires_grad_(True)
+  rm, rv = torch.zeros_like(gamma), torch.ones_like(gamma)
+  c = x.shape[-1]
+  y = F.batch_norm(xr.reshape(-1, c), rm, rv, g, b, True, 0.1, eps).reshape(x.shape)
+  if rr is not None:
+    y = y + rr
+  if relu:
+    y = F.relu(y)
+  y.backward(dy.float())
+  return y.detach(), xr.grad, (rr.grad if rr is not None else None), g.grad, b.grad, rm, rv
+
+
+@pytest.mark.parametrize('shape', [(4, 14, 14, 64), (2, 7, 7, 2048), (3, 9, 5, 16), (1, 1, 1, 8), (2, 28, 28, 256),
+                                   (33, 3, 3, 40), (2, 56, 56, 64)])
+@pytest.mark.parametrize('relu,with_res', [(False, False), (True, False), (True, True), (False, True)])
+def test_fused_bn(shape, relu, with_res):
+  from rigl_amd import ops
+  if shape[0] * shape[1] * shape[2] == 1:
+    pytest.skip('batch statistics of one row are degenerate')
+  gen = torch.Generator(device=DEV).manual_seed(sum(shape) + relu + 2 * with_res)
+  c = shape[-1]
+  x = (torch.randn(shape, generator=gen, device=DEV) * 1.7 + 0.3).to(torch.bfloat16)
+  res = torch.randn(shape, generator=gen, device=DEV).to(torch.bfloat16) if with_res else None
+  dy = torch.randn(shape, generator=gen, device=DEV).to(torch.bfloat16)
+  gamma = torch.rand(c, generator=gen, device=DEV) + 0.5
+  beta = torch.randn(c, generator=gen, device=DEV) * 0.2
+  rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+  y, saved = ops.bn_fwd(x, gamma, beta, rm, rv, 0.1, 1e-5, relu, res)
+  dgamma, dbeta = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+  dx, dres = ops.bn_bwd(x, y if (relu and with_res) else None, dy, gamma, saved, relu, dgamma, dbeta,
+                        want_dres=with_res)
+  yr, dxr, dresr, dgr, dbr, rmr, rvr = _ref(x, res, gamma, beta, relu, dy)
+
+  def close(a, b, rel, what):
+    err = (a.float() - b).abs().max().item()
+    tol = rel * b.abs().max().item() + 1e-6
+    assert err <= tol, '%s: %g > %g' % (what, err, tol)
+
+  close(y, yr, 2.0**-7, 'y')
+  # a handful of elements sit within bf16 rounding of the ReLU knee; exclude exact-zero disagreements
+  agree = ((y.float() > 0) == (yr > 0)) if relu else torch.ones_like(yr, dtype=torch.bool)
+  assert agree.float().mean() > 0.999
+  close(dx.float() * agree, dxr * agree, 2e-2, 'dx')
+  close(dgamma, dgr, 2e-2, 'dgamma')
+  close(dbeta, dbr, 2e-2, 'dbeta')
+  if with_res:
+    close(dres.float() * agree, dresr * agree, 2.0**-7, 'dres')
+  close(rm, rmr, 1e-3, 'running_mean')
+  close(rv, rvr, 1e-3, 'running_var')
+  close(saved[0], x.float().reshape(-1, c).mean(0), 1e-4, 'saved mean')
+
+
+def test_fused_bn_is_deterministic():
+  from rigl_amd import ops
+  x = torch.randn(8, 28, 28, 128, device=DEV).to(torch.bfloat16)
+  gamma, beta = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
+  y1, s1 = ops.bn_fwd(x, gamma, beta, None, None, 0.1, 1e-5, True)
+  y2, s2 = ops.bn_fwd(x, gamma, beta, None, None, 0.1, 1e-5, True)
+  assert torch.equal(y1, y2) and torch.equal(s1, s2)
