@@ -108,6 +108,31 @@ __global__ __launch_bounds__(THREADS) void k_reduce(Geom G, const uint16_t* __re
   }
 }
 
+// Sums the per-part partials of 16 channels with 16 part-lanes each (fixed
+// order: lane-strided, then lanes ascending) -- a 256-thread block per 16
+// channels instead of one thread walking all parts serially.
+__device__ __forceinline__ void sum_partials(const Geom& G, const float* __restrict__ partial, double& s0, double& s1,
+                                             int& c, bool& leader) {
+  __shared__ double acc[2][16][17];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  c = blockIdx.x * 16 + cl;
+  double a0 = 0.0, a1 = 0.0;
+  if (c < G.C) {
+    for (int p = pl; p < G.parts; p += 16) {
+      a0 += (double)partial[((int64_t)p * 2) * G.C + c];
+      a1 += (double)partial[((int64_t)p * 2 + 1) * G.C + c];
+    }
+  }
+  acc[0][pl][cl] = a0; acc[1][pl][cl] = a1;
+  __syncthreads();
+  leader = pl == 0 && c < G.C;
+  s0 = s1 = 0.0;
+  if (leader) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { s0 += acc[0][k][cl]; s1 += acc[1][k][cl]; }
+  }
+}
+
 // Forward finalize: mean / invstd, running statistics, fused scale & shift.
 __global__ __launch_bounds__(THREADS) void k_fwd_finalize(Geom G, const float* __restrict__ partial,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -115,13 +140,9 @@ __global__ __launch_bounds__(THREADS) void k_fwd_finalize(Geom G, const float* _
                                                            float momentum, float eps, float* __restrict__ save_mean,
                                                            float* __restrict__ save_invstd, float* __restrict__ scale,
                                                            float* __restrict__ shift) {
-  const int c = blockIdx.x * THREADS + threadIdx.x;
-  if (c >= G.C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int p = 0; p < G.parts; ++p) {
-    s0 += (double)partial[((int64_t)p * 2) * G.C + c];
-    s1 += (double)partial[((int64_t)p * 2 + 1) * G.C + c];
-  }
+  double s0, s1; int c; bool leader;
+  sum_partials(G, partial, s0, s1, c, leader);
+  if (!leader) return;
   const double m = (double)G.M;
   const double mean = s0 / m;
   double var = s1 / m - mean * mean;           // biased variance normalises (TF fused BN)
@@ -172,13 +193,9 @@ __global__ __launch_bounds__(THREADS) void k_bwd_finalize(Geom G, const float* _
                                                            const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            float* __restrict__ coef /*[3][C]: a, b, c*/) {
-  const int c = blockIdx.x * THREADS + threadIdx.x;
-  if (c >= G.C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int p = 0; p < G.parts; ++p) {
-    s0 += (double)partial[((int64_t)p * 2) * G.C + c];
-    s1 += (double)partial[((int64_t)p * 2 + 1) * G.C + c];
-  }
+  double s0, s1; int c; bool leader;
+  sum_partials(G, partial, s0, s1, c, leader);
+  if (!leader) return;
   dbeta[c] = (float)s0;
   dgamma[c] = (float)s1;
   coef[c] = gamma[c] * invstd[c];
@@ -281,7 +298,7 @@ int rigl_bn_fwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* resid
   dim3 rgrid((unsigned)g.parts, (unsigned)((g.cg + g.tpr - 1) / g.tpr));
   hipLaunchKernelGGL((k_reduce<0, false, false>), rgrid, dim3(THREADS), 0, st, g, x, nullptr, nullptr, nullptr, nullptr,
                      nullptr, nullptr, partial);
-  hipLaunchKernelGGL(k_fwd_finalize, dim3((unsigned)((c + THREADS - 1) / THREADS)), dim3(THREADS), 0, st, g, partial, gamma,
+  hipLaunchKernelGGL(k_fwd_finalize, dim3((unsigned)((c + 15) / 16)), dim3(THREADS), 0, st, g, partial, gamma,
                      beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale, save_shift);
   const size_t lds = (size_t)2 * c * 4;
   dim3 agrid(apply_grid(g));
@@ -315,7 +332,7 @@ int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* y, co
   if (!relu) hipLaunchKernelGGL((k_reduce<1, false, false>), rgrid, dim3(THREADS), 0, st, g, x, y, dy, save_mean, save_invstd, save_scale, save_shift, partial);
   else if (has_y) hipLaunchKernelGGL((k_reduce<1, true, true>), rgrid, dim3(THREADS), 0, st, g, x, y, dy, save_mean, save_invstd, save_scale, save_shift, partial);
   else hipLaunchKernelGGL((k_reduce<1, true, false>), rgrid, dim3(THREADS), 0, st, g, x, y, dy, save_mean, save_invstd, save_scale, save_shift, partial);
-  hipLaunchKernelGGL(k_bwd_finalize, dim3((unsigned)((c + THREADS - 1) / THREADS)), dim3(THREADS), 0, st, g, partial, gamma,
+  hipLaunchKernelGGL(k_bwd_finalize, dim3((unsigned)((c + 15) / 16)), dim3(THREADS), 0, st, g, partial, gamma,
                      save_invstd, dgamma, dbeta, coef);
   const size_t lds = (size_t)7 * c * 4;
   dim3 agrid(apply_grid(g));
