@@ -13,6 +13,8 @@
 // wave owns TMxTN 32x32 MFMA tiles (block tile 64*TM x 64*TN), K-tile BK,
 // double-buffered LDS with register staging (next tile's global loads are in
 // flight while the current tile is multiplied), one barrier per K-tile.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace rigl {
@@ -628,7 +630,13 @@ static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
   const int BM = 128;
   const int BN = wide_n ? 128 : 64;
   a.tiles_n = (a.N + BN - 1) / BN;
-  const int bk = a.Cred >= 64 ? 64 : (a.Cred >= 32 ? 32 : 16);
+  int bk = a.Cred >= 64 ? 64 : (a.Cred >= 32 ? 32 : 16);
+  // short reductions (<= 4 K-tiles of 64, e.g. 1x1 convs with Cin <= 256) are latency/HBM-bound:
+  // BK = 32 halves the LDS footprint (3 workgroups per CU instead of 2); long ones keep BK = 64
+  // (measured on MI355X, batch 128: 1x1 56x56 64->256 fwd 81 -> 62 us; 3x3 512->512 65 -> 81 us).
+  if (bk == 64 && a.KH * a.KW * ((a.Cred + 63) / 64) <= 4) bk = 32;
+  static const int bk_cap = [] { const char* e = getenv("RIGL_CONV_BK"); return e ? atoi(e) : 64; }();   // tuning knob
+  if (bk > bk_cap && bk_cap >= 16) bk = bk_cap;
   if (MODE == 1 && (a.sh > 1 || a.sw > 1) && a.sh <= 2 && a.sw <= 2) {
     // class-major rows: class c = (h % sh) * sw + (w % sw)
     const int n_img = a.M / (a.RH * a.RW);

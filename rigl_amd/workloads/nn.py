@@ -102,8 +102,13 @@ def max_pool_3x3_s2_same(x):
   """tf.layers.max_pooling2d(pool_size=3, strides=2, padding='SAME')
   (resnet_model.py:637-644): TF pads (0,1) on even inputs, i.e. only at the
   bottom / right -- not torchvision's symmetric pad 1."""
+  # TF SAME on an even size pads only bottom/right with -inf; windows start at
+  # 0, 2, 4, ... -- exactly max_pool2d(3, 2, padding=0, ceil_mode=True), with no
+  # padded copy of the 205 MB stem activation.
   xn = nchw_view(x)
   h, w = xn.shape[2], xn.shape[3]
+  if h % 2 == 0 and w % 2 == 0:
+    return nhwc_view(F.max_pool2d(xn, 3, 2, padding=0, ceil_mode=True))
   ph = max((-(-h // 2) - 1) * 2 + 3 - h, 0)
   pw = max((-(-w // 2) - 1) * 2 + 3 - w, 0)
   xn = F.pad(xn, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2),
