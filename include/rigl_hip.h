@@ -134,6 +134,17 @@ int rigl_prune_regrow(const RiglPruneRegrowLayer* layers /* host */,
 int rigl_topk_mask(const float* score, int64_t n, int64_t n_keep,
                    uint32_t* mask_bits, void* workspace,
                    size_t workspace_bytes, rigl_stream_t stream);
+/* The same for many tensors in the same launches (DNW re-derives every mask
+ * every step).  Workspace: rigl_prune_regrow_workspace_bytes of the sizes.   */
+typedef struct RiglTopkLayer {
+  const float* score;   /* fp32 [n] */
+  int64_t n;
+  int64_t n_keep;
+  uint32_t* mask_bits;  /* out, ceil(n/32) words */
+} RiglTopkLayer;
+int rigl_topk_mask_batched(const RiglTopkLayer* layers /* host */,
+                           int32_t n_layers, void* workspace,
+                           size_t workspace_bytes, rigl_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * K3: masked fused SGD / momentum update (+ bf16 shadow of mask*W).

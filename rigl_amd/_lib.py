@@ -42,6 +42,11 @@ class PruneRegrowParams(C.Structure):
               ('initial_acc_scale', C.c_float), ('reinit_when_same', C.c_int32)]
 
 
+class TopkLayer(C.Structure):
+  _fields_ = [('score', C.c_void_p), ('n', C.c_int64), ('n_keep', C.c_int64),
+              ('mask_bits', C.c_void_p)]
+
+
 class PackLayer(C.Structure):
   _fields_ = [('w', C.c_void_p), ('mask_bits', C.c_void_p),
               ('hwio', C.c_void_p), ('ohwi', C.c_void_p), ('k', C.c_int32),
@@ -68,6 +73,7 @@ SIGNATURES = {
                                     C.POINTER(PruneRegrowParams), _P, _P, _SZ,
                                     _P]),
     'rigl_topk_mask': (C.c_int, [_P, _I64, _I64, _P, _P, _SZ, _P]),
+    'rigl_topk_mask_batched': (C.c_int, [C.POINTER(TopkLayer), _I32, _P, _SZ, _P]),
     'rigl_masked_sgd_momentum': (C.c_int, [_I64, _P, _P, _P, _P, _F, _F, _F, _F,
                                            _I32, _P, _P]),
     'rigl_pack_weights': (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P]),

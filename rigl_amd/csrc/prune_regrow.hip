@@ -787,6 +787,24 @@ int rigl_prune_regrow(const RiglPruneRegrowLayer* layers, int32_t n_layers, cons
                        rigl::as_stream(stream));
 }
 
+int rigl_topk_mask_batched(const RiglTopkLayer* layers, int32_t n_layers, void* workspace, size_t workspace_bytes,
+                           rigl_stream_t stream) {
+  if (n_layers < 0 || (n_layers > 0 && !layers)) return rigl::fail(RIGL_EINVAL, "rigl_topk_mask_batched: bad arguments");
+  std::vector<RiglPruneRegrowLayer> ls((size_t)n_layers);
+  std::vector<int64_t> ks((size_t)n_layers);
+  std::vector<uint32_t*> ov((size_t)n_layers);
+  for (int i = 0; i < n_layers; ++i) {
+    if (!layers[i].score || !layers[i].mask_bits || layers[i].n_keep < 0)
+      return rigl::fail(RIGL_EINVAL, "rigl_topk_mask_batched: layer %d: bad score/mask_bits/n_keep", i);
+    RiglPruneRegrowLayer l = {};
+    l.n = layers[i].n; l.mask_bits = layers[i].mask_bits; l.score_drop = layers[i].score;
+    ls[i] = l; ks[i] = layers[i].n_keep; ov[i] = layers[i].mask_bits;
+  }
+  rigl::k2::Params p = {};
+  return rigl::k2::run(ls.data(), n_layers, ks.data(), p, false, ov.data(), nullptr, workspace, workspace_bytes,
+                       rigl::as_stream(stream));
+}
+
 int rigl_topk_mask(const float* score, int64_t n, int64_t n_keep, uint32_t* mask_bits, void* workspace,
                    size_t workspace_bytes, rigl_stream_t stream) {
   if (!score || !mask_bits) return rigl::fail(RIGL_EINVAL, "rigl_topk_mask: NULL pointer");

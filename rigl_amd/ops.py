@@ -145,6 +145,27 @@ def topk_mask(score, n_keep, out=None):
   return out
 
 
+def topk_mask_batched(items):
+  """items: list of (score fp32 tensor, n_keep, mask_bits int32 tensor); all
+  masks are rewritten in the same launches."""
+  nl = len(items)
+  if nl == 0:
+    return
+  lib = _lib.load()
+  arr = (_lib.TopkLayer * nl)()
+  ns = (C.c_int64 * nl)()
+  for i, (score, n_keep, bits) in enumerate(items):
+    _req(score, torch.float32, 'score')
+    _req(bits, torch.int32, 'mask_bits')
+    arr[i].score = score.data_ptr()
+    arr[i].n = score.numel()
+    arr[i].n_keep = int(n_keep)
+    arr[i].mask_bits = bits.data_ptr()
+    ns[i] = score.numel()
+  ws = workspace(lib.rigl_prune_regrow_workspace_bytes(ns, nl), items[0][0].device)
+  check(lib.rigl_topk_mask_batched(arr, nl, _ptr(ws), ws.numel(), _stream()))
+
+
 # ----------------------------------------------------------------------------
 # K3
 # ----------------------------------------------------------------------------

@@ -503,3 +503,105 @@ def get_grow_grads(optimizer_or_graph=None):
       return [w2g[w.name] for w in opt.get_weights()]
     g = opt.graph
   return [w.grad for w in g.get_weights()]
+
+
+class SparseSnipOptimizer(PruningGetterMixin, train.Optimizer):
+  """SNIP (rigl/sparse_optimizers.py:217-338): at global_step 0, once, every
+  mask becomes the top (n - floor(s*n)) entries of |g * w| (g = gradient of the
+  still-dense layer); that call applies no gradients and does not advance the
+  step.  Afterwards it is the plain inner optimizer.  Masks are derived by the
+  K2 selection kernels (rigl_topk_mask_batched), all layers in one call."""
+
+  def __init__(self, optimizer, default_sparsity, mask_init_method,
+               custom_sparsity_map=None, use_locking=False, use_tpu=False,
+               name='SparseSnipOptimizer'):
+    super().__init__(use_locking, name, getattr(optimizer, '_graph', None))
+    self._optimizer = optimizer
+    self._use_tpu = use_tpu
+    self._default_sparsity = default_sparsity
+    self._mask_init_method = mask_init_method
+    self._custom_sparsity_map = custom_sparsity_map or {}
+    self.is_snipped = False
+
+  def compute_gradients(self, loss, **kwargs):
+    return self._optimizer.compute_gradients(loss, **kwargs)
+
+  def get_slot_names(self):
+    return self._optimizer.get_slot_names()
+
+  def get_slot(self, var, name):
+    return self._optimizer.get_slot(var, name)
+
+  def apply_gradients(self, grads_and_vars, global_step=None, name=None):
+    """:258-338.  Returns True on the snip iteration."""
+    from rigl_amd import sparse_utils  # pylint: disable=import-outside-toplevel
+    gs = global_step if global_step is not None else \
+        train.get_or_create_global_step(self.graph)
+    if int(gs.value) == 0 and not self.is_snipped:
+      masks = self.get_masks()
+      sparsities = sparse_utils.get_sparsities(
+          masks, self._mask_init_method, self._default_sparsity,
+          self._custom_sparsity_map)
+      items = []
+      for l in self.graph.masked_layers():
+        n = l.weights.numel
+        n_keep = n - sparse_utils.get_n_zeros(n, sparsities[l.mask.name])
+        score = (l.weights.grad * l.weights.data).abs().contiguous().view(-1)   # |g * v|  (:301)
+        items.append((score, n_keep, l.mask.bits))
+      ops.topk_mask_batched(items)
+      self.graph.shadows_dirty = True
+      self.is_snipped = True
+      if hasattr(self._optimizer, '_backward_done_for'):
+        self._optimizer._backward_done_for = None
+      return True
+    self._optimizer.apply_gradients(grads_and_vars, global_step=global_step,
+                                    name=name)
+    return False
+
+
+class SparseDNWOptimizer(PruningGetterMixin, train.Optimizer):
+  """Discovering Neural Wirings (rigl/sparse_optimizers.py:341-480): the DENSE
+  gradient updates every weight (masked-out ones included), then every mask is
+  re-derived each step as the top (n - floor(s*n)) entries of |w|."""
+
+  def __init__(self, optimizer, default_sparsity, mask_init_method,
+               custom_sparsity_map=None, use_tpu=False, use_locking=False,
+               name='SparseDNWOptimizer'):
+    super().__init__(use_locking, name, getattr(optimizer, '_graph', None))
+    self._optimizer = optimizer
+    self._use_tpu = use_tpu
+    self._default_sparsity = default_sparsity
+    self._mask_init_method = mask_init_method
+    self._custom_sparsity_map = custom_sparsity_map or {}
+
+  def compute_gradients(self, loss, var_list=None, **kwargs):
+    # the gradient arena already holds d loss / d(mask*W): dense (:381-394)
+    return self._optimizer.compute_gradients(loss, **kwargs)
+
+  def get_slot_names(self):
+    return self._optimizer.get_slot_names()
+
+  def get_slot(self, var, name):
+    return self._optimizer.get_slot(var, name)
+
+  def apply_gradients(self, grads_and_vars, global_step=None, name=None):
+    from rigl_amd import sparse_utils  # pylint: disable=import-outside-toplevel
+    self._optimizer.dense_masked_update = True       # no `mask *` on the gradient
+    try:
+      self._optimizer.apply_gradients(grads_and_vars, global_step=global_step,
+                                      name=name)
+    finally:
+      self._optimizer.dense_masked_update = False
+    masks = self.get_masks()
+    sparsities = sparse_utils.get_sparsities(
+        masks, self._mask_init_method, self._default_sparsity,
+        self._custom_sparsity_map)
+    items = []
+    for l in self.graph.masked_layers():
+      n = l.weights.numel
+      n_keep = n - sparse_utils.get_n_zeros(n, sparsities[l.mask.name])
+      items.append((l.weights.data.abs().contiguous().view(-1), n_keep,
+                    l.mask.bits))
+    ops.topk_mask_batched(items)
+    self.graph.shadows_dirty = True
+    return None

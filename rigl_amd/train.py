@@ -66,6 +66,7 @@ class GradientDescentOptimizer(Optimizer):
     self._slot = None              # flat momentum arena (same layout as W)
     self._grad_sync = grad_sync    # rigl_amd.dist.GradSync or None
     self._backward_done_for = None
+    self.dense_masked_update = False   # DNW: apply the dense gradient to masked kernels too
 
   # ---- gradients -------------------------------------------------------------
   def compute_gradients(self, loss, var_list=None, **kwargs):
@@ -110,7 +111,8 @@ class GradientDescentOptimizer(Optimizer):
       ops.masked_sgd_momentum(
           g.W[b:e], g.G[b:e], lr,
           momentum=self._slot[b:e] if self._slot is not None else None,
-          mask_bits=g.BITS[b // 32:e // 32] if kind == V.KIND_MASKED else None,
+          mask_bits=(g.BITS[b // 32:e // 32]
+                     if kind == V.KIND_MASKED and not self.dense_masked_update else None),
           mu=mu, weight_decay=wd, grad_scale=scale, nesterov=self._nesterov)
     b, e = g.seg[V.KIND_OTHER]
     if e > b:
@@ -135,7 +137,7 @@ class GradientDescentOptimizer(Optimizer):
       ops.masked_sgd_momentum(
           g.W[o:o + n4], g.G[o:o + n4], lr,
           momentum=self._slot[o:o + n4] if self._slot is not None else None,
-          mask_bits=l.mask.bits if l.mask is not None else None, mu=mu,
+          mask_bits=(l.mask.bits if l.mask is not None and not self.dense_masked_update else None), mu=mu,
           weight_decay=v.weight_decay, grad_scale=scale,
           nesterov=self._nesterov)
 

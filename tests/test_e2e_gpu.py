@@ -139,6 +139,67 @@ def test_rigl_apply_gradients_golden(start_iter, end_iter, freq_iter, is_increme
     assert gs.value == before + one
 
 
+# ---------------------------------------------------------------------------- SNIP / DNW
+def _setup_oneshot(kind, default_sparsity, n_inp, n_out):
+  """sparse_optimizers_test.py:372-402 / :472-507: x = 1..n_inp, loss = sum(y * scale)."""
+  from rigl_amd import pruning, pruning_layers as PL, sparse_optimizers as SO, train, variables as V
+  g = V.reset_default_graph(DEV)
+  inner = train.GradientDescentOptimizer(1e-3)
+  cls = SO.SparseSnipOptimizer if kind == 'snip' else SO.SparseDNWOptimizer
+  opt = cls(inner, default_sparsity, 'random', custom_sparsity_map={})
+  inp = np.arange(1, n_inp + 1).astype(np.float32)
+  scale = (np.random.RandomState(n_inp * 7 + n_out).uniform(size=(n_out,)) - 0.5).astype(np.float32)
+  scale = torch.from_numpy(scale).to(torch.bfloat16).float().numpy()       # exactly representable downstream
+  expected_grads = np.outer(inp, scale)
+  gs = train.get_or_create_global_step()
+
+  def loss_fn():
+    x = torch.from_numpy(inp).reshape(1, n_inp).to(DEV, torch.bfloat16)
+    y = PL.sparse_fully_connected(x, n_out, sparsity_technique='threshold', name='fully_connected').float()
+    return (y * torch.from_numpy(scale).to(DEV)).sum()
+
+  loss_fn()
+  return opt, loss_fn, expected_grads, pruning.get_masks()[0], pruning.get_weights()[0], gs
+
+
+@pytest.mark.parametrize('n_inp,n_out,s', [(3, 4, 0.5), (5, 3, 0.8), (8, 5, 0.8)])
+def test_snip(n_inp, n_out, s):
+  # sparse_optimizers_test.py:404-468
+  from rigl_amd import sparse_utils
+  opt, loss_fn, expected_grads, mask, weights, gs = _setup_oneshot('snip', s, n_inp, n_out)
+  assert mask.numpy().sum() == mask.numel                       # testInitialMaskIsDense
+  w0 = weights.numpy().copy()
+  is_snip = opt.minimize(loss_fn(), gs)
+  assert is_snip and gs.value == 0
+  m = mask.numpy()
+  assert m.size - m.sum() == sparse_utils.get_n_zeros(m.size, s)  # testSnipSparsity
+  scores = np.abs(expected_grads * w0)                          # testGradientUsed
+  assert scores[m == 0].max() <= scores[m == 1].min()
+  np.testing.assert_array_equal(weights.numpy(), w0)            # no gradient applied on the snip step
+  for i in range(3):                                            # testAfterSnipTraining
+    assert gs.value == i
+    assert opt.minimize(loss_fn(), gs) is False and opt.is_snipped
+    np.testing.assert_array_equal(mask.numpy(), m)
+
+
+@pytest.mark.parametrize('n_inp,n_out,s', [(3, 4, 0.5), (5, 3, 0.8), (8, 5, 0.8)])
+def test_dnw(n_inp, n_out, s):
+  # sparse_optimizers_test.py:509-586
+  from rigl_amd import sparse_utils
+  opt, loss_fn, expected_grads, mask, weights, gs = _setup_oneshot('dnw', s, n_inp, n_out)
+  gv = opt.compute_gradients(loss_fn())
+  grad = [g for g, v in gv if v is weights][0]
+  np.testing.assert_allclose(grad.cpu().numpy(), expected_grads, rtol=1e-6)   # testGradientIsDense
+  opt.apply_gradients(gv, gs)
+  for _ in range(5):                                            # testDNWUpdates / testSparsityAfterDNWUpdates
+    m, w = mask.numpy(), weights.numpy()
+    assert m.size - m.sum() == sparse_utils.get_n_zeros(m.size, s)
+    assert np.abs(w[m == 0]).max() <= np.abs(w[m == 1]).min()
+    opt.minimize(loss_fn(), gs)
+  # the dense gradient moved masked-out weights too (DNW's point)
+  assert np.all(weights.numpy() != 0)
+
+
 # ---------------------------------------------------------------------------- ResNet-50
 @pytest.fixture(scope='module')
 def rn50():
