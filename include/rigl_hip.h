@@ -222,6 +222,22 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x,
                              const rigl_bf16* dy, float* dw, void* workspace,
                              size_t workspace_bytes, rigl_stream_t stream);
 
+/* K1d: dense depthwise convolution (depth multiplier 1), NHWC bf16, fp32 HWIO
+ * weights [kh][kw][c][1] read directly.  Replaces
+ * contrib_layers.separable_conv2d(num_outputs=None)
+ * (rigl/imagenet_resnet/mobilenetv1_model.py:81-92) and its autodiff; these
+ * layers are NOT masked in the reference.  d->cin == d->cout,
+ * channels % 8 == 0.  HBM-bound, no MFMA.  dw is overwritten (dense fp32).   */
+size_t rigl_depthwise_conv2d_workspace_bytes(const RiglConvDesc* d);
+int rigl_depthwise_conv2d_fwd(const RiglConvDesc* d, const rigl_bf16* x,
+                              const float* w, rigl_bf16* y, rigl_stream_t stream);
+int rigl_depthwise_conv2d_dgrad(const RiglConvDesc* d, const rigl_bf16* dy,
+                                const float* w, rigl_bf16* dx,
+                                rigl_stream_t stream);
+int rigl_depthwise_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x,
+                                const rigl_bf16* dy, float* dw, void* workspace,
+                                size_t workspace_bytes, rigl_stream_t stream);
+
 /* Direct (non-MFMA) kernels, same operand layouts, any channel count: taken
  * for shapes the MFMA path reports RIGL_EUNSUPPORTED for (cin/cout not a
  * multiple of 8 -- MNIST MLP 784-300-100-10, 10-class logits) and used as an

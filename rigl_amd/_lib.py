@@ -88,6 +88,10 @@ SIGNATURES = {
     'rigl_conv2d_fwd_ref': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     'rigl_conv2d_dgrad_ref': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     'rigl_conv2d_wgrad_ref': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    'rigl_depthwise_conv2d_workspace_bytes': (_SZ, [C.POINTER(ConvDesc)]),
+    'rigl_depthwise_conv2d_fwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    'rigl_depthwise_conv2d_dgrad': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    'rigl_depthwise_conv2d_wgrad': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _SZ, _P]),
     'rigl_bn_workspace_bytes': (_SZ, [_I64, _I32]),
     'rigl_bn_fwd': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'rigl_bn_bwd': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -293,6 +293,35 @@ def conv_wgrad(d, x, dy, dw=None, force_ref=False):
 
 
 # ----------------------------------------------------------------------------
+# K1d depthwise
+# ----------------------------------------------------------------------------
+def depthwise_fwd(d, x, w):
+  _req(x, torch.bfloat16, 'x')
+  _req(w, torch.float32, 'w')
+  y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16, device=x.device)
+  check(_lib.load().rigl_depthwise_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _stream()))
+  return y
+
+
+def depthwise_dgrad(d, dy, w):
+  _req(dy, torch.bfloat16, 'dy')
+  _req(w, torch.float32, 'w')
+  dx = torch.empty((d.n, d.h, d.w, d.cin), dtype=torch.bfloat16, device=dy.device)
+  check(_lib.load().rigl_depthwise_conv2d_dgrad(C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _stream()))
+  return dx
+
+
+def depthwise_wgrad(d, x, dy, dw):
+  _req(x, torch.bfloat16, 'x')
+  _req(dy, torch.bfloat16, 'dy')
+  _req(dw, torch.float32, 'dw')
+  lib = _lib.load()
+  ws = workspace(lib.rigl_depthwise_conv2d_workspace_bytes(C.byref(d)), x.device)
+  check(lib.rigl_depthwise_conv2d_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), _stream()))
+  return dw
+
+
+# ----------------------------------------------------------------------------
 # fused batch-norm (+ residual) (+ ReLU)
 # ----------------------------------------------------------------------------
 def bn_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu,

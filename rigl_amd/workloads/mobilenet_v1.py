@@ -1,0 +1,66 @@
+"""MobileNet-v1 workload (rigl/imagenet_resnet/mobilenetv1_model.py:156-342),
+BASELINE config 5.  Dense 3x3/2 stem -> 13 x [dense depthwise 3x3 -> BN-ReLU ->
+MASKED 1x1 'contraction' -> BN-ReLU] -> global average pool -> masked
+final_dense.  Only the pointwise convs and the classifier carry masks (F7)."""
+import torch
+
+from rigl_amd import pruning_layers as PL
+from rigl_amd import variables as V
+from rigl_amd.workloads import nn as gnn
+from rigl_amd.workloads import shapes as WS
+
+
+class MobileNetV1:
+
+  def __init__(self, graph=None, num_classes=1000, pruning_method='threshold', prune_last_layer=True,
+               weight_decay=4e-5, seed=0):
+    self.graph = g = graph or V.get_default_graph()
+    PL.set_init_seed(seed)
+    scope = WS.SCOPE
+    self.stem = PL.MaskedConv2d(g, scope + '/initial_conv', 3, 32, (3, 3), (2, 2), 'SAME', 'baseline', weight_decay,
+                                PL.variance_scaling_initializer(), need_input_grad=False)
+    self.stem_bn = gnn.BatchNorm(g, scope + '/initial_bn', 32)
+    self.blocks = []
+    cin = 32
+    for i, (f, stride) in enumerate(WS.MOBILENET_V1_BLOCKS):
+      dw = gnn.DepthwiseConv2d(g, '%s/depthwise_nxn_%d' % (scope, i), cin, 3, stride)
+      bn_a = gnn.BatchNorm(g, '%s/depthwise_bn_%d' % (scope, i), cin)
+      name = '%s/contraction_1x1_%d' % (scope, i)
+      pw = PL.MaskedConv2d(g, name, cin, f, (1, 1), (1, 1), 'SAME', pruning_method, weight_decay,
+                           PL.variance_scaling_initializer())
+      g.modules[name] = pw
+      bn_b = gnn.BatchNorm(g, '%s/contraction_bn_%d' % (scope, i), f)
+      self.blocks.append((dw, bn_a, pw, bn_b))
+      cin = f
+    self.fc = PL.MaskedDense(g, scope + '/final_dense', 1024, num_classes, True,
+                             pruning_method if prune_last_layer else 'baseline', weight_decay,
+                             PL.variance_scaling_initializer())
+    g.modules[scope + '/final_dense'] = self.fc
+    g.finalize()
+
+  def _stem(self, images):
+    # fixed_padding(k=3) + VALID, stride 2 (mobilenetv1_model.py:251-268): symmetric pad 1
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    c = self.stem
+    n, h, w, _ = images.shape
+    key = (n, h, w)
+    if key not in c._descs:
+      c._descs[key] = ops.conv_desc(n, h, w, 3, 32, 3, 3, 2, 1, 1, (h - 1) // 2 + 1, (w - 1) // 2 + 1)
+    return c(images)
+
+  def __call__(self, images, is_training=True):
+    x = self.stem_bn(self._stem(images), is_training, relu=True)
+    for dw, bn_a, pw, bn_b in self.blocks:
+      x = bn_a(dw(x), is_training, relu=True)
+      x = bn_b(pw(x), is_training, relu=True)
+    return self.fc(gnn.global_avg_pool(x))
+
+  def loss(self, images, labels, label_smoothing=0.1, is_training=True):
+    return gnn.softmax_cross_entropy(self(images, is_training), labels, label_smoothing)
+
+
+def synthetic_batch(batch, device, seed=1234, image_size=224, num_classes=1000):
+  gen = torch.Generator(device=device).manual_seed(seed)
+  images = torch.randn(batch, image_size, image_size, 3, generator=gen, device=device).to(torch.bfloat16)
+  labels = torch.randint(0, num_classes, (batch,), generator=gen, device=device)
+  return images, labels

@@ -98,6 +98,53 @@ class BatchNorm:
     return y
 
 
+class _DepthwiseFn(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, x, layer, desc):
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    x = x.contiguous()
+    ctx.layer, ctx.desc = layer, desc
+    ctx.save_for_backward(x)
+    return ops.depthwise_fwd(desc, x, layer.weights.data.view(-1))
+
+  @staticmethod
+  def backward(ctx, dy):
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    (x,) = ctx.saved_tensors
+    dy = dy.contiguous()
+    w = ctx.layer.weights
+    ops.depthwise_wgrad(ctx.desc, x, dy, w.grad.view(-1))          # dense fp32, into the gradient arena
+    return ops.depthwise_dgrad(ctx.desc, dy, w.data.view(-1)), None, None
+
+
+class DepthwiseConv2d:
+  """depthwise_conv2d_fixed_padding (mobilenetv1_model.py:43-92): dense
+  depthwise kxk, no bias, no regulariser, NOT masked; stride > 1 uses explicit
+  fixed padding + VALID, stride 1 uses SAME."""
+
+  def __init__(self, graph, scope, channels, kernel_size=3, stride=1):
+    from rigl_amd import pruning_layers as PL  # pylint: disable=import-outside-toplevel
+    self.k, self.stride, self.channels = kernel_size, stride, channels
+    init = PL.variance_scaling_initializer()((kernel_size, kernel_size, channels, 1))
+    self.weights = graph.add_variable(scope + '/depthwise_weights', (kernel_size, kernel_size, channels, 1),
+                                      V.KIND_OTHER, 0.0, init)
+    self._descs = {}
+
+  def __call__(self, x):
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    n, h, w, c = x.shape
+    d = self._descs.get((n, h, w))
+    if d is None:
+      pad = (self.k - 1) // 2
+      ho, wo = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
+      d = ops.conv_desc(n, h, w, c, c, self.k, self.k, self.stride, pad, pad, ho, wo)
+      self._descs[(n, h, w)] = d
+    if not x.requires_grad:
+      x = x.detach().requires_grad_(True)
+    return _DepthwiseFn.apply(x, self, d)
+
+
 def max_pool_3x3_s2_same(x):
   """tf.layers.max_pooling2d(pool_size=3, strides=2, padding='SAME')
   (resnet_model.py:637-644): TF pads (0,1) on even inputs, i.e. only at the

@@ -122,3 +122,25 @@ def test_config4_resnet50_erk99_dense_stem():
   x, y = resnet50.synthetic_batch(8, DEV)
   _step_parity(g, lambda: model.loss(x, y, label_smoothing=0.1), opt, 0.05, 0.9,
                {V.KIND_MASKED: 1e-4, V.KIND_DENSE: 1e-4, V.KIND_OTHER: 0.0}, 'cosine', 0.3, 0, 25000)
+
+
+def test_config5_mobilenet_v1_uniform90():
+  """MobileNet-v1, --mask_init_method=random --end_sparsity=0.9 on the 13
+  pointwise convs + final_dense; depthwise convs and the stem stay dense."""
+  from rigl_amd import sparse_optimizers as SO, sparse_utils, train, variables as V
+  from rigl_amd.workloads import mobilenet_v1, shapes as WS
+  g = V.reset_default_graph(DEV)
+  model = mobilenet_v1.MobileNetV1(g, seed=0)
+  assert [m.name for m in g.get_masks()] == list(WS.mobilenet_v1_masks().keys())
+  np.random.seed(0)
+  sparse_utils.get_mask_init_fn(g.get_masks(), 'random', 0.9, {})()
+  assert sum(m.numel for m in g.get_masks()) == 4163584
+  assert sum(m.sum() for m in g.get_masks()) == 416365                  # BASELINE.md section 2
+  inner = train.MomentumOptimizer(0.05, 0.9, use_nesterov=True, graph=g)
+  opt = SO.SparseRigLOptimizer(inner, 0, 25000, 100, drop_fraction=0.3, drop_fraction_anneal='cosine', noise_std=0.)
+  x, y = mobilenet_v1.synthetic_batch(8, DEV)
+  _step_parity(g, lambda: model.loss(x, y, label_smoothing=0.1), opt, 0.05, 0.9,
+               {V.KIND_MASKED: 4e-5, V.KIND_DENSE: 4e-5, V.KIND_OTHER: 0.0}, 'cosine', 0.3, 0, 25000)
+  # depthwise weights really train (dense gradient landed in the arena)
+  dwv = [v for v in g.variables.values() if v.name.endswith('depthwise_weights:0')]
+  assert len(dwv) == 13 and all(float(v.grad.abs().sum()) > 0 for v in dwv)

@@ -250,3 +250,35 @@ def test_conv_resnet50_sizes_vs_gpu_fp32(shape):
   if Cin % 8 == 0:
     dx = ops.conv_dgrad(d, dy, hwio).float()
     assert (dx - dxr).abs().max() <= 2.0**-7 * dxr.abs().max()
+
+
+# ------------------------------------------------------------------ K1d depthwise
+@pytest.mark.parametrize('case', [(2, 14, 14, 32, 3, 1), (2, 15, 13, 64, 3, 2), (3, 8, 8, 8, 3, 2), (1, 7, 7, 1024, 3, 1),
+                                  (2, 112, 112, 32, 3, 1), (2, 9, 9, 40, 5, 1)])
+def test_depthwise_conv(case):
+  """Dense depthwise conv fwd/dgrad/wgrad vs a grouped fp32 convolution of the
+  same bf16 activations (stride 1 = SAME, stride 2 = fixed_padding + VALID)."""
+  from rigl_amd import ops
+  N, H, W, C, k, stride = case
+  g = torch.Generator().manual_seed(sum(case))
+  x = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16)
+  w = torch.randn(k, k, C, 1, generator=g) * 0.3
+  pad = (k - 1) // 2
+  Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+  dy = torch.randn(N, Ho, Wo, C, generator=g).to(torch.bfloat16)
+  d = ops.conv_desc(N, H, W, C, C, k, k, stride, pad, pad, Ho, Wo)
+  xr = x.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+  wr = w.permute(2, 3, 0, 1).contiguous().requires_grad_(True)          # [C,1,k,k]
+  yr = F.conv2d(xr, wr, stride=stride, padding=pad, groups=C)
+  assert yr.shape[2:] == (Ho, Wo)
+  yr.backward(dy.float().permute(0, 3, 1, 2))
+  wd = w.reshape(-1).contiguous().to(DEV)
+  y = ops.depthwise_fwd(d, x.to(DEV), wd).float().cpu()
+  dx = ops.depthwise_dgrad(d, dy.to(DEV), wd).float().cpu()
+  dw = torch.empty(k * k * C, device=DEV)
+  ops.depthwise_wgrad(d, x.to(DEV), dy.to(DEV), dw)
+  ref_y, ref_dx = yr.detach().permute(0, 2, 3, 1), xr.grad.permute(0, 2, 3, 1)
+  ref_dw = wr.grad.permute(2, 3, 0, 1).reshape(-1)
+  assert (y - ref_y).abs().max() <= 2.0**-7 * ref_y.abs().max() + 1e-6
+  assert (dx - ref_dx).abs().max() <= 2.0**-7 * ref_dx.abs().max() + 1e-6
+  assert (dw.cpu() - ref_dw).abs().max() <= 1e-4 * ref_dw.abs().max() + 1e-5
