@@ -90,7 +90,7 @@ struct IgemmArgs {
   int cls_n, cls_ids[4], cls_interleave;   // non-empty classes and the common tile count they interleave over
 };
 
-template <int TM, int TN, int BK, int MODE /*0 fwd, 1 dgrad*/, bool OUT_F32, bool CLS>
+template <int TM, int TN, int BK, int MODE /*0 fwd, 1 dgrad*/, bool OUT_F32, bool CLS, int STAGES>
 __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
   constexpr int BM = 64 * TM, BN = 64 * TN, CPR = BK / 8, RPP = THREADS / CPR;
   constexpr int APASS = (BM + RPP - 1) / RPP, BPASS = (BN + RPP - 1) / RPP;
@@ -98,7 +98,9 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
   constexpr int CS_LD = BN + 8;
   constexpr int EPI = OUT_F32 ? 0 : BM * CS_LD * 2;
   constexpr int EPI_ALL = EPI + (CLS ? BM * 4 : 0);       // + per-row output pixel table
-  constexpr int SMEM = (2 * STAGE > EPI_ALL) ? 2 * STAGE : EPI_ALL;
+  constexpr int SMEM = (STAGES * STAGE > EPI_ALL) ? STAGES * STAGE : EPI_ALL;
+  static_assert(SMEM <= 65536, "static LDS limit");
+  static_assert(STAGES == 2 || (BM % RPP == 0 && BN % RPP == 0), "LDS-DMA needs whole 1-KB wave rows");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -214,6 +216,64 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
     }                                                                                                 \
   }
 
+  // LDS-DMA staging (STAGES >= 3): `buffer_load_dwordx4 ... lds` writes
+  // M0-base + lane*16, i.e. one wave instruction fills 1 KB = 64/CPR whole tile
+  // rows in LINEAR order, so the XOR swizzle goes on the SOURCE side: the lane
+  // that fills slot `lchunk` of its row fetches channel-chunk lchunk ^ f(row).
+  // Out-of-image / out-of-range lanes use an offset beyond num_records and the
+  // hardware writes zeros (measured: tools/probes/lds_dma_probe.hip).  No
+  // registers are held, so several K-tiles stay in flight behind a counted vmcnt.
+  constexpr int SWZ_SH = (CPR == 8) ? 1 : (CPR == 4 ? 2 : 3);
+  const int dchunk = lchunk ^ ((lrow >> SWZ_SH) & (CPR - 1));
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#define RIGL_DMA_ISSUE(r_, s_, cb_, stage_)                                                           \
+  {                                                                                                   \
+    unsigned char* As_ = smem + (stage_) * STAGE;                                                     \
+    unsigned char* Bs_ = As_ + A_BYTES;                                                               \
+    const int cofs = (cb_) * BK + dchunk * 8;                                                         \
+    const bool c_ok = cofs < P.Cred;                                                                  \
+    _Pragma("unroll") for (int p = 0; p < APASS; ++p) {                                               \
+      bool ok = a_ok[p] && c_ok;                                                                      \
+      int gh, gw;                                                                                     \
+      if (MODE == 0) {                                                                                \
+        gh = a_c0[p] + (r_); gw = a_c1[p] + (s_);                                                     \
+      } else {                                                                                        \
+        int th = a_c0[p] - (r_), tw = a_c1[p] - (s_);                                                 \
+        ok = ok && th >= 0 && tw >= 0;                                                                \
+        if (P.sh == 1) gh = th; else { gh = th / P.sh; ok = ok && (th - gh * P.sh) == 0; }            \
+        if (P.sw == 1) gw = tw; else { gw = tw / P.sw; ok = ok && (tw - gw * P.sw) == 0; }            \
+      }                                                                                               \
+      ok = ok && (unsigned)gh < (unsigned)P.GH && (unsigned)gw < (unsigned)P.GW;                      \
+      const int off = (a_pix[p] + gh * P.GW + gw) * P.a_pix_stride + cofs;                            \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                       \
+          rsrcA, (__attribute__((address_space(3))) void*)(As_ + (p * RPP + wave_u * (64 / CPR)) * (BK * 2)), 16, \
+          ok ? (int)((uint32_t)off * 2u) : (int)OOB, 0, 0, 0);                                        \
+    }                                                                                                 \
+    const int tap = (r_) * P.KW + (s_);                                                               \
+    _Pragma("unroll") for (int p = 0; p < BPASS; ++p) {                                               \
+      const int off = b_off[p] + tap * P.b_tap_stride + cofs;                                         \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                       \
+          rsrcB, (__attribute__((address_space(3))) void*)(Bs_ + (p * RPP + wave_u * (64 / CPR)) * (BK * 2)), 16, \
+          (b_ok[p] && c_ok) ? (int)((uint32_t)off * 2u) : (int)OOB, 0, 0, 0);                         \
+    }                                                                                                 \
+  }
+#define RIGL_COMPUTE_TILE(stage_)                                                                     \
+  {                                                                                                   \
+    const unsigned char* As = smem + (stage_) * STAGE;                                                \
+    const unsigned char* Bs = As + A_BYTES;                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                          \
+      const int chunk = ks * 2 + (lane >> 5);                                                         \
+      bf16x8 af[TM], bfr[TN];                                                                         \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+        af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off<BK>(wm * 32 * TM + i * 32 + (lane & 31), chunk)); \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                  \
+        bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<BK>(wn * 32 * TN + j * 32 + (lane & 31), chunk)); \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);     \
+    }                                                                                                 \
+  }
+
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -225,39 +285,45 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
   // ---- main loop ------------------------------------------------------------
   int r = r0, s = s0, cb = 0;
 #define RIGL_ADVANCE() { if (++cb == kc_tiles) { cb = 0; s += s_step; if (s >= P.KW) { s = s0; r += r_step; } } }
-  if (KT > 0) {
-    RIGL_LOAD_TILE(r, s, cb);
-    RIGL_STORE_TILE(0);
-    RIGL_ADVANCE();
-  }
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < KT;
-    if (more) { RIGL_LOAD_TILE(r, s, cb); RIGL_ADVANCE(); }
-    const unsigned char* As = smem + buf * STAGE;
-    const unsigned char* Bs = As + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int chunk = ks * 2 + (lane >> 5);
-      bf16x8 af[TM], bfr[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off<BK>(wm * 32 * TM + i * 32 + (lane & 31), chunk));
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<BK>(wn * 32 * TN + j * 32 + (lane & 31), chunk));
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+  if constexpr (STAGES == 2) {
+    // register-staged double buffer: tile kt+1's global loads are in flight during tile kt's MFMAs
+    if (KT > 0) {
+      RIGL_LOAD_TILE(r, s, cb);
+      RIGL_STORE_TILE(0);
+      RIGL_ADVANCE();
     }
-    if (more) RIGL_STORE_TILE(buf ^ 1);
     __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+      const int buf = kt & 1;
+      const bool more = kt + 1 < KT;
+      if (more) { RIGL_LOAD_TILE(r, s, cb); RIGL_ADVANCE(); }
+      RIGL_COMPUTE_TILE(buf);
+      if (more) RIGL_STORE_TILE(buf ^ 1);
+      __syncthreads();
+    }
+  } else {
+    // STAGES-deep LDS-DMA ring: tiles kt+1 .. kt+STAGES-2 stay in flight while tile kt is
+    // multiplied.  Per iteration: counted wait for MY loads of tile kt -> barrier (everyone's
+    // landed, and everyone is done reading the stage about to be refilled) -> issue tile
+    // kt+STAGES-1 into the stage tile kt-1 used -> MFMAs on tile kt.  One barrier per K-tile,
+    // never vmcnt(0) in steady state.
+    constexpr int L = APASS + BPASS;   // DMA instructions per thread per K-tile
+    for (int t = 0; t < STAGES - 1; ++t)
+      if (t < KT) { RIGL_DMA_ISSUE(r, s, cb, t); RIGL_ADVANCE(); }
+    for (int kt = 0; kt < KT; ++kt) {
+      if (kt + STAGES - 1 <= KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (STAGES - 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + STAGES - 1 < KT) { RIGL_DMA_ISSUE(r, s, cb, (kt + STAGES - 1) % STAGES); RIGL_ADVANCE(); }
+      RIGL_COMPUTE_TILE(kt % STAGES);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // all tiles consumed before the epilogue reuses the LDS
   }
 #undef RIGL_LOAD_TILE
 #undef RIGL_STORE_TILE
+#undef RIGL_DMA_ISSUE
+#undef RIGL_COMPUTE_TILE
 #undef RIGL_ADVANCE
 
   // ---- epilogue -------------------------------------------------------------
@@ -610,16 +676,21 @@ static TinyGeom tiny_geom(const RiglConvDesc* d) {
 
 // ------------------------------------------------------------------ dispatch
 template <int MODE, bool F32, bool CLS>
-static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, int bk, hipStream_t st) {
+static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, int bk, bool dma, hipStream_t st) {
   dim3 blk(THREADS);
+  if (dma) {   // 4-stage LDS-DMA ring, BK = 32 (64 KB of LDS, 2 workgroups per CU)
+    if (wide_n) hipLaunchKernelGGL((k_igemm<2, 2, 32, MODE, F32, CLS, 4>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((k_igemm<2, 1, 32, MODE, F32, CLS, 4>), grid, blk, 0, st, a);
+    return;
+  }
   if (wide_n) {
-    if (bk == 64) hipLaunchKernelGGL((k_igemm<2, 2, 64, MODE, F32, CLS>), grid, blk, 0, st, a);
-    else if (bk == 32) hipLaunchKernelGGL((k_igemm<2, 2, 32, MODE, F32, CLS>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((k_igemm<2, 2, 16, MODE, F32, CLS>), grid, blk, 0, st, a);
+    if (bk == 64) hipLaunchKernelGGL((k_igemm<2, 2, 64, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
+    else if (bk == 32) hipLaunchKernelGGL((k_igemm<2, 2, 32, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((k_igemm<2, 2, 16, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
   } else {
-    if (bk == 64) hipLaunchKernelGGL((k_igemm<2, 1, 64, MODE, F32, CLS>), grid, blk, 0, st, a);
-    else if (bk == 32) hipLaunchKernelGGL((k_igemm<2, 1, 32, MODE, F32, CLS>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((k_igemm<2, 1, 16, MODE, F32, CLS>), grid, blk, 0, st, a);
+    if (bk == 64) hipLaunchKernelGGL((k_igemm<2, 1, 64, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
+    else if (bk == 32) hipLaunchKernelGGL((k_igemm<2, 1, 32, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((k_igemm<2, 1, 16, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
   }
 }
 
@@ -635,8 +706,10 @@ static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
   // BK = 32 halves the LDS footprint (3 workgroups per CU instead of 2); long ones keep BK = 64
   // (measured on MI355X, batch 128: 1x1 56x56 64->256 fwd 81 -> 62 us; 3x3 512->512 65 -> 81 us).
   if (bk == 64 && a.KH * a.KW * ((a.Cred + 63) / 64) <= 4) bk = 32;
-  static const int bk_cap = [] { const char* e = getenv("RIGL_CONV_BK"); return e ? atoi(e) : 64; }();   // tuning knob
+  static const int bk_cap = [] { const char* e = getenv("RIGL_CONV_BK"); return e ? atoi(e) : 64; }();   // tuning knobs
+  static const int use_dma = [] { const char* e = getenv("RIGL_CONV_DMA"); return e ? atoi(e) : 1; }();
   if (bk > bk_cap && bk_cap >= 16) bk = bk_cap;
+  const bool dma = use_dma && a.Cred >= 32;
   if (MODE == 1 && (a.sh > 1 || a.sw > 1) && a.sh <= 2 && a.sw <= 2) {
     // class-major rows: class c = (h % sh) * sw + (w % sw)
     const int n_img = a.M / (a.RH * a.RW);
@@ -657,11 +730,11 @@ static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
       if (tc > 0) { a.cls_ids[a.cls_n++] = c; if (tc < a.cls_interleave) a.cls_interleave = tc; }
     }
     if (a.cls_n == 0) { a.cls_n = 1; a.cls_ids[0] = 0; a.cls_interleave = 0; }
-    launch_igemm_t<MODE, F32, true>(a, dim3((unsigned)(tiles * a.tiles_n)), wide_n, bk, st);
+    launch_igemm_t<MODE, F32, true>(a, dim3((unsigned)(tiles * a.tiles_n)), wide_n, bk, dma, st);
     return;
   }
   const int tiles_m = (a.M + BM - 1) / BM;
-  launch_igemm_t<MODE, F32, false>(a, dim3((unsigned)(tiles_m * a.tiles_n)), wide_n, bk, st);
+  launch_igemm_t<MODE, F32, false>(a, dim3((unsigned)(tiles_m * a.tiles_n)), wide_n, bk, dma, st);
 }
 
 static int check_desc(const RiglConvDesc* d, const char* who) {
