@@ -538,6 +538,182 @@ __global__ __launch_bounds__(THREADS) void k_wgrad(WgradArgs P) {
       }
 }
 
+// wgrad, LDS-DMA + transpose-read variant.  Both operands are reduction(pixel)-major
+// in memory ([pixel][channel]) while the MFMA wants 8 consecutive k per lane, so
+// k_wgrad transposes 8x8 blocks in registers (~100 VALU per K-tile).  gfx950's
+// ds_read_b64_tr_b16 does that transposition in the LDS read path: per 16-lane
+// group, lane j supplies the address of 4 consecutive channels of pixel j/4 and
+// receives channel j of the 16-channel block for pixels 0..3 (measured:
+// tools/probes/tr_read_probe.hip).  The LDS image can therefore stay
+// [pixel][channel] -- exactly what `buffer_load ... lds` writes (lane-linear) --
+// so the tile goes HBM -> LDS without touching registers, 4 stages deep behind a
+// counted vmcnt, and the K loop holds only DMA issue, 8-byte tr reads and MFMAs.
+// Bank conflicts: a 32-lane pass reads 4 pixel rows x 64 B; 64-B quads are XORed
+// with the pixel index (source-side, in the DMA lane -> channel mapping) so the
+// four rows land in four different 16-bank groups.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 lds_read_tr_pair(const unsigned char* p0, const unsigned char* p1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p1);
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+// 16-B slot XOR for pixel row p of a [pixel][C*8 channels] image (C = 8 or 16 slots per row)
+template <int C>
+__device__ __forceinline__ int trswz(int p) { return ((p / (16 / C)) & (C / 4 - 1)) << 2; }
+
+template <int TM, int TN, int STAGES>
+__global__ __launch_bounds__(THREADS) void k_wgrad_tr(WgradArgs P) {
+  constexpr int BK = 32;
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int CA = BM / 8, CB = BN / 8;
+  constexpr int A_BYTES = BK * BM * 2, B_BYTES = BK * BN * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int APASS = BK * CA / THREADS, BPASS = BK * CB / THREADS;
+  static_assert(STAGES * STAGE <= 65536, "static LDS limit");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  uint32_t b = xcd_remap(blockIdx.x, gridDim.x);
+  const int tco = b % P.tiles_co; b /= P.tiles_co;
+  const int tci = b % P.tiles_ci; b /= P.tiles_ci;
+  const int tap = b % (P.KH * P.KW);
+  const int split = b / (P.KH * P.KW);
+  const int r = tap / P.KW, s = tap % P.KW;
+  const int ci0 = tci * BM, co0 = tco * BN;
+  const int KT_all = (P.M + BK - 1) / BK;
+  const int kt_begin = (int)((int64_t)KT_all * split / P.splits);
+  const int kt_end = (int)((int64_t)KT_all * (split + 1) / P.splits);
+  const int KT = kt_end - kt_begin;
+  const bool direct = P.KH == 1 && P.KW == 1 && P.sh == 1 && P.sw == 1 && P.ph == 0 && P.pw == 0;
+  const bool fast_inc = (BK / P.Wo + 1) <= P.Ho;
+  const int inc_w = BK % P.Wo, inc_h = BK / P.Wo;
+  const int hi0 = r - P.ph, wi0 = s - P.pw;
+  const __amdgpu_buffer_rsrc_t rsrcX = make_rsrc(P.X, P.x_bytes), rsrcY = make_rsrc(P.DY, P.dy_bytes);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+  // ---- DMA lanes: slot q*256+tid of a stage = (pixel row, 16-B slot) ----------
+  int a_m[APASS], a_ch[APASS], a_n[APASS], a_ho[APASS], a_wo[APASS];
+  bool a_cok[APASS];
+#pragma unroll
+  for (int q = 0; q < APASS; ++q) {
+    const int slot = q * THREADS + tid, p = slot / CA, pc = slot % CA;
+    a_ch[q] = ci0 + ((pc ^ trswz<CA>(p)) << 3);
+    a_cok[q] = a_ch[q] < P.Cin;
+    a_m[q] = kt_begin * BK + p;
+    const int t = a_m[q] / P.Wo;
+    a_wo[q] = a_m[q] % P.Wo; a_ho[q] = t % P.Ho; a_n[q] = t / P.Ho;
+  }
+  int b_m[BPASS], b_ch[BPASS];
+  bool b_cok[BPASS];
+#pragma unroll
+  for (int q = 0; q < BPASS; ++q) {
+    const int slot = q * THREADS + tid, p = slot / CB, pc = slot % CB;
+    b_ch[q] = co0 + ((pc ^ trswz<CB>(p)) << 3);
+    b_cok[q] = b_ch[q] < P.Cout;
+    b_m[q] = kt_begin * BK + p;
+  }
+#define RIGL_WTR_ISSUE(stage_)                                                                        \
+  {                                                                                                   \
+    unsigned char* As_ = smem + (stage_) * STAGE;                                                     \
+    unsigned char* Bs_ = As_ + A_BYTES;                                                               \
+    _Pragma("unroll") for (int q = 0; q < APASS; ++q) {                                               \
+      bool ok = a_cok[q] && a_m[q] < P.M;                                                             \
+      int off;                                                                                        \
+      if (direct) {                                                                                   \
+        off = a_m[q] * P.x_pix_stride + a_ch[q];                                                      \
+      } else {                                                                                        \
+        const int hi = a_ho[q] * P.sh + hi0, wi = a_wo[q] * P.sw + wi0;                               \
+        ok = ok && (unsigned)hi < (unsigned)P.H && (unsigned)wi < (unsigned)P.W;                      \
+        off = ((a_n[q] * P.H + hi) * P.W + wi) * P.x_pix_stride + a_ch[q];                            \
+      }                                                                                               \
+      const int boff = ok ? (int)((uint32_t)off * 2u) : (int)OOB;                                     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                       \
+          rsrcX, (__attribute__((address_space(3))) void*)(As_ + (q * THREADS + wave_u * 64) * 16), 16, boff, 0, 0, 0); \
+      a_m[q] += BK;                                                                                   \
+      if (!direct) {                                                                                  \
+        if (fast_inc) {                                                                               \
+          a_wo[q] += inc_w; if (a_wo[q] >= P.Wo) { a_wo[q] -= P.Wo; ++a_ho[q]; }                      \
+          a_ho[q] += inc_h; if (a_ho[q] >= P.Ho) { a_ho[q] -= P.Ho; ++a_n[q]; }                       \
+        } else {                                                                                      \
+          const int t = a_m[q] / P.Wo;                                                                \
+          a_wo[q] = a_m[q] % P.Wo; a_ho[q] = t % P.Ho; a_n[q] = t / P.Ho;                             \
+        }                                                                                             \
+      }                                                                                               \
+    }                                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < BPASS; ++q) {                                               \
+      const bool okb = b_cok[q] && b_m[q] < P.M;                                                      \
+      const int boff = okb ? (int)((uint32_t)(b_m[q] * P.Cout + b_ch[q]) * 2u) : (int)OOB;            \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                       \
+          rsrcY, (__attribute__((address_space(3))) void*)(Bs_ + (q * THREADS + wave_u * 64) * 16), 16, boff, 0, 0, 0); \
+      b_m[q] += BK;                                                                                   \
+    }                                                                                                 \
+  }
+
+  // ---- tr-read lanes ----------------------------------------------------------
+  const int g = lane >> 4, j = lane & 15;
+  const int prow = 8 * (g >> 1) + (j >> 2);               // pixel inside a 16-pixel k-step (t = 0)
+  int a_rd[TM], b_rd[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int chunk = (wm * 32 * TM + i * 32) / 8 + 2 * (g & 1) + ((j >> 1) & 1);
+    a_rd[i] = prow * (CA * 16) + ((chunk ^ trswz<CA>(prow)) << 4) + (j & 1) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int chunk = (wn * 32 * TN + i * 32) / 8 + 2 * (g & 1) + ((j >> 1) & 1);
+    b_rd[i] = prow * (CB * 16) + ((chunk ^ trswz<CB>(prow)) << 4) + (j & 1) * 8;
+  }
+#define RIGL_WTR_COMPUTE(stage_)                                                                      \
+  {                                                                                                   \
+    const unsigned char* As = smem + (stage_) * STAGE;                                                \
+    const unsigned char* Bs = As + A_BYTES;                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                          \
+      bf16x8 af[TM], bfr[TN];                                                                         \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+        af[i] = lds_read_tr_pair(As + a_rd[i] + (ks * 16) * (CA * 16), As + a_rd[i] + (ks * 16 + 4) * (CA * 16)); \
+      _Pragma("unroll") for (int i = 0; i < TN; ++i)                                                  \
+        bfr[i] = lds_read_tr_pair(Bs + b_rd[i] + (ks * 16) * (CB * 16), Bs + b_rd[i] + (ks * 16 + 4) * (CB * 16)); \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+        _Pragma("unroll") for (int jj = 0; jj < TN; ++jj)                                             \
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[jj], acc[i][jj], 0, 0, 0);  \
+    }                                                                                                 \
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
+
+  constexpr int L = APASS + BPASS;
+  for (int t = 0; t < STAGES - 1; ++t)
+    if (t < KT) RIGL_WTR_ISSUE(t);
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + STAGES - 1 <= KT) wait_vmcnt<L * (STAGES - 2)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + STAGES - 1 < KT) RIGL_WTR_ISSUE((kt + STAGES - 1) % STAGES);
+    RIGL_WTR_COMPUTE(kt % STAGES);
+  }
+#undef RIGL_WTR_ISSUE
+#undef RIGL_WTR_COMPUTE
+  float* out = P.OUT + (int64_t)split * P.slab_elems + (int64_t)tap * P.Cin * P.Cout;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = ci0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int co = co0 + wn * 32 * TN + jj * 32 + (lane & 31);
+        if (ci < P.Cin && co < P.Cout) out[(int64_t)ci * P.Cout + co] = acc[i][jj][e];
+      }
+}
+
 // dw[i] = sum_s slab[s][i] in a FIXED order (deterministic => identical masks
 // run to run).  A workgroup owns 64 consecutive outputs; its 256 threads are 16
 // float4 columns x 16 split-groups, so 16 independent 256-B reads are in flight
@@ -765,6 +941,26 @@ static inline bool small_cin(const RiglConvDesc* d) { return (d->cin % 8) != 0 &
 static inline int kpad(const RiglConvDesc* d) { return (d->kh * d->kw * d->cin + 31) / 32 * 32; }
 
 struct WgradPlan { int tm, tn, tiles_ci, tiles_co, splits; int64_t slab; };
+// DMA ring depth of the tr kernel: 3 stages for the 128x128 tile (48 KB -> 3 workgroups/CU),
+// 4 for the smaller tiles (measured per layer; RIGL_WGRAD_STAGES=3|4 forces one).
+static int wgrad_stages(int tm, int tn) {
+  static const int forced = [] { const char* e = getenv("RIGL_WGRAD_STAGES"); return e ? atoi(e) : 0; }();
+  if (forced == 3 || forced == 4) return forced;
+  return (tm == 2 && tn == 2) ? 3 : 4;
+}
+static int num_cus() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return n;
+}
+// Split-K plan.  Partial slabs cost 8 B of HBM traffic per output element per split, so
+// the split count is the largest that still fits ONE co-resident round of workgroups
+// (CUs x workgroups/CU at this tile's LDS footprint: 64/48/32 KB -> 2/3/4); one more
+// workgroup than that starts a second, nearly empty round (measured: 513 workgroups of
+// the 128x128 tile take 1.4x the time of 504).
 static WgradPlan plan_wgrad(int M, int cin, int cout, int taps) {
   WgradPlan p;
   p.tm = cin > 64 ? 2 : 1;
@@ -773,10 +969,16 @@ static WgradPlan plan_wgrad(int M, int cin, int cout, int taps) {
   p.tiles_co = (cout + 64 * p.tn - 1) / (64 * p.tn);
   const int64_t base = (int64_t)p.tiles_ci * p.tiles_co * taps;
   const int kt = (M + 63) / 64;
-  int64_t s = (1024 + base - 1) / base;      // aim for ~1024 workgroups (4 per CU)
-  if (s > kt / 4) s = kt / 4;                // at least 4 K-tiles (256 pixels) per split
+  static const int target = [] { const char* e = getenv("RIGL_WGRAD_WGS"); return e ? atoi(e) : 0; }();
+  const int lds = wgrad_stages(p.tm, p.tn) * 32 * 64 * (p.tm + p.tn) * 2;   // bytes of the tr kernel's DMA ring
+  static const int lds_cu = [] { const char* e = getenv("RIGL_WGRAD_LDS_KB"); return (e ? atoi(e) : 160) * 1024; }();
+  int occ = lds_cu / lds;
+  if (occ > 4) occ = 4;
+  const int64_t slots = target > 0 ? target : (int64_t)num_cus() * occ;
+  int64_t s = slots / base;
+  if (s > kt / 4) s = kt / 4;                // at least 256 pixels per split
   if (s < 1) s = 1;
-  if (s > 512) s = 512;
+  if (s > 1024) s = 1024;
   p.splits = (int)s;
   p.slab = (int64_t)taps * cin * cout;
   return p;
@@ -946,10 +1148,25 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   const bool two_pass = p.splits > 1 || small_cin(d) || tiny_cin(d);
   a.OUT = two_pass ? reinterpret_cast<float*>(ws) : dw;
   dim3 grid((unsigned)((int64_t)p.tiles_ci * p.tiles_co * a.KH * a.KW * p.splits)), blk(THREADS);
-  if (p.tm == 2 && p.tn == 2) hipLaunchKernelGGL((k_wgrad<2, 2>), grid, blk, 0, st, a);
-  else if (p.tm == 2) hipLaunchKernelGGL((k_wgrad<2, 1>), grid, blk, 0, st, a);
-  else if (p.tn == 2) hipLaunchKernelGGL((k_wgrad<1, 2>), grid, blk, 0, st, a);
-  else hipLaunchKernelGGL((k_wgrad<1, 1>), grid, blk, 0, st, a);
+  static const bool use_tr = [] { const char* e = getenv("RIGL_WGRAD_TR"); return e ? atoi(e) != 0 : true; }();
+  if (use_tr) {
+    if (wgrad_stages(p.tm, p.tn) == 3) {
+      if (p.tm == 2 && p.tn == 2) hipLaunchKernelGGL((k_wgrad_tr<2, 2, 3>), grid, blk, 0, st, a);
+      else if (p.tm == 2) hipLaunchKernelGGL((k_wgrad_tr<2, 1, 3>), grid, blk, 0, st, a);
+      else if (p.tn == 2) hipLaunchKernelGGL((k_wgrad_tr<1, 2, 3>), grid, blk, 0, st, a);
+      else hipLaunchKernelGGL((k_wgrad_tr<1, 1, 3>), grid, blk, 0, st, a);
+    } else {
+      if (p.tm == 2 && p.tn == 2) hipLaunchKernelGGL((k_wgrad_tr<2, 2, 4>), grid, blk, 0, st, a);
+      else if (p.tm == 2) hipLaunchKernelGGL((k_wgrad_tr<2, 1, 4>), grid, blk, 0, st, a);
+      else if (p.tn == 2) hipLaunchKernelGGL((k_wgrad_tr<1, 2, 4>), grid, blk, 0, st, a);
+      else hipLaunchKernelGGL((k_wgrad_tr<1, 1, 4>), grid, blk, 0, st, a);
+    }
+  } else {
+    if (p.tm == 2 && p.tn == 2) hipLaunchKernelGGL((k_wgrad<2, 2>), grid, blk, 0, st, a);
+    else if (p.tm == 2) hipLaunchKernelGGL((k_wgrad<2, 1>), grid, blk, 0, st, a);
+    else if (p.tn == 2) hipLaunchKernelGGL((k_wgrad<1, 2>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((k_wgrad<1, 1>), grid, blk, 0, st, a);
+  }
   if (two_pass) {
     const int64_t blocks = ceil_div64(n_out, 64);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)blocks), blk, 0, st, reinterpret_cast<const float*>(ws),
