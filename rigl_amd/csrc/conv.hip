@@ -863,9 +863,16 @@ static TinyGeom tiny_geom(const RiglConvDesc* d) {
 template <int MODE, bool F32, bool CLS>
 static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, int bk, bool dma, hipStream_t st) {
   dim3 blk(THREADS);
-  if (dma) {   // 4-stage LDS-DMA ring, BK = 32 (64 KB of LDS, 2 workgroups per CU)
-    if (wide_n) hipLaunchKernelGGL((k_igemm<2, 2, 32, MODE, F32, CLS, 4>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((k_igemm<2, 1, 32, MODE, F32, CLS, 4>), grid, blk, 0, st, a);
+  if (dma) {   // LDS-DMA ring, BK = 32: 3 stages = 48 KB of LDS -> 3 workgroups per CU (the 136-VGPR limit too); 4 stages
+    // = 64 KB -> 2 per CU measured 4-7 % slower over the ResNet-50 layer set (RIGL_CONV_STAGES=4 to compare)
+    static const int stages = [] { const char* e = getenv("RIGL_CONV_STAGES"); return (e && atoi(e) == 4) ? 4 : 3; }();
+    if (stages == 3) {
+      if (wide_n) hipLaunchKernelGGL((k_igemm<2, 2, 32, MODE, F32, CLS, 3>), grid, blk, 0, st, a);
+      else hipLaunchKernelGGL((k_igemm<2, 1, 32, MODE, F32, CLS, 3>), grid, blk, 0, st, a);
+    } else {
+      if (wide_n) hipLaunchKernelGGL((k_igemm<2, 2, 32, MODE, F32, CLS, 4>), grid, blk, 0, st, a);
+      else hipLaunchKernelGGL((k_igemm<2, 1, 32, MODE, F32, CLS, 4>), grid, blk, 0, st, a);
+    }
     return;
   }
   if (wide_n) {
@@ -894,7 +901,8 @@ static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
   static const int bk_cap = [] { const char* e = getenv("RIGL_CONV_BK"); return e ? atoi(e) : 64; }();   // tuning knobs
   static const int use_dma = [] { const char* e = getenv("RIGL_CONV_DMA"); return e ? atoi(e) : 1; }();
   if (bk > bk_cap && bk_cap >= 16) bk = bk_cap;
-  const bool dma = use_dma && a.Cred >= 32;
+  static const int shortk = [] { const char* e = getenv("RIGL_CONV_SHORTK"); return e ? atoi(e) : 0; }();
+  const bool dma = use_dma && a.Cred >= 32 && a.KH * a.KW * ((a.Cred + 31) / 32) > shortk;
   if (MODE == 1 && (a.sh > 1 || a.sw > 1) && a.sh <= 2 && a.sw <= 2) {
     // class-major rows: class c = (h % sh) * sw + (w % sw)
     const int n_img = a.M / (a.RH * a.RW);
