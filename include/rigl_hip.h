@@ -217,6 +217,16 @@ int rigl_masked_conv2d_dgrad(const RiglConvDesc* d, const rigl_bf16* dy,
                              const rigl_bf16* w_hwio, rigl_bf16* dx,
                              void* workspace, size_t workspace_bytes,
                              rigl_stream_t stream);
+/* dx = conv2d_backprop_input(dy, mask*W) + addend: the gradient accumulation
+ * TF's autodiff emits (AddN) where a tensor feeds two consumers -- a residual
+ * block's input feeds conv1 and the shortcut (resnet_model.py:300-330, 374-420)
+ * -- folded into the dgrad epilogue.  addend: bf16 NHWC like dx, nullable
+ * (then identical to rigl_masked_conv2d_dgrad); may alias dx.
+ * out = bf16(bf16(dgrad) + addend), bit-identical to dgrad followed by an add. */
+int rigl_masked_conv2d_dgrad_acc(const RiglConvDesc* d, const rigl_bf16* dy,
+                                 const rigl_bf16* w_hwio, const rigl_bf16* addend,
+                                 rigl_bf16* dx, void* workspace,
+                                 size_t workspace_bytes, rigl_stream_t stream);
 /* dw: fp32 [kh][kw][cin][cout], DENSE (overwritten, not accumulated).       */
 int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x,
                              const rigl_bf16* dy, float* dw, void* workspace,

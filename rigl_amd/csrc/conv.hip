@@ -32,6 +32,12 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
   return (uint16_t)(u >> 16);
 }
 
+__device__ __forceinline__ uint32_t add_bf16x2(uint32_t a, uint32_t b) {
+  const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
+  const float hi = __uint_as_float(a & 0xFFFF0000u) + __uint_as_float(b & 0xFFFF0000u);
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
 // Byte offset of 16-byte chunk `chunk` of row `row` in a [rows][BK] bf16 tile.
 // The chunk index is XORed with a row-derived value so that the 16-lane groups
 // of ds_read_b128 (rows r..r+3, r+12.., r+20..) hit 16 distinct 16-B slots.
@@ -80,6 +86,7 @@ struct IgemmArgs {
   const uint16_t* A;   // gathered activation tensor (x for fwd, dy for dgrad), NHWC
   const uint16_t* B;   // packed weights
   void* C;             // output rows
+  const uint16_t* ADD; // optional bf16 tensor added to the bf16 output rows (same layout as C), or NULL
   int M, N, Cred;      // GEMM rows, columns, reduction channels per tap
   int KH, KW;
   int RH, RW;          // spatial size of the row space (ho,wo | h,w)
@@ -375,8 +382,14 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
     for (int idx = tid; idx < BM * CH; idx += THREADS) {
       const int row = idx / CH, ch = idx % CH;
       const int m = CLS ? rowpix[row] : m0 + row, n = n0 + ch * 8;
-      if (m >= 0 && m < P.M && n < P.N)
-        *reinterpret_cast<uint4*>(C + (int64_t)m * P.ldc + n) = *reinterpret_cast<const uint4*>(Cs + row * CS_LD + ch * 8);
+      if (m >= 0 && m < P.M && n < P.N) {
+        uint4 v = *reinterpret_cast<const uint4*>(Cs + row * CS_LD + ch * 8);
+        if (P.ADD) {   // fused gradient accumulation: out = bf16(bf16(acc) + addend), as the separate add would give
+          const uint4 q = *reinterpret_cast<const uint4*>(P.ADD + (int64_t)m * P.ldc + n);
+          v.x = add_bf16x2(v.x, q.x); v.y = add_bf16x2(v.y, q.y); v.z = add_bf16x2(v.z, q.z); v.w = add_bf16x2(v.w, q.w);
+        }
+        *reinterpret_cast<uint4*>(C + (int64_t)m * P.ldc + n) = v;
+      }
     }
   }
 }
@@ -1079,8 +1092,9 @@ int rigl_masked_conv2d_fwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl
   return RIGL_OK;
 }
 
-int rigl_masked_conv2d_dgrad(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf16* w_hwio, rigl_bf16* dx,
-                             void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+int rigl_masked_conv2d_dgrad_acc(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                                 const rigl_bf16* addend, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
+                                 rigl_stream_t stream) {
   using namespace rigl;
   using namespace rigl::k1;
   (void)workspace; (void)workspace_bytes;
@@ -1091,7 +1105,7 @@ int rigl_masked_conv2d_dgrad(const RiglConvDesc* d, const rigl_bf16* dy, const r
   hipStream_t st = as_stream(stream);
   ProfScope prof(PROF_CONV_DGRAD, st);
   IgemmArgs a = {};
-  a.A = dy; a.B = w_hwio; a.C = dx;
+  a.A = dy; a.B = w_hwio; a.C = dx; a.ADD = addend;
   a.M = d->n * d->h * d->w; a.N = d->cin; a.Cred = d->cout; a.ldc = d->cin;
   a.KH = d->kh; a.KW = d->kw; a.RH = d->h; a.RW = d->w; a.GH = d->ho; a.GW = d->wo;
   a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
@@ -1101,6 +1115,11 @@ int rigl_masked_conv2d_dgrad(const RiglConvDesc* d, const rigl_bf16* dy, const r
   launch_igemm<1, false>(a, st);
   RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
   return RIGL_OK;
+}
+
+int rigl_masked_conv2d_dgrad(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf16* w_hwio, rigl_bf16* dx,
+                             void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+  return rigl_masked_conv2d_dgrad_acc(d, dy, w_hwio, nullptr, dx, workspace, workspace_bytes, stream);
 }
 
 int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, float* dw,

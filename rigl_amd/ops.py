@@ -253,20 +253,29 @@ def conv_fwd(d, x, w_ohwi, y=None, force_ref=False):
   return y
 
 
-def conv_dgrad(d, dy, w_hwio, dx=None, force_ref=False):
+def conv_dgrad(d, dy, w_hwio, dx=None, force_ref=False, addend=None):
+  """dx = conv2d_backprop_input(dy, w) (+ addend, fused into the epilogue: the
+  gradient accumulation of a tensor that feeds this conv and a shortcut)."""
   _req(dy, torch.bfloat16, 'dy')
   _req(w_hwio, torch.bfloat16, 'w_hwio')
   if dx is None:
     dx = torch.empty((d.n, d.h, d.w, d.cin), dtype=torch.bfloat16,
                      device=dy.device)
   _req(dx, torch.bfloat16, 'dx')
+  if addend is not None:
+    _req(addend, torch.bfloat16, 'addend')
+    if addend.numel() != dx.numel():
+      raise ValueError('addend must have the shape of dx')
   lib = _lib.load()
   if force_ref or not mfma_dgrad_supported(d):
     check(lib.rigl_conv2d_dgrad_ref(C.byref(d), _ptr(dy), _ptr(w_hwio),
                                     _ptr(dx), _stream()))
+    if addend is not None:
+      dx += addend.view_as(dx)
     return dx
-  check(lib.rigl_masked_conv2d_dgrad(C.byref(d), _ptr(dy), _ptr(w_hwio),
-                                     _ptr(dx), None, 0, _stream()))
+  check(lib.rigl_masked_conv2d_dgrad_acc(C.byref(d), _ptr(dy), _ptr(w_hwio),
+                                         _ptr(addend), _ptr(dx), None, 0,
+                                         _stream()))
   return dx
 
 

@@ -60,6 +60,33 @@ class _MaskedConvFn(torch.autograd.Function):
     return dx, None, None, None
 
 
+class _MaskedConvForkFn(torch.autograd.Function):
+  """(y, x') = (conv(x, mask*W), x): the conv plus an alias of its input for the
+  tensor's OTHER consumer (a residual shortcut, or the next conv reading the
+  same block input).  Backward folds the alias' gradient into the dgrad
+  epilogue -- dx = conv2d_backprop_input(dy, mask*W) + dx' -- instead of the
+  separate AddN pass autodiff would emit (rigl_masked_conv2d_dgrad_acc)."""
+
+  @staticmethod
+  def forward(ctx, x, lv, desc):
+    ctx.lv, ctx.desc = lv, desc
+    ctx.save_for_backward(x)
+    return ops.conv_fwd(desc, x, lv.ohwi), x.view_as(x)
+
+  @staticmethod
+  def backward(ctx, dy, dalias):
+    (x,) = ctx.saved_tensors
+    lv, d = ctx.lv, ctx.desc
+    dy = dy.contiguous()
+    ops.conv_wgrad(d, x, dy, lv.weights.grad.view(-1))
+    sync = getattr(lv.weights.graph, 'grad_sync', None)
+    if sync is not None:
+      sync.notify_layer_grad_ready(lv.weights)
+    if dalias is not None:
+      dalias = dalias.contiguous()
+    return ops.conv_dgrad(d, dy, lv.hwio, addend=dalias), None, None
+
+
 class _Layer:
   """Common part of MaskedConv2d / MaskedDense."""
 
@@ -132,6 +159,17 @@ class MaskedConv2d(_Layer):
     if not x.requires_grad:
       x = x.detach().requires_grad_(True)  # keep the node so wgrad runs
     return _MaskedConvFn.apply(x.contiguous(), self.vars, d, need_dx)
+
+  def fork(self, x):
+    """Returns (conv(x), x'): use x' for x's other consumer and its gradient
+    is accumulated inside this conv's dgrad kernel (see _MaskedConvForkFn)."""
+    if x.dim() != 4 or x.shape[-1] != self.cin:
+      raise ValueError('expected [N,H,W,%d], got %s' % (self.cin, tuple(x.shape)))
+    if not (self.need_input_grad and x.requires_grad):
+      return self(x), x
+    self.graph.refresh_shadows()
+    n, h, w, _ = x.shape
+    return _MaskedConvForkFn.apply(x.contiguous(), self.vars, self.desc_for(n, h, w))
 
 
 class MaskedDense(_Layer):

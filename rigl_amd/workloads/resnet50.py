@@ -49,6 +49,9 @@ class _ConvFixedPadding:
   def __call__(self, x):
     return self.conv(x)
 
+  def fork(self, x):
+    return self.conv.fork(x)
+
 
 class _Bottleneck:
   """bottleneck_block_ (resnet_model.py:396-501)."""
@@ -67,10 +70,15 @@ class _Bottleneck:
     self.bn3 = gnn.BatchNorm(graph, tag + '/bn3', by_role['c3'].cout, init_zero=True)
 
   def __call__(self, x, is_training):
-    shortcut = x
+    # The block input feeds two consumers; the first one hands back an alias whose
+    # gradient it accumulates in its own dgrad epilogue (no separate AddN pass).
     if self.proj is not None:
-      shortcut = self.proj_bn(self.proj(x), is_training, relu=False)
-    y = self.bn1(self.c1(x), is_training, relu=True)
+      p, x = self.proj.fork(x)
+      shortcut = self.proj_bn(p, is_training, relu=False)
+      y = self.c1(x)
+    else:
+      y, shortcut = self.c1.fork(x)
+    y = self.bn1(y, is_training, relu=True)
     y = self.bn2(self.c2(y), is_training, relu=True)
     return self.bn3(self.c3(y), is_training, relu=True, residual=shortcut)   # relu(bn3 + shortcut)
 

@@ -255,12 +255,30 @@ def test_resnet50_every_conv_in_situ_and_loss_vs_cpu_oracle(rn50):
                    dw=ctx.lv.weights.grad.detach().clone())
     return out
 
+  # the convs that share their input with a shortcut (fused gradient accumulation)
+  ffwd0, fbwd0 = PL._MaskedConvForkFn.forward, PL._MaskedConvForkFn.backward
+
+  def ffwd(ctx, x, lv, desc):
+    y, alias = ffwd0(ctx, x, lv, desc)
+    rec.append(dict(lv=lv, d=desc, x=x.detach().clone(), y=y.detach().clone()))
+    ctx.rec = rec[-1]
+    return y, alias
+
+  def fbwd(ctx, dy, dalias):
+    out = fbwd0(ctx, dy, dalias)
+    ctx.rec.update(dy=dy.detach().clone(), dx=out[0].detach().clone(), dw=ctx.lv.weights.grad.detach().clone(),
+                   dadd=None if dalias is None else dalias.detach().clone())
+    return out
+
   PL._MaskedConvFn.forward, PL._MaskedConvFn.backward = staticmethod(fwd), staticmethod(bwd)
+  PL._MaskedConvForkFn.forward, PL._MaskedConvForkFn.backward = staticmethod(ffwd), staticmethod(fbwd)
   try:
     loss = model.loss(images, labels, label_smoothing=0.1)
     opt.compute_gradients(loss)
   finally:
     PL._MaskedConvFn.forward, PL._MaskedConvFn.backward = staticmethod(fwd0), staticmethod(bwd0)
+    PL._MaskedConvForkFn.forward, PL._MaskedConvForkFn.backward = staticmethod(ffwd0), staticmethod(fbwd0)
+  assert sum(1 for r in rec if r.get('dadd') is not None) == 16      # one per bottleneck block
   assert len(rec) == 54
   for r in rec:
     d, lv = r['d'], r['lv']
@@ -277,6 +295,8 @@ def test_resnet50_every_conv_in_situ_and_loss_vs_cpu_oracle(rn50):
     assert (r['dw'].reshape(dwr.shape) - dwr).abs().max() <= 3e-4 * dwr.abs().max() + 1e-9, tag
     if r['dx'] is not None:
       dxr = x.grad.permute(0, 2, 3, 1)
+      if r.get('dadd') is not None:
+        dxr = dxr + r['dadd'].float()
       assert (r['dx'].float() - dxr).abs().max() <= 2.0**-7 * dxr.abs().max() + 1e-9, tag
   # (b) loss vs the CPU model with the same (bf16-rounded, masked) weights
   cpu = ResNet50CPU(seed=0)

@@ -204,6 +204,28 @@ def test_conv_fwd_dgrad_wgrad(case):
     _check('wgrad_ref', dw2, dwr, dwa, 1e-5)
 
 
+@pytest.mark.parametrize('case', [CONV_CASES[0], CONV_CASES[3], CONV_CASES[4], CONV_CASES[5], CONV_CASES[13],
+                                  CONV_CASES[14], CONV_CASES[15]])
+def test_conv_dgrad_accumulate_is_dgrad_plus_addend(case):
+  """rigl_masked_conv2d_dgrad_acc == dgrad followed by a bf16 add, bit for bit
+  (stride-1, parity-class stride-2 incl. classes without taps, ragged M)."""
+  from rigl_amd import ops
+  N, H, W, Cin, Cout, k, stride, pt, pl, Ho, Wo = case
+  g = torch.Generator().manual_seed(7 + sum(case))
+  dy = torch.randn(N, Ho, Wo, Cout, generator=g).to(torch.bfloat16).to(DEV)
+  add = torch.randn(N, H, W, Cin, generator=g).to(torch.bfloat16).to(DEV)
+  hwio = (torch.randn(k * k * Cin * Cout, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+  d = ops.conv_desc(N, H, W, Cin, Cout, k, k, stride, pt, pl, Ho, Wo)
+  plain = ops.conv_dgrad(d, dy, hwio)
+  fused = ops.conv_dgrad(d, dy, hwio, addend=add)
+  want = plain + add
+  assert torch.equal(fused.view(torch.int16), want.view(torch.int16))
+  # in place on the addend buffer is allowed
+  buf = add.clone()
+  ops.conv_dgrad(d, dy, hwio, dx=buf, addend=buf)
+  assert torch.equal(buf.view(torch.int16), want.view(torch.int16))
+
+
 def test_conv_asymmetric_b_detects_transposes():
   """A = identity-like activations, asymmetric weights: catches swapped
   rows/cols in the MFMA C/D mapping (guide rule 16)."""
