@@ -217,6 +217,19 @@ int rigl_masked_conv2d_dgrad(const RiglConvDesc* d, const rigl_bf16* dy,
                              const rigl_bf16* w_hwio, rigl_bf16* dx,
                              void* workspace, size_t workspace_bytes,
                              rigl_stream_t stream);
+/* Forward conv that also leaves the batch-norm statistics of its output
+ * behind (the reference follows every conv with tf.layers.batch_normalization,
+ * resnet_model.py:41-82, whose first pass re-reads the whole activation):
+ * stats[p][0][c] = sum, stats[p][1][c] = sum of squares of the bf16-rounded
+ * outputs of 128-row tile p, p < rigl_conv2d_stats_parts(d), computed in the
+ * epilogue from the tile already in LDS (deterministic, no atomics).
+ * stats == NULL: plain rigl_masked_conv2d_fwd.                              */
+int32_t rigl_conv2d_stats_parts(const RiglConvDesc* d);
+int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x,
+                                 const rigl_bf16* w_ohwi, rigl_bf16* y,
+                                 float* stats, size_t stats_floats,
+                                 void* workspace, size_t workspace_bytes,
+                                 rigl_stream_t stream);
 /* dx = conv2d_backprop_input(dy, mask*W) + addend: the gradient accumulation
  * TF's autodiff emits (AddN) where a tensor feeds two consumers -- a residual
  * block's input feeds conv1 and the shortcut (resnet_model.py:300-330, 374-420)
@@ -283,6 +296,19 @@ int rigl_bn_fwd(int64_t m, int32_t c, const rigl_bf16* x,
                 float* save_mean, float* save_invstd, float* save_scale,
                 float* save_shift, void* workspace, size_t workspace_bytes,
                 rigl_stream_t stream);
+/* As rigl_bn_fwd, with the statistics pass replaced by the partial sums a
+ * producer left behind: stats = [stats_parts][2][c] fp32 (sum x, sum x^2 over
+ * disjoint row sets covering all m rows), e.g. from
+ * rigl_masked_conv2d_fwd_stats.  stats == NULL behaves like rigl_bn_fwd
+ * (workspace required); with stats the workspace may be NULL.               */
+int rigl_bn_fwd_stats(int64_t m, int32_t c, const rigl_bf16* x,
+                      const rigl_bf16* residual /* nullable */,
+                      const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum,
+                      float eps, int32_t relu, rigl_bf16* y, float* save_mean,
+                      float* save_invstd, float* save_scale, float* save_shift,
+                      const float* stats, int32_t stats_parts, void* workspace,
+                      size_t workspace_bytes, rigl_stream_t stream);
 int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x,
                 const rigl_bf16* y /* nullable */, const rigl_bf16* dy,
                 const float* gamma, const float* save_mean,

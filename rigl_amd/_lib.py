@@ -83,6 +83,9 @@ SIGNATURES = {
                                          _SZ, _P]),
     'rigl_masked_conv2d_dgrad': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P,
                                            _SZ, _P]),
+    'rigl_conv2d_stats_parts': (_I32, [C.POINTER(ConvDesc)]),
+    'rigl_masked_conv2d_fwd_stats': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P,
+                                               _SZ, _P, _SZ, _P]),
     'rigl_masked_conv2d_dgrad_acc': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P,
                                                _P, _P, _SZ, _P]),
     'rigl_masked_conv2d_wgrad': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P,
@@ -96,6 +99,7 @@ SIGNATURES = {
     'rigl_depthwise_conv2d_wgrad': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _SZ, _P]),
     'rigl_bn_workspace_bytes': (_SZ, [_I64, _I32]),
     'rigl_bn_fwd': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    'rigl_bn_fwd_stats': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _SZ, _P]),
     'rigl_bn_bwd': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _SZ, _P]),
     'rigl_prof_enable': (C.c_int, [_I32]),
     'rigl_prof_collect': (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64)]),

@@ -108,17 +108,22 @@ __global__ __launch_bounds__(THREADS) void k_reduce(Geom G, const uint16_t* __re
   }
 }
 
-// Sums the per-part partials of 16 channels with 16 part-lanes each (fixed
-// order: lane-strided, then lanes ascending) -- a 256-thread block per 16
-// channels instead of one thread walking all parts serially.
+// Sums the per-part partials of CL channels with 256/CL part-lanes each (fixed
+// order: lane-strided, then lanes ascending) -- a 256-thread block per CL
+// channels instead of one thread walking all parts serially.  CL = 16 for the
+// <= 512 partials of k_reduce, 4 (64 part-lanes) for the per-row-tile partials a
+// conv epilogue leaves (up to M/128 of them).
+template <int CL>
 __device__ __forceinline__ void sum_partials(const Geom& G, const float* __restrict__ partial, double& s0, double& s1,
                                              int& c, bool& leader) {
-  __shared__ double acc[2][16][17];
-  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-  c = blockIdx.x * 16 + cl;
+  constexpr int PL = THREADS / CL;
+  __shared__ double acc[2][PL][CL + 1];
+  const int cl = threadIdx.x % CL, pl = threadIdx.x / CL;
+  c = blockIdx.x * CL + cl;
   double a0 = 0.0, a1 = 0.0;
   if (c < G.C) {
-    for (int p = pl; p < G.parts; p += 16) {
+#pragma unroll 4
+    for (int p = pl; p < G.parts; p += PL) {
       a0 += (double)partial[((int64_t)p * 2) * G.C + c];
       a1 += (double)partial[((int64_t)p * 2 + 1) * G.C + c];
     }
@@ -128,12 +133,13 @@ __device__ __forceinline__ void sum_partials(const Geom& G, const float* __restr
   leader = pl == 0 && c < G.C;
   s0 = s1 = 0.0;
   if (leader) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { s0 += acc[0][k][cl]; s1 += acc[1][k][cl]; }
+#pragma unroll 8
+    for (int k = 0; k < PL; ++k) { s0 += acc[0][k][cl]; s1 += acc[1][k][cl]; }
   }
 }
 
 // Forward finalize: mean / invstd, running statistics, fused scale & shift.
+template <int CL>
 __global__ __launch_bounds__(THREADS) void k_fwd_finalize(Geom G, const float* __restrict__ partial,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(THREADS) void k_fwd_finalize(Geom G, const float* _
                                                            float* __restrict__ save_invstd, float* __restrict__ scale,
                                                            float* __restrict__ shift) {
   double s0, s1; int c; bool leader;
-  sum_partials(G, partial, s0, s1, c, leader);
+  sum_partials<CL>(G, partial, s0, s1, c, leader);
   if (!leader) return;
   const double m = (double)G.M;
   const double mean = s0 / m;
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(THREADS) void k_bwd_finalize(Geom G, const float* _
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            float* __restrict__ coef /*[3][C]: a, b, c*/) {
   double s0, s1; int c; bool leader;
-  sum_partials(G, partial, s0, s1, c, leader);
+  sum_partials<16>(G, partial, s0, s1, c, leader);
   if (!leader) return;
   dbeta[c] = (float)s0;
   dgamma[c] = (float)s1;
@@ -280,26 +286,38 @@ size_t rigl_bn_workspace_bytes(int64_t m, int32_t c) {
   return rigl::align_up((size_t)g.parts * 2 * c * 4, 256) + rigl::align_up((size_t)3 * c * 4, 256);
 }
 
-int rigl_bn_fwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* residual, const float* gamma,
-                const float* beta, float* running_mean, float* running_var, float momentum, float eps, int32_t relu,
-                rigl_bf16* y, float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
-                void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+int rigl_bn_fwd_stats(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* residual, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                      int32_t relu, rigl_bf16* y, float* save_mean, float* save_invstd, float* save_scale,
+                      float* save_shift, const float* stats, int32_t stats_parts, void* workspace,
+                      size_t workspace_bytes, rigl_stream_t stream) {
   using namespace rigl;
   using namespace rigl::kbn;
   if (m <= 0 || c <= 0 || !x || !gamma || !beta || !y || !save_mean || !save_invstd || !save_scale || !save_shift)
     return fail(RIGL_EINVAL, "rigl_bn_fwd: bad arguments");
   if (c % 8) return fail(RIGL_EUNSUPPORTED, "rigl_bn_fwd: channels %% 8 != 0");
   if (2 * (size_t)c * 4 > 65536) return fail(RIGL_EUNSUPPORTED, "rigl_bn_fwd: too many channels for the LDS parameter cache");
-  const size_t need = rigl_bn_workspace_bytes(m, c);
-  if (!workspace || workspace_bytes < need) return fail(RIGL_EWORKSPACE, "rigl_bn_fwd: workspace %zu < %zu", workspace_bytes, need);
+  if (stats && stats_parts <= 0) return fail(RIGL_EINVAL, "rigl_bn_fwd_stats: stats_parts must be positive");
   hipStream_t st = as_stream(stream);
   Geom g = make_geom(m, c);
-  float* partial = static_cast<float*>(workspace);
-  dim3 rgrid((unsigned)g.parts, (unsigned)((g.cg + g.tpr - 1) / g.tpr));
-  hipLaunchKernelGGL((k_reduce<0, false, false>), rgrid, dim3(THREADS), 0, st, g, x, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, partial);
-  hipLaunchKernelGGL(k_fwd_finalize, dim3((unsigned)((c + 15) / 16)), dim3(THREADS), 0, st, g, partial, gamma,
-                     beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale, save_shift);
+  const float* partial = stats;
+  if (!stats) {
+    const size_t need = rigl_bn_workspace_bytes(m, c);
+    if (!workspace || workspace_bytes < need) return fail(RIGL_EWORKSPACE, "rigl_bn_fwd: workspace %zu < %zu", workspace_bytes, need);
+    float* ws_partial = static_cast<float*>(workspace);
+    dim3 rgrid((unsigned)g.parts, (unsigned)((g.cg + g.tpr - 1) / g.tpr));
+    hipLaunchKernelGGL((k_reduce<0, false, false>), rgrid, dim3(THREADS), 0, st, g, x, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, ws_partial);
+    partial = ws_partial;
+  } else {
+    g.parts = stats_parts;               // the producer's partial sums [stats_parts][2][C] replace the reduction pass
+  }
+  if (g.parts > 256)
+    hipLaunchKernelGGL(k_fwd_finalize<4>, dim3((unsigned)((c + 3) / 4)), dim3(THREADS), 0, st, g, partial, gamma,
+                       beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale, save_shift);
+  else
+    hipLaunchKernelGGL(k_fwd_finalize<16>, dim3((unsigned)((c + 15) / 16)), dim3(THREADS), 0, st, g, partial, gamma,
+                       beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale, save_shift);
   const size_t lds = (size_t)2 * c * 4;
   dim3 agrid(apply_grid(g));
   if (relu && residual) hipLaunchKernelGGL((k_fwd_apply<true, true>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y);
@@ -308,6 +326,14 @@ int rigl_bn_fwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* resid
   else hipLaunchKernelGGL((k_fwd_apply<false, false>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y);
   RIGL_CHECK_LAUNCH("rigl_bn_fwd");
   return RIGL_OK;
+}
+
+int rigl_bn_fwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* residual, const float* gamma,
+                const float* beta, float* running_mean, float* running_var, float momentum, float eps, int32_t relu,
+                rigl_bf16* y, float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
+                void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+  return rigl_bn_fwd_stats(m, c, x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, y, save_mean,
+                           save_invstd, save_scale, save_shift, nullptr, 0, workspace, workspace_bytes, stream);
 }
 
 int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* y, const rigl_bf16* dy, const float* gamma,

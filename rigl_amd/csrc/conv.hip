@@ -87,6 +87,7 @@ struct IgemmArgs {
   const uint16_t* B;   // packed weights
   void* C;             // output rows
   const uint16_t* ADD; // optional bf16 tensor added to the bf16 output rows (same layout as C), or NULL
+  float* STATS;        // optional per-row-tile column statistics [tiles_m][2][N]: sum y, sum y^2 of the bf16 outputs
   int M, N, Cred;      // GEMM rows, columns, reduction channels per tap
   int KH, KW;
   int RH, RW;          // spatial size of the row space (ho,wo | h,w)
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int CS_LD = BN + 8;
   constexpr int EPI = OUT_F32 ? 0 : BM * CS_LD * 2;
-  constexpr int EPI_ALL = EPI + (CLS ? BM * 4 : 0);       // + per-row output pixel table
+  constexpr int EPI_TAB = EPI + (CLS ? BM * 4 : 0);       // + per-row output pixel table
+  constexpr int EPI_ALL = EPI_TAB + ((MODE == 0 && !OUT_F32) ? THREADS * 8 : 0);   // + column-statistics scratch
   constexpr int SMEM = (STAGES * STAGE > EPI_ALL) ? STAGES * STAGE : EPI_ALL;
   static_assert(SMEM <= 65536, "static LDS limit");
   static_assert(STAGES == 2 || (BM % RPP == 0 && BN % RPP == 0), "LDS-DMA needs whole 1-KB wave rows");
@@ -377,6 +379,28 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
           Cs[row * CS_LD + col] = f2bf(acc[i][j][e]);
         }
     __syncthreads();
+    if (MODE == 0 && P.STATS) {
+      // Batch-norm statistics of this row tile, from the bf16-rounded outputs the BN will
+      // read: PARTS row-slices per column, combined in a fixed order (deterministic).
+      // Rows beyond M hold exact zeros (their gathers were zero-filled).
+      constexpr int PARTS = THREADS / BN, RPS = BM / PARTS;
+      const int col = tid % BN, part = tid / BN;
+      float sy = 0.f, sq = 0.f;
+#pragma unroll 8
+      for (int r2 = 0; r2 < RPS; ++r2) {
+        const float v = __uint_as_float((uint32_t)Cs[(part * RPS + r2) * CS_LD + col] << 16);
+        sy += v; sq = fmaf(v, v, sq);
+      }
+      float2* red = reinterpret_cast<float2*>(smem + EPI_TAB);
+      red[tid] = make_float2(sy, sq);
+      __syncthreads();
+      if (part == 0 && n0 + col < P.N) {
+#pragma unroll
+        for (int k = 1; k < PARTS; ++k) { sy += red[k * BN + col].x; sq += red[k * BN + col].y; }
+        float* st = P.STATS + (int64_t)tile_m * 2 * P.N + n0 + col;
+        st[0] = sy; st[P.N] = sq;
+      }
+    }
     uint16_t* C = static_cast<uint16_t*>(P.C);
     constexpr int CH = BN / 8;
     for (int idx = tid; idx < BM * CH; idx += THREADS) {
@@ -1042,18 +1066,28 @@ size_t rigl_conv2d_workspace_bytes(const RiglConvDesc* d, int32_t which) {
   return 0;
 }
 
-int rigl_masked_conv2d_fwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* w_ohwi, rigl_bf16* y,
-                           void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+int32_t rigl_conv2d_stats_parts(const RiglConvDesc* d) {
+  if (!d || d->cout <= 0 || (d->cout % 8)) return 0;
+  const int64_t M = (int64_t)d->n * d->ho * d->wo;
+  return (int32_t)((M + 127) / 128);     // one partial per 128-row output tile
+}
+
+int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* w_ohwi, rigl_bf16* y,
+                                 float* stats, size_t stats_floats, void* workspace, size_t workspace_bytes,
+                                 rigl_stream_t stream) {
   using namespace rigl;
   using namespace rigl::k1;
   int rc = check_desc(d, "rigl_masked_conv2d_fwd");
   if (rc) return rc;
   if (!x || !w_ohwi || !y) return fail(RIGL_EINVAL, "rigl_masked_conv2d_fwd: NULL tensor");
   if (d->cout % 8) return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_fwd: cout %% 8 != 0 (use the reference kernel)");
+  if (stats && stats_floats < (size_t)rigl_conv2d_stats_parts(d) * 2 * d->cout)
+    return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_fwd_stats: stats buffer %zu floats < %zu", stats_floats,
+                (size_t)rigl_conv2d_stats_parts(d) * 2 * d->cout);
   hipStream_t st = as_stream(stream);
   ProfScope prof(PROF_CONV_FWD, st);
   IgemmArgs a = {};
-  a.C = y; a.M = d->n * d->ho * d->wo; a.N = d->cout; a.ldc = d->cout;
+  a.C = y; a.M = d->n * d->ho * d->wo; a.N = d->cout; a.ldc = d->cout; a.STATS = stats;
   const size_t need = rigl_conv2d_workspace_bytes(d, 0);
   if (need && (!workspace || workspace_bytes < need))
     return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_fwd: workspace %zu < %zu", workspace_bytes, need);
@@ -1090,6 +1124,11 @@ int rigl_masked_conv2d_fwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl
   launch_igemm<0, false>(a, st);
   RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
   return RIGL_OK;
+}
+
+int rigl_masked_conv2d_fwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* w_ohwi, rigl_bf16* y,
+                           void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+  return rigl_masked_conv2d_fwd_stats(d, x, w_ohwi, y, nullptr, 0, workspace, workspace_bytes, stream);
 }
 
 int rigl_masked_conv2d_dgrad_acc(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf16* w_hwio,

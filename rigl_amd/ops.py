@@ -232,8 +232,10 @@ def mfma_dgrad_supported(d):
   return d.cout % 8 == 0 and d.cin % 8 == 0
 
 
-def conv_fwd(d, x, w_ohwi, y=None, force_ref=False):
-  """y[N,Ho,Wo,Cout] (bf16, NHWC memory) = conv(x, w)."""
+def conv_fwd(d, x, w_ohwi, y=None, force_ref=False, stats=False):
+  """y[N,Ho,Wo,Cout] (bf16, NHWC memory) = conv(x, w).  With ``stats`` returns
+  (y, partials): fp32 [parts, 2, Cout] batch-norm partial sums of y left by the
+  conv epilogue (None where the MFMA path does not apply)."""
   _req(x, torch.bfloat16, 'x')
   _req(w_ohwi, torch.bfloat16, 'w_ohwi')
   if y is None:
@@ -244,13 +246,18 @@ def conv_fwd(d, x, w_ohwi, y=None, force_ref=False):
   if force_ref or not mfma_supported(d):
     check(lib.rigl_conv2d_fwd_ref(C.byref(d), _ptr(x), _ptr(w_ohwi), _ptr(y),
                                   _stream()))
-    return y
+    return (y, None) if stats else y
   need = lib.rigl_conv2d_workspace_bytes(C.byref(d), 0)
   ws = workspace(need, x.device) if need else None
-  check(lib.rigl_masked_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w_ohwi), _ptr(y),
-                                   _ptr(ws), ws.numel() if ws is not None else 0,
-                                   _stream()))
-  return y
+  part = None
+  if stats:
+    parts = lib.rigl_conv2d_stats_parts(C.byref(d))
+    part = torch.empty((parts, 2, d.cout), dtype=torch.float32, device=x.device)
+  check(lib.rigl_masked_conv2d_fwd_stats(
+      C.byref(d), _ptr(x), _ptr(w_ohwi), _ptr(y), _ptr(part),
+      part.numel() if part is not None else 0, _ptr(ws),
+      ws.numel() if ws is not None else 0, _stream()))
+  return (y, part) if stats else y
 
 
 def conv_dgrad(d, dy, w_hwio, dx=None, force_ref=False, addend=None):
@@ -334,9 +341,10 @@ def depthwise_wgrad(d, x, dy, dw):
 # fused batch-norm (+ residual) (+ ReLU)
 # ----------------------------------------------------------------------------
 def bn_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu,
-           residual=None):
+           residual=None, partials=None):
   """x [..., C] bf16 contiguous.  Returns (y, saved) with saved = fp32 [4, C]
-  (mean, invstd, scale, shift)."""
+  (mean, invstd, scale, shift).  ``partials`` (fp32 [parts, 2, C], from
+  conv_fwd(stats=True)) replaces the statistics pass over x."""
   _req(x, torch.bfloat16, 'x')
   _req(residual, torch.bfloat16, 'residual', allow_none=True)
   for t, nm in ((gamma, 'gamma'), (beta, 'beta')):
@@ -346,12 +354,20 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu,
   lib = _lib.load()
   y = torch.empty_like(x)
   saved = torch.empty((4, c), dtype=torch.float32, device=x.device)
-  ws = workspace(lib.rigl_bn_workspace_bytes(m, c), x.device)
-  check(lib.rigl_bn_fwd(m, c, _ptr(x), _ptr(residual), _ptr(gamma), _ptr(beta),
-                        _ptr(running_mean), _ptr(running_var), float(momentum),
-                        float(eps), int(bool(relu)), _ptr(y), _ptr(saved[0]),
-                        _ptr(saved[1]), _ptr(saved[2]), _ptr(saved[3]), _ptr(ws),
-                        ws.numel(), _stream()))
+  if partials is not None:
+    _req(partials, torch.float32, 'partials')
+    if partials.dim() != 3 or partials.shape[1] != 2 or partials.shape[2] != c:
+      raise ValueError('partials must be [parts, 2, C]')
+    ws = None
+  else:
+    ws = workspace(lib.rigl_bn_workspace_bytes(m, c), x.device)
+  check(lib.rigl_bn_fwd_stats(
+      m, c, _ptr(x), _ptr(residual), _ptr(gamma), _ptr(beta),
+      _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
+      int(bool(relu)), _ptr(y), _ptr(saved[0]), _ptr(saved[1]), _ptr(saved[2]),
+      _ptr(saved[3]), _ptr(partials),
+      partials.shape[0] if partials is not None else 0, _ptr(ws),
+      ws.numel() if ws is not None else 0, _stream()))
   return y, saved
 
 

@@ -39,13 +39,19 @@ class _MaskedConvFn(torch.autograd.Function):
   """y = conv(x, mask*W) with dense dW written into lv.weights.grad."""
 
   @staticmethod
-  def forward(ctx, x, lv, desc, need_dx):
+  def forward(ctx, x, lv, desc, need_dx, want_stats=False):
     ctx.lv, ctx.desc, ctx.need_dx = lv, desc, need_dx
     ctx.save_for_backward(x)
-    return ops.conv_fwd(desc, x, lv.ohwi)
+    if not want_stats:
+      return ops.conv_fwd(desc, x, lv.ohwi)
+    y, part = ops.conv_fwd(desc, x, lv.ohwi, stats=True)
+    if part is None:
+      part = torch.empty(0, device=x.device)
+    ctx.mark_non_differentiable(part)
+    return y, part
 
   @staticmethod
-  def backward(ctx, dy):
+  def backward(ctx, dy, _dpart=None):
     (x,) = ctx.saved_tensors
     lv, d = ctx.lv, ctx.desc
     dy = dy.contiguous()
@@ -57,7 +63,7 @@ class _MaskedConvFn(torch.autograd.Function):
     dx = None
     if ctx.need_dx:
       dx = ops.conv_dgrad(d, dy, lv.hwio)
-    return dx, None, None, None
+    return dx, None, None, None, None
 
 
 class _MaskedConvForkFn(torch.autograd.Function):
@@ -68,13 +74,19 @@ class _MaskedConvForkFn(torch.autograd.Function):
   separate AddN pass autodiff would emit (rigl_masked_conv2d_dgrad_acc)."""
 
   @staticmethod
-  def forward(ctx, x, lv, desc):
+  def forward(ctx, x, lv, desc, want_stats=False):
     ctx.lv, ctx.desc = lv, desc
     ctx.save_for_backward(x)
-    return ops.conv_fwd(desc, x, lv.ohwi), x.view_as(x)
+    if not want_stats:
+      return ops.conv_fwd(desc, x, lv.ohwi), x.view_as(x)
+    y, part = ops.conv_fwd(desc, x, lv.ohwi, stats=True)
+    if part is None:
+      part = torch.empty(0, device=x.device)
+    ctx.mark_non_differentiable(part)
+    return y, x.view_as(x), part
 
   @staticmethod
-  def backward(ctx, dy, dalias):
+  def backward(ctx, dy, dalias, _dpart=None):
     (x,) = ctx.saved_tensors
     lv, d = ctx.lv, ctx.desc
     dy = dy.contiguous()
@@ -84,7 +96,7 @@ class _MaskedConvForkFn(torch.autograd.Function):
       sync.notify_layer_grad_ready(lv.weights)
     if dalias is not None:
       dalias = dalias.contiguous()
-    return ops.conv_dgrad(d, dy, lv.hwio, addend=dalias), None, None
+    return ops.conv_dgrad(d, dy, lv.hwio, addend=dalias), None, None, None
 
 
 class _Layer:
@@ -146,7 +158,10 @@ class MaskedConv2d(_Layer):
       self._descs[key] = d
     return d
 
-  def __call__(self, x):
+  def __call__(self, x, bn_stats=False):
+    """``bn_stats``: also leave the batch-norm partial sums of the output on the
+    returned tensor (attribute ``bn_partials``) for the BatchNorm that follows,
+    which then skips its statistics pass (rigl_masked_conv2d_fwd_stats)."""
     if x.dim() != 4:
       raise ValueError('Rank not supported {}'.format(x.dim()))
     if x.shape[-1] != self.cin:
@@ -158,18 +173,28 @@ class MaskedConv2d(_Layer):
     need_dx = self.need_input_grad and x.requires_grad
     if not x.requires_grad:
       x = x.detach().requires_grad_(True)  # keep the node so wgrad runs
-    return _MaskedConvFn.apply(x.contiguous(), self.vars, d, need_dx)
+    if not bn_stats:
+      return _MaskedConvFn.apply(x.contiguous(), self.vars, d, need_dx)
+    y, part = _MaskedConvFn.apply(x.contiguous(), self.vars, d, need_dx, True)
+    if part.numel():
+      y.bn_partials = part
+    return y
 
-  def fork(self, x):
+  def fork(self, x, bn_stats=False):
     """Returns (conv(x), x'): use x' for x's other consumer and its gradient
     is accumulated inside this conv's dgrad kernel (see _MaskedConvForkFn)."""
     if x.dim() != 4 or x.shape[-1] != self.cin:
       raise ValueError('expected [N,H,W,%d], got %s' % (self.cin, tuple(x.shape)))
     if not (self.need_input_grad and x.requires_grad):
-      return self(x), x
+      return self(x, bn_stats), x
     self.graph.refresh_shadows()
     n, h, w, _ = x.shape
-    return _MaskedConvForkFn.apply(x.contiguous(), self.vars, self.desc_for(n, h, w))
+    if not bn_stats:
+      return _MaskedConvForkFn.apply(x.contiguous(), self.vars, self.desc_for(n, h, w))
+    y, alias, part = _MaskedConvForkFn.apply(x.contiguous(), self.vars, self.desc_for(n, h, w), True)
+    if part.numel():
+      y.bn_partials = part
+    return y, alias
 
 
 class MaskedDense(_Layer):

@@ -32,12 +32,13 @@ class _FusedBNFn(torch.autograd.Function):
   the conv kernels' dW; autograd only routes dx (and the residual's grad)."""
 
   @staticmethod
-  def forward(ctx, x, residual, bn, relu):
+  def forward(ctx, x, residual, bn, relu, partials=None):
     from rigl_amd import ops  # pylint: disable=import-outside-toplevel
     x = x.contiguous()
     res = residual.contiguous() if residual is not None else None
     y, saved = ops.bn_fwd(x, bn.gamma.data, bn.beta.data, bn.moving_mean,
-                          bn.moving_variance, 1.0 - bn.decay, bn.eps, relu, res)
+                          bn.moving_variance, 1.0 - bn.decay, bn.eps, relu, res,
+                          partials=partials)
     ctx.bn, ctx.relu, ctx.has_res = bn, relu, res is not None
     # the ReLU mask of bn+residual needs y; without a residual it is recomputed from x
     if relu and res is not None:
@@ -57,7 +58,7 @@ class _FusedBNFn(torch.autograd.Function):
     dx, dres = ops.bn_bwd(x, y, dy.contiguous(), bn.gamma.data, saved, ctx.relu,
                           bn.gamma.grad, bn.beta.grad,
                           want_dres=ctx.has_res and ctx.needs_input_grad[1])
-    return dx, dres, None, None
+    return dx, dres, None, None, None
 
 
 class BatchNorm:
@@ -84,9 +85,10 @@ class BatchNorm:
   def __call__(self, x, is_training=True, relu=False, residual=None):
     if (self.fused and is_training and x.is_cuda and self.channels % 8 == 0
         and x.dtype == torch.bfloat16):
+      partials = getattr(x, 'bn_partials', None)   # left by the producing conv's epilogue
       if not x.requires_grad:
         x = x.detach().requires_grad_(True)
-      return _FusedBNFn.apply(x, residual, self, relu)
+      return _FusedBNFn.apply(x, residual, self, relu, partials)
     y = F.batch_norm(nchw_view(x), self.moving_mean, self.moving_variance,
                      bias_tensor(self.gamma), bias_tensor(self.beta),
                      is_training, 1.0 - self.decay, self.eps)

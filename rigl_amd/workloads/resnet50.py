@@ -46,11 +46,11 @@ class _ConvFixedPadding:
       c._descs[key] = d
     return d
 
-  def __call__(self, x):
-    return self.conv(x)
+  def __call__(self, x, bn_stats=True):
+    return self.conv(x, bn_stats)
 
-  def fork(self, x):
-    return self.conv.fork(x)
+  def fork(self, x, bn_stats=True):
+    return self.conv.fork(x, bn_stats)
 
 
 class _Bottleneck:

@@ -72,3 +72,31 @@ def test_fused_bn_is_deterministic():
   y1, s1 = ops.bn_fwd(x, gamma, beta, None, None, 0.1, 1e-5, True)
   y2, s2 = ops.bn_fwd(x, gamma, beta, None, None, 0.1, 1e-5, True)
   assert torch.equal(y1, y2) and torch.equal(s1, s2)
+
+
+@pytest.mark.parametrize('shape', [(4, 14, 14, 64), (16, 28, 28, 128), (128, 20, 20, 24)])
+def test_fused_bn_from_producer_partials(shape):
+  """rigl_bn_fwd_stats with the partial sums a conv epilogue would leave (here
+  built by hand, one partial per 128 rows: 7 / 98 / 400 of them, covering both
+  finalize variants) matches the self-reducing rigl_bn_fwd."""
+  from rigl_amd import ops
+  gen = torch.Generator(device=DEV).manual_seed(sum(shape))
+  c = shape[-1]
+  x = (torch.randn(shape, generator=gen, device=DEV) * 1.3 - 0.2).to(torch.bfloat16)
+  gamma = torch.rand(c, generator=gen, device=DEV) + 0.5
+  beta = torch.randn(c, generator=gen, device=DEV) * 0.2
+  xf = x.float().reshape(-1, c)
+  m = xf.shape[0]
+  parts = (m + 127) // 128
+  pad = torch.zeros(parts * 128 - m, c, device=DEV)
+  xt = torch.cat([xf, pad]).reshape(parts, 128, c)
+  partials = torch.stack([xt.sum(1), (xt * xt).sum(1)], dim=1).contiguous()
+  rm0, rv0 = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+  rm1, rv1 = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+  y0, s0 = ops.bn_fwd(x, gamma, beta, rm0, rv0, 0.1, 1e-5, True)
+  y1, s1 = ops.bn_fwd(x, gamma, beta, rm1, rv1, 0.1, 1e-5, True, partials=partials)
+  assert torch.allclose(s0, s1, rtol=2e-5, atol=1e-6)
+  assert torch.allclose(rm0, rm1, rtol=1e-5, atol=1e-7) and torch.allclose(rv0, rv1, rtol=1e-5, atol=1e-7)
+  # outputs differ at most by one bf16 rounding where the fp32 value sits on a tie
+  assert ((y0.float() - y1.float()).abs() <= 2.0**-7 * y0.float().abs() + 1e-6).all()
+  assert (y0 != y1).float().mean() < 1e-3

@@ -243,13 +243,14 @@ def test_resnet50_every_conv_in_situ_and_loss_vs_cpu_oracle(rn50):
   rec = []
   fwd0, bwd0 = PL._MaskedConvFn.forward, PL._MaskedConvFn.backward
 
-  def fwd(ctx, x, lv, desc, need_dx):
-    y = fwd0(ctx, x, lv, desc, need_dx)
+  def fwd(ctx, x, lv, desc, need_dx, want_stats=False):
+    out = fwd0(ctx, x, lv, desc, need_dx, want_stats)
+    y = out[0] if want_stats else out
     rec.append(dict(lv=lv, d=desc, x=x.detach().clone(), y=y.detach().clone()))
     ctx.rec = rec[-1]
-    return y
+    return out
 
-  def bwd(ctx, dy):
+  def bwd(ctx, dy, _dpart=None):
     out = bwd0(ctx, dy)
     ctx.rec.update(dy=dy.detach().clone(), dx=None if out[0] is None else out[0].detach().clone(),
                    dw=ctx.lv.weights.grad.detach().clone())
@@ -258,13 +259,13 @@ def test_resnet50_every_conv_in_situ_and_loss_vs_cpu_oracle(rn50):
   # the convs that share their input with a shortcut (fused gradient accumulation)
   ffwd0, fbwd0 = PL._MaskedConvForkFn.forward, PL._MaskedConvForkFn.backward
 
-  def ffwd(ctx, x, lv, desc):
-    y, alias = ffwd0(ctx, x, lv, desc)
-    rec.append(dict(lv=lv, d=desc, x=x.detach().clone(), y=y.detach().clone()))
+  def ffwd(ctx, x, lv, desc, want_stats=False):
+    out = ffwd0(ctx, x, lv, desc, want_stats)
+    rec.append(dict(lv=lv, d=desc, x=x.detach().clone(), y=out[0].detach().clone()))
     ctx.rec = rec[-1]
-    return y, alias
+    return out
 
-  def fbwd(ctx, dy, dalias):
+  def fbwd(ctx, dy, dalias, _dpart=None):
     out = fbwd0(ctx, dy, dalias)
     ctx.rec.update(dy=dy.detach().clone(), dx=out[0].detach().clone(), dw=ctx.lv.weights.grad.detach().clone(),
                    dadd=None if dalias is None else dalias.detach().clone())

@@ -226,6 +226,34 @@ def test_conv_dgrad_accumulate_is_dgrad_plus_addend(case):
   assert torch.equal(buf.view(torch.int16), want.view(torch.int16))
 
 
+@pytest.mark.parametrize('case', [CONV_CASES[0], CONV_CASES[1], CONV_CASES[4], CONV_CASES[5], CONV_CASES[8],
+                                  CONV_CASES[12], CONV_CASES[13], CONV_CASES[18],
+                                  (3, 28, 28, 64, 256, 1, 1, 0, 0, 28, 28), (9, 12, 12, 32, 64, 3, 1, 1, 1, 12, 12)])
+def test_conv_fwd_epilogue_bn_statistics(case):
+  """rigl_masked_conv2d_fwd_stats: y unchanged, and the per-tile partial sums
+  add up to the column sums / sums of squares of the bf16 outputs."""
+  from rigl_amd import ops
+  N, H, W, Cin, Cout, k, stride, pt, pl, Ho, Wo = case
+  g = torch.Generator().manual_seed(11 + sum(case))
+  x = torch.randn(N, H, W, Cin, generator=g).to(torch.bfloat16).to(DEV)
+  ohwi = (torch.randn(k * k * Cin * Cout, generator=g) * (2.0 / (k * k * Cin)) ** 0.5).to(torch.bfloat16).to(DEV)
+  d = ops.conv_desc(N, H, W, Cin, Cout, k, k, stride, pt, pl, Ho, Wo)
+  y0 = ops.conv_fwd(d, x, ohwi)
+  y, part = ops.conv_fwd(d, x, ohwi, stats=True)
+  assert torch.equal(y.view(torch.int16), y0.view(torch.int16))
+  M = N * Ho * Wo
+  assert part.shape == ((M + 127) // 128, 2, Cout)
+  yf = y.double().reshape(M, Cout)
+  s = part.double().sum(0)
+  np.testing.assert_allclose(s[0].cpu().numpy(), yf.sum(0).cpu().numpy(), rtol=0, atol=2e-6 * float(yf.abs().sum(0).max()) + 1e-6)
+  np.testing.assert_allclose(s[1].cpu().numpy(), (yf * yf).sum(0).cpu().numpy(), rtol=2e-6, atol=1e-6)
+  # every tile's partial is exactly the fp32 statistics of its own 128 rows (within fp32 summation error)
+  t = min(part.shape[0] - 1, 1)
+  rows = yf[t * 128:(t + 1) * 128]
+  np.testing.assert_allclose(part[t, 0].double().cpu().numpy(), rows.sum(0).cpu().numpy(), rtol=0,
+                             atol=1e-5 * float(rows.abs().sum(0).max()) + 1e-6)
+
+
 def test_conv_asymmetric_b_detects_transposes():
   """A = identity-like activations, asymmetric weights: catches swapped
   rows/cols in the MFMA C/D mapping (guide rule 16)."""
