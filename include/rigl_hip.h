@@ -318,6 +318,18 @@ int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x,
                 float* dbeta, void* workspace, size_t workspace_bytes,
                 rigl_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Glue: max pooling, NHWC bf16 (tf.layers.max_pooling2d(3, 2, 'SAME') after the
+ * stem, rigl/imagenet_resnet/resnet_model.py:637-644).  The descriptor is a
+ * RiglConvDesc with cin == cout (% 8 == 0); padding explicit, windows clipped
+ * to the image.  argmax: 1 byte per output element (r*kw+s of the FIRST
+ * maximum in row-major window order); the backward is a deterministic gather.
+ * ---------------------------------------------------------------------- */
+int rigl_maxpool_fwd(const RiglConvDesc* d, const rigl_bf16* x, rigl_bf16* y,
+                     uint8_t* argmax, rigl_stream_t stream);
+int rigl_maxpool_bwd(const RiglConvDesc* d, const rigl_bf16* dy,
+                     const uint8_t* argmax, rigl_bf16* dx, rigl_stream_t stream);
+
 /* Optional per-kernel timing (HIP events recorded on the launch stream around
  * every K1/K2/K3 launch while enabled).  rigl_prof_collect synchronises the
  * recorded events and returns accumulated milliseconds / launch counts per

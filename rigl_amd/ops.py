@@ -391,6 +391,27 @@ def bn_bwd(x, y, dy, gamma, saved, relu, dgamma, dbeta, want_dres=False):
 
 
 # ----------------------------------------------------------------------------
+# max pooling (glue)
+# ----------------------------------------------------------------------------
+def maxpool_fwd(d, x):
+  """Returns (y, argmax) for the pooling geometry ``d`` (conv_desc with
+  cin == cout); argmax is uint8, one byte per output element."""
+  _req(x, torch.bfloat16, 'x')
+  y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16, device=x.device)
+  arg = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.uint8, device=x.device)
+  check(_lib.load().rigl_maxpool_fwd(C.byref(d), _ptr(x), _ptr(y), _ptr(arg), _stream()))
+  return y, arg
+
+
+def maxpool_bwd(d, dy, arg):
+  _req(dy, torch.bfloat16, 'dy')
+  _req(arg, torch.uint8, 'argmax')
+  dx = torch.empty((d.n, d.h, d.w, d.cin), dtype=torch.bfloat16, device=dy.device)
+  check(_lib.load().rigl_maxpool_bwd(C.byref(d), _ptr(dy), _ptr(arg), _ptr(dx), _stream()))
+  return dx
+
+
+# ----------------------------------------------------------------------------
 # profiling
 # ----------------------------------------------------------------------------
 def prof_enable(on=True):

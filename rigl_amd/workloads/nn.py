@@ -147,10 +147,43 @@ class DepthwiseConv2d:
     return _DepthwiseFn.apply(x, self, d)
 
 
+class _MaxPoolFn(torch.autograd.Function):
+  """NHWC bf16 max pooling through rigl_maxpool_fwd / rigl_maxpool_bwd."""
+
+  @staticmethod
+  def forward(ctx, x, desc):
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    y, arg = ops.maxpool_fwd(desc, x.contiguous())
+    ctx.desc = desc
+    ctx.save_for_backward(arg)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    (arg,) = ctx.saved_tensors
+    return ops.maxpool_bwd(ctx.desc, dy.contiguous(), arg), None
+
+
+_POOL_DESCS = {}
+
+
 def max_pool_3x3_s2_same(x):
   """tf.layers.max_pooling2d(pool_size=3, strides=2, padding='SAME')
   (resnet_model.py:637-644): TF pads (0,1) on even inputs, i.e. only at the
   bottom / right -- not torchvision's symmetric pad 1."""
+  if x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[-1] % 8 == 0:
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    n, h, w, c = x.shape
+    key = (n, h, w, c)
+    d = _POOL_DESCS.get(key)
+    if d is None:
+      ho, wo = -(-h // 2), -(-w // 2)
+      ph = max((ho - 1) * 2 + 3 - h, 0)
+      pw = max((wo - 1) * 2 + 3 - w, 0)
+      d = ops.conv_desc(n, h, w, c, c, 3, 3, 2, ph // 2, pw // 2, ho, wo)
+      _POOL_DESCS[key] = d
+    return _MaxPoolFn.apply(x, d)
   # TF SAME on an even size pads only bottom/right with -inf; windows start at
   # 0, 2, 4, ... -- exactly max_pool2d(3, 2, padding=0, ceil_mode=True), with no
   # padded copy of the 205 MB stem activation.
