@@ -48,12 +48,15 @@ class _MaskedConvFn(torch.autograd.Function):
     if part is None:
       part = torch.empty(0, device=x.device)
     ctx.mark_non_differentiable(part)
+    ctx.set_materialize_grads(False)     # no zero-filled "gradient" for the statistics output
     return y, part
 
   @staticmethod
   def backward(ctx, dy, _dpart=None):
     (x,) = ctx.saved_tensors
     lv, d = ctx.lv, ctx.desc
+    if dy is None:                       # output unused: zero gradient
+      dy = torch.zeros((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16, device=x.device)
     dy = dy.contiguous()
     # dense dL/d(mask*W), fp32 HWIO, into this layer's slice of the G arena
     ops.conv_wgrad(d, x, dy, lv.weights.grad.view(-1))
@@ -83,12 +86,15 @@ class _MaskedConvForkFn(torch.autograd.Function):
     if part is None:
       part = torch.empty(0, device=x.device)
     ctx.mark_non_differentiable(part)
+    ctx.set_materialize_grads(False)
     return y, x.view_as(x), part
 
   @staticmethod
   def backward(ctx, dy, dalias, _dpart=None):
     (x,) = ctx.saved_tensors
     lv, d = ctx.lv, ctx.desc
+    if dy is None:
+      dy = torch.zeros((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16, device=x.device)
     dy = dy.contiguous()
     ops.conv_wgrad(d, x, dy, lv.weights.grad.view(-1))
     sync = getattr(lv.weights.graph, 'grad_sync', None)
