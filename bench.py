@@ -129,9 +129,18 @@ def main():
       launches = sum(prof[k][1] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad'))
       n_fwd_bwd = args.steps               # every step (update or not) runs fwd + bwd
       achieved = flops_per_step * n_fwd_bwd / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+      # HBM bytes per K1 launch from the PMC passes (rocprofv3 cannot run inside this process: the two
+      # counters need separate passes) -- tools/pmc_summary.py writes the figure next to the profiles.
+      traffic = None
+      try:
+        with open(os.path.join(ROOT, 'profiles', 'r1', 'k1_traffic.json')) as fh:
+          traffic = float(json.load(fh)['bytes_per_launch'])
+      except (OSError, ValueError, KeyError):
+        pass
       out['roofline'] = {
           'bound': 'mfma', 'achieved': achieved, 'peak': 2500.0, 'unit': 'TFLOP/s',
-          'frac': achieved / 2500.0, 'traffic': None,
+          'frac': achieved / 2500.0, 'traffic': traffic,
+          'traffic_unit': 'HBM bytes per K1 launch (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes, profiles/r1/pmc_hbm_traffic.csv)',
           'kernel': 'K1 masked conv implicit-GEMM (fwd+dgrad+wgrad), all %d launches of the timed region' % launches,
           'algorithmic_gflop_per_image': flops_per_step / args.batch / 1e9,
           'avg_launch_ms': conv_ms / max(launches, 1),
