@@ -319,6 +319,21 @@ int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x,
                 rigl_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Stateless random tensors with TensorFlow's bit layout:
+ *   out[i] = rnd_i * scale + shift,  rnd = tf.random.stateless_{uniform,normal}
+ *   (shape=[n], seed=[seed0, seed1], float32)  -- Philox-4x32-10 keyed by the
+ *   scrambled seed pair, element i = lane i%4 of counter + i/4, Box-Muller for
+ *   normals.  Replaces stateless_random_normal (drop noise, stddev = scale) and
+ *   stateless_random_uniform (SET grow scores) of
+ *   rigl/sparse_optimizers_base.py:402-418; seed0 = int32(offset +
+ *   hash(name + 'drop'|'grow')), seed1 = int32(global_step).
+ *   dist: 0 uniform [0,1), 1 standard normal.
+ * ---------------------------------------------------------------------- */
+int rigl_stateless_random(float* out, int64_t n, int32_t seed0, int32_t seed1,
+                          int32_t dist, float scale, float shift,
+                          rigl_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Glue: max pooling, NHWC bf16 (tf.layers.max_pooling2d(3, 2, 'SAME') after the
  * stem, rigl/imagenet_resnet/resnet_model.py:637-644).  The descriptor is a
  * RiglConvDesc with cin == cout (% 8 == 0); padding explicit, windows clipped

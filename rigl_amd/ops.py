@@ -391,6 +391,27 @@ def bn_bwd(x, y, dy, gamma, saved, relu, dgamma, dbeta, want_dres=False):
 
 
 # ----------------------------------------------------------------------------
+# stateless random tensors (TensorFlow bit layout)
+# ----------------------------------------------------------------------------
+def stateless_random(n, seed0, seed1, dist, scale=1.0, shift=0.0, device=None,
+                     out=None):
+  """fp32 [n] = tf.random.stateless_{uniform|normal}([n], seed=[seed0, seed1])
+  * scale + shift.  seed0 / seed1 are int32 (Python ints are wrapped)."""
+  def i32(v):
+    v = int(v) & 0xFFFFFFFF
+    return v - (1 << 32) if v >= 1 << 31 else v
+  if dist not in ('uniform', 'normal'):
+    raise ValueError('dist must be "uniform" or "normal"')
+  if out is None:
+    out = torch.empty(int(n), dtype=torch.float32, device=device)
+  _req(out, torch.float32, 'out')
+  check(_lib.load().rigl_stateless_random(_ptr(out), out.numel(), i32(seed0), i32(seed1),
+                                          1 if dist == 'normal' else 0,
+                                          float(scale), float(shift), _stream()))
+  return out
+
+
+# ----------------------------------------------------------------------------
 # max pooling (glue)
 # ----------------------------------------------------------------------------
 def maxpool_fwd(d, x):

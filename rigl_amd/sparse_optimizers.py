@@ -18,13 +18,13 @@ touches a weight runs in the HIP kernels.
 """
 import math
 import re
-import zlib
 
 import numpy as np
 import torch
 
 from rigl_amd import _lib
 from rigl_amd import ops
+from rigl_amd import pyhash
 from rigl_amd import train
 from rigl_amd import variables as V
 
@@ -38,9 +38,9 @@ def extract_number(token):
 
 
 def _stable_hash(text):
-  """Process-independent replacement for the reference's salted
-  ``hash(weights.name + 'drop')`` seed."""
-  return zlib.crc32(text.encode('utf-8')) & 0x7FFFFFFF
+  """The reference's ``hash(weights.name + 'drop')`` seed: the
+  builtin hash under a fixed PYTHONHASHSEED, else its PYTHONHASHSEED=0 value."""
+  return pyhash.name_hash(text)
 
 
 class PruningGetterMixin:
@@ -217,21 +217,34 @@ class SparseSETOptimizerBase(train.Optimizer):
     gen.manual_seed((self._seed(weights, tag) * 1000003 + gs) & 0x7FFFFFFFFFFFFFFF)
     return gen
 
-  def _random_normal(self, shape, stddev, dtype, seed):
-    gen = torch.Generator(device=self.graph.device)
+  def _tf_seed(self, seed):
+    """int32([offset + seed, global_step]) -- the reference adds the offset in
+    _random_normal/_random_uniform (:402-418); ``seed`` already carries it here."""
     gs = int(self._global_step.value) if self._global_step is not None else 0
-    gen.manual_seed((int(seed) * 1000003 + gs) & 0x7FFFFFFFFFFFFFFF)
-    return torch.randn(tuple(shape), generator=gen, device=self.graph.device,
-                       dtype=dtype) * stddev
+    return int(seed), gs
+
+  def _random_normal(self, shape, stddev, dtype, seed):
+    """stateless_random_normal(shape, stddev=stddev, seed=[seed, global_step]) with
+    TensorFlow's bit layout (Philox-4x32-10 + Box-Muller, rigl_stateless_random)."""
+    n = 1
+    for d in shape:
+      n *= int(d)
+    s0, s1 = self._tf_seed(seed)
+    out = ops.stateless_random(n, s0, s1, 'normal', scale=float(stddev), shift=0.0,
+                               device=self.graph.device)
+    return out.view(tuple(shape)).to(dtype)
 
   def _random_uniform(self, shape, minval=0., maxval=1., dtype=torch.float32,
                       seed=0):
-    gen = torch.Generator(device=self.graph.device)
-    gs = int(self._global_step.value) if self._global_step is not None else 0
-    gen.manual_seed((int(seed) * 1000003 + gs) & 0x7FFFFFFFFFFFFFFF)
-    u = torch.rand(tuple(shape), generator=gen, device=self.graph.device,
-                   dtype=dtype)
-    return u * (maxval - minval) + minval
+    n = 1
+    for d in shape:
+      n *= int(d)
+    s0, s1 = self._tf_seed(seed)
+    lo, hi = float(minval), float(maxval)
+    # rnd * (maxval - minval) + minval with the difference taken in fp32, like the TF graph
+    out = ops.stateless_random(n, s0, s1, 'uniform', scale=float(np.float32(hi) - np.float32(lo)), shift=lo,
+                               device=self.graph.device)
+    return out.view(tuple(shape)).to(dtype)
 
   # ---- internals ------------------------------------------------------------------
   def _find_layer(self, mask, weights):
