@@ -46,6 +46,10 @@ enum {
 };
 
 int rigl_version(void);
+/* Host utility: CRC-32C (Castagnoli) of a host buffer, continuing from `crc`
+ * (0 to start) -- the checksum TensorFlow's checkpoint bundles carry
+ * (README.md:34-58 checkpoints; rigl_amd/tf_checkpoint.py).                 */
+uint32_t rigl_crc32c(const void* data, size_t n, uint32_t crc);
 /* Message of the last failing call made by THIS thread ("" if none). */
 const char* rigl_last_error(void);
 

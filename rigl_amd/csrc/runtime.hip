@@ -65,6 +65,34 @@ extern "C" {
 
 int rigl_version(void) { return RIGL_ABI_VERSION; }
 
+// CRC-32C (Castagnoli, reflected 0x82F63B78), slicing-by-8, host only: the
+// checksum of TensorFlow's checkpoint bundles (rigl_amd/tf_checkpoint.py).
+uint32_t rigl_crc32c(const void* data, size_t n, uint32_t crc) {
+  static uint32_t T[8][256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? 0x82F63B78u : 0u);
+      T[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFFu];
+    ready = true;
+  }
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  crc = ~crc;
+  while (n >= 8) {
+    const uint32_t lo = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    const uint32_t a = crc ^ lo;
+    crc = T[7][a & 0xFFu] ^ T[6][(a >> 8) & 0xFFu] ^ T[5][(a >> 16) & 0xFFu] ^ T[4][a >> 24] ^
+          T[3][p[4]] ^ T[2][p[5]] ^ T[1][p[6]] ^ T[0][p[7]];
+    p += 8; n -= 8;
+  }
+  while (n--) crc = (crc >> 8) ^ T[0][(crc ^ *p++) & 0xFFu];
+  return ~crc;
+}
+
 const char* rigl_last_error(void) { return rigl::g_err; }
 
 int rigl_prof_enable(int32_t on) {

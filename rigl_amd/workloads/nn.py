@@ -81,6 +81,8 @@ class BatchNorm:
     self.decay, self.eps = decay, eps
     self.channels = channels
     self.fused = fused
+    self.scope = scope
+    graph.modules[scope] = self          # creation order = TF's batch_normalization_<k> numbering
 
   def __call__(self, x, is_training=True, relu=False, residual=None):
     if (self.fused and is_training and x.is_cuda and self.channels % 8 == 0
