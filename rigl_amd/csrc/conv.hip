@@ -106,8 +106,11 @@ struct IgemmArgs {
   int cls_n, cls_ids[4], cls_interleave;   // non-empty classes and the common tile count they interleave over
 };
 
+// STAGES: 2 = register-staged double buffer; 3 / 4 = LDS-DMA ring of that depth; 22 = LDS-DMA ring of
+// depth 2 (32 KB: with the 128-VGPR cap of k_igemm_w4 that is 4 workgroups per CU, for short reductions).
 template <int TM, int TN, int BK, int MODE /*0 fwd, 1 dgrad*/, bool OUT_F32, bool CLS, int STAGES>
-__global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
+__device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
+  constexpr int NST = (STAGES == 22) ? 2 : STAGES;
   constexpr int BM = 64 * TM, BN = 64 * TN, CPR = BK / 8, RPP = THREADS / CPR;
   constexpr int APASS = (BM + RPP - 1) / RPP, BPASS = (BN + RPP - 1) / RPP;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
   constexpr int EPI = OUT_F32 ? 0 : BM * CS_LD * 2;
   constexpr int EPI_TAB = EPI + (CLS ? BM * 4 : 0);       // + per-row output pixel table
   constexpr int EPI_ALL = EPI_TAB + ((MODE == 0 && !OUT_F32) ? THREADS * 8 : 0);   // + column-statistics scratch
-  constexpr int SMEM = (STAGES * STAGE > EPI_ALL) ? STAGES * STAGE : EPI_ALL;
+  constexpr int SMEM = (NST * STAGE > EPI_ALL) ? NST * STAGE : EPI_ALL;
   static_assert(SMEM <= 65536, "static LDS limit");
   static_assert(STAGES == 2 || (BM % RPP == 0 && BN % RPP == 0), "LDS-DMA needs whole 1-KB wave rows");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
@@ -320,20 +323,20 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
       __syncthreads();
     }
   } else {
-    // STAGES-deep LDS-DMA ring: tiles kt+1 .. kt+STAGES-2 stay in flight while tile kt is
+    // NST-deep LDS-DMA ring: tiles kt+1 .. kt+NST-2 stay in flight while tile kt is
     // multiplied.  Per iteration: counted wait for MY loads of tile kt -> barrier (everyone's
     // landed, and everyone is done reading the stage about to be refilled) -> issue tile
-    // kt+STAGES-1 into the stage tile kt-1 used -> MFMAs on tile kt.  One barrier per K-tile,
+    // kt+NST-1 into the stage tile kt-1 used -> MFMAs on tile kt.  One barrier per K-tile,
     // never vmcnt(0) in steady state.
     constexpr int L = APASS + BPASS;   // DMA instructions per thread per K-tile
-    for (int t = 0; t < STAGES - 1; ++t)
+    for (int t = 0; t < NST - 1; ++t)
       if (t < KT) { RIGL_DMA_ISSUE(r, s, cb, t); RIGL_ADVANCE(); }
     for (int kt = 0; kt < KT; ++kt) {
-      if (kt + STAGES - 1 <= KT) wait_vmcnt<L * (STAGES - 2)>();
+      if (kt + NST - 1 <= KT) wait_vmcnt<L * (NST - 2)>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
-      if (kt + STAGES - 1 < KT) { RIGL_DMA_ISSUE(r, s, cb, (kt + STAGES - 1) % STAGES); RIGL_ADVANCE(); }
-      RIGL_COMPUTE_TILE(kt % STAGES);
+      if (kt + NST - 1 < KT) { RIGL_DMA_ISSUE(r, s, cb, (kt + NST - 1) % NST); RIGL_ADVANCE(); }
+      RIGL_COMPUTE_TILE(kt % NST);
     }
     wait_vmcnt<0>();
     __syncthreads();   // all tiles consumed before the epilogue reuses the LDS
@@ -416,6 +419,17 @@ __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
       }
     }
   }
+}
+
+template <int TM, int TN, int BK, int MODE, bool OUT_F32, bool CLS, int STAGES>
+__global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
+  igemm_body<TM, TN, BK, MODE, OUT_F32, CLS, STAGES>(P);
+}
+// Same body compiled for 4 waves per SIMD (<= 128 VGPRs): with the 2-deep ring's 35 KB of LDS that
+// is 4 workgroups per CU for the latency-bound short reductions.
+template <int TM, int TN, int BK, int MODE, bool OUT_F32, bool CLS, int STAGES>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_igemm_w4(IgemmArgs P) {
+  igemm_body<TM, TN, BK, MODE, OUT_F32, CLS, STAGES>(P);
 }
 
 // ------------------------------------------------------------------ wgrad
@@ -898,8 +912,13 @@ static TinyGeom tiny_geom(const RiglConvDesc* d) {
 
 // ------------------------------------------------------------------ dispatch
 template <int MODE, bool F32, bool CLS>
-static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, int bk, bool dma, hipStream_t st) {
+static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, int bk, bool dma, bool w4, hipStream_t st) {
   dim3 blk(THREADS);
+  if (dma && w4) {
+    if (wide_n) hipLaunchKernelGGL((k_igemm_w4<2, 2, 32, MODE, F32, CLS, 22>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((k_igemm_w4<2, 1, 32, MODE, F32, CLS, 22>), grid, blk, 0, st, a);
+    return;
+  }
   if (dma) {   // LDS-DMA ring, BK = 32: 3 stages = 48 KB of LDS -> 3 workgroups per CU (the 136-VGPR limit too); 4 stages
     // = 64 KB -> 2 per CU measured 4-7 % slower over the ResNet-50 layer set (RIGL_CONV_STAGES=4 to compare)
     static const int stages = [] { const char* e = getenv("RIGL_CONV_STAGES"); return (e && atoi(e) == 4) ? 4 : 3; }();
@@ -940,6 +959,8 @@ static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
   if (bk > bk_cap && bk_cap >= 16) bk = bk_cap;
   static const int shortk = [] { const char* e = getenv("RIGL_CONV_SHORTK"); return e ? atoi(e) : 0; }();
   const bool dma = use_dma && a.Cred >= 32 && a.KH * a.KW * ((a.Cred + 31) / 32) > shortk;
+  static const int w4_kt = [] { const char* e = getenv("RIGL_CONV_W4_KT"); return e ? atoi(e) : 0; }();
+  const bool w4 = dma && a.KH * a.KW * ((a.Cred + 31) / 32) <= w4_kt;   // K-tiles of 32
   if (MODE == 1 && (a.sh > 1 || a.sw > 1) && a.sh <= 2 && a.sw <= 2) {
     // class-major rows: class c = (h % sh) * sw + (w % sw)
     const int n_img = a.M / (a.RH * a.RW);
@@ -960,11 +981,11 @@ static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
       if (tc > 0) { a.cls_ids[a.cls_n++] = c; if (tc < a.cls_interleave) a.cls_interleave = tc; }
     }
     if (a.cls_n == 0) { a.cls_n = 1; a.cls_ids[0] = 0; a.cls_interleave = 0; }
-    launch_igemm_t<MODE, F32, true>(a, dim3((unsigned)(tiles * a.tiles_n)), wide_n, bk, dma, st);
+    launch_igemm_t<MODE, F32, true>(a, dim3((unsigned)(tiles * a.tiles_n)), wide_n, bk, dma, w4, st);
     return;
   }
   const int tiles_m = (a.M + BM - 1) / BM;
-  launch_igemm_t<MODE, F32, false>(a, dim3((unsigned)(tiles_m * a.tiles_n)), wide_n, bk, dma, st);
+  launch_igemm_t<MODE, F32, false>(a, dim3((unsigned)(tiles_m * a.tiles_n)), wide_n, bk, dma, w4, st);
 }
 
 static int check_desc(const RiglConvDesc* d, const char* who) {
