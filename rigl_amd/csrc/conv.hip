@@ -447,6 +447,8 @@ struct WgradArgs {
   int64_t slab_elems;  // KH*KW*Cin*Cout
   uint32_t x_bytes, dy_bytes;
   int x_pix_stride;    // elements between consecutive pixels of X (== Cin except on the tiny-Cin path)
+  int fold;            // > 0 (k_wgrad_tr only): the KH taps are folded into the channel axis, `fold` channels per
+                       // tap -- channel c of the GEMM is tap c / fold, input channel c % fold (KW == 1, Cin = taps*fold)
 };
 
 template <int TM, int TN>
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(THREADS) void k_wgrad_tr(WgradArgs P) {
   const int kt_begin = (int)((int64_t)KT_all * split / P.splits);
   const int kt_end = (int)((int64_t)KT_all * (split + 1) / P.splits);
   const int KT = kt_end - kt_begin;
-  const bool direct = P.KH == 1 && P.KW == 1 && P.sh == 1 && P.sw == 1 && P.ph == 0 && P.pw == 0;
+  const bool direct = !P.fold && P.KH == 1 && P.KW == 1 && P.sh == 1 && P.sw == 1 && P.ph == 0 && P.pw == 0;
   const bool fast_inc = (BK / P.Wo + 1) <= P.Ho;
   const int inc_w = BK % P.Wo, inc_h = BK / P.Wo;
   const int hi0 = r - P.ph, wi0 = s - P.pw;
@@ -645,13 +647,15 @@ __global__ __launch_bounds__(THREADS) void k_wgrad_tr(WgradArgs P) {
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
   // ---- DMA lanes: slot q*256+tid of a stage = (pixel row, 16-B slot) ----------
-  int a_m[APASS], a_ch[APASS], a_n[APASS], a_ho[APASS], a_wo[APASS];
+  int a_m[APASS], a_ch[APASS], a_r[APASS], a_n[APASS], a_ho[APASS], a_wo[APASS];
   bool a_cok[APASS];
 #pragma unroll
   for (int q = 0; q < APASS; ++q) {
     const int slot = q * THREADS + tid, p = slot / CA, pc = slot % CA;
     a_ch[q] = ci0 + ((pc ^ trswz<CA>(p)) << 3);
     a_cok[q] = a_ch[q] < P.Cin;
+    a_r[q] = 0;
+    if (P.fold) { a_r[q] = a_ch[q] / P.fold; a_ch[q] -= a_r[q] * P.fold; }   // folded taps: this lane's own filter row
     a_m[q] = kt_begin * BK + p;
     const int t = a_m[q] / P.Wo;
     a_wo[q] = a_m[q] % P.Wo; a_ho[q] = t % P.Ho; a_n[q] = t / P.Ho;
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(THREADS) void k_wgrad_tr(WgradArgs P) {
       if (direct) {                                                                                   \
         off = a_m[q] * P.x_pix_stride + a_ch[q];                                                      \
       } else {                                                                                        \
-        const int hi = a_ho[q] * P.sh + hi0, wi = a_wo[q] * P.sw + wi0;                               \
+        const int hi = a_ho[q] * P.sh + hi0 + a_r[q], wi = a_wo[q] * P.sw + wi0;                      \
         ok = ok && (unsigned)hi < (unsigned)P.H && (unsigned)wi < (unsigned)P.W;                      \
         off = ((a_n[q] * P.H + hi) * P.W + wi) * P.x_pix_stride + a_ch[q];                            \
       }                                                                                               \
@@ -1050,6 +1054,17 @@ static WgradPlan plan_wgrad(int M, int cin, int cout, int taps) {
   return p;
 }
 
+static bool wgrad_use_tr() {
+  static const bool v = [] { const char* e = getenv("RIGL_WGRAD_TR"); return e ? atoi(e) != 0 : true; }();
+  return v;
+}
+// Tiny-Cin (stem) wgrad: with the tr kernel the KH filter rows are folded into the channel axis
+// (KH*cred = 224 "channels", one tap) so the 128-channel tile is full and dY is read by 2 channel
+// tiles instead of KH = 7 taps; the register-transposing kernel keeps one tap per workgroup.
+static WgradPlan tiny_wgrad_plan(int M, int cred, int cout, int kh) {
+  return wgrad_use_tr() ? plan_wgrad(M, kh * cred, cout, 1) : plan_wgrad(M, cred, cout, kh);
+}
+
 }  // namespace k1
 }  // namespace rigl
 
@@ -1065,7 +1080,7 @@ size_t rigl_conv2d_workspace_bytes(const RiglConvDesc* d, int32_t which) {
     const size_t xp = align_up((size_t)d->n * tg.hp * tg.wp * 4 * 2, 256);
     if (which == 0) return xp + align_up((size_t)d->cout * d->kh * tg.cred * 2, 256);
     if (which == 2) {
-      WgradPlan p = plan_wgrad((int)M, tg.cred, d->cout, d->kh);
+      WgradPlan p = tiny_wgrad_plan((int)M, tg.cred, d->cout, d->kh);
       return xp + align_up((size_t)p.slab * 4, 256) + align_up((size_t)p.splits * p.slab * 4, 256);
     }
     return 0;
@@ -1211,6 +1226,7 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
     a.X = xp; a.Cin = tg.cred; a.x_pix_stride = 4; a.KH = d->kh; a.KW = 1; a.H = tg.hp; a.W = tg.wp;
     a.Ho = d->ho; a.Wo = d->wo; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = a.pw = 0;
     a.x_bytes = (uint32_t)xp_bytes;
+    if (wgrad_use_tr()) { a.fold = tg.cred; a.Cin = d->kh * tg.cred; a.KH = 1; }   // [kh][cred] is one channel axis
     n_out = (int64_t)d->kh * tg.cred * d->cout;
     tiny_tmp = reinterpret_cast<float*>(ws);
     ws += align_up((size_t)n_out * 4, 256);
@@ -1235,7 +1251,7 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   const bool two_pass = p.splits > 1 || small_cin(d) || tiny_cin(d);
   a.OUT = two_pass ? reinterpret_cast<float*>(ws) : dw;
   dim3 grid((unsigned)((int64_t)p.tiles_ci * p.tiles_co * a.KH * a.KW * p.splits)), blk(THREADS);
-  static const bool use_tr = [] { const char* e = getenv("RIGL_WGRAD_TR"); return e ? atoi(e) != 0 : true; }();
+  const bool use_tr = wgrad_use_tr();
   if (use_tr) {
     if (wgrad_stages(p.tm, p.tn) == 3) {
       if (p.tm == 2 && p.tn == 2) hipLaunchKernelGGL((k_wgrad_tr<2, 2, 3>), grid, blk, 0, st, a);
