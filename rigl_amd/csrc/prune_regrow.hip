@@ -180,6 +180,26 @@ __device__ __forceinline__ bool digit_of(uint32_t key, uint32_t prefix, uint32_t
 __device__ __forceinline__ void hist_clear(uint32_t* h) {
   for (int i = threadIdx.x; i < NB; i += BLOCK) h[i] = 0u;
 }
+// Histogram increment with wave-level aggregation of the dominant bins.  RigL's scores are
+// degenerate by construction -- |mask*w| is exactly 0 for the 80-99 % inactive weights and every
+// kept weight's lifted grow score is one sentinel value -- so most lanes of a wave would hit ONE
+// LDS address and the atomics serialise.  Two rounds of "everyone who shares the first active
+// lane's bin adds through that lane" absorb the hot bins; what is left is spread out.  Safe under
+// divergence: ballot / readlane only involve the lanes that reach the call.
+__device__ __forceinline__ void hist_add(uint32_t* h, bool ok, uint32_t bin) {
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    const uint64_t act = __ballot(ok);
+    if (act == 0) return;
+    const int leader = __ffsll((unsigned long long)act) - 1;
+    const uint32_t lb = (uint32_t)__shfl((int)bin, leader);
+    const bool same = ok && bin == lb;
+    const uint64_t m = __ballot(same);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&h[lb], (uint32_t)__popcll(m));
+    ok = ok && !same;
+  }
+  if (ok) atomicAdd(&h[bin], 1u);
+}
 __device__ __forceinline__ void hist_flush(const uint32_t* h, uint32_t* gh) {
   for (int i = threadIdx.x; i < NB; i += BLOCK) {
     uint32_t c = h[i];
@@ -257,57 +277,82 @@ __device__ __forceinline__ void tie_rank_bases(const uint32_t tie_nib[SEGS], uin
 // ------------------------------------------------------------------ kernels
 // Pass A of the drop selection: histogram of the top digit of the drop keys;
 // P == 0 additionally gathers popcount(mask) and min(grow score).
+// The histogram passes run a fixed number of workgroups, each over a CONTIGUOUS range of
+// chunks (chunks are ordered by layer, so a range rarely crosses a layer), and flush their
+// LDS histogram to the layer's global one only when the layer changes: one flush per
+// workgroup instead of one per 4096 elements (the flush is ~100 contended global atomics).
+__device__ __forceinline__ void chunk_range(uint32_t total, uint32_t* c0, uint32_t* c1) {
+  *c0 = (uint32_t)((uint64_t)blockIdx.x * total / gridDim.x);
+  *c1 = (uint32_t)((uint64_t)(blockIdx.x + 1) * total / gridDim.x);
+}
+
 template <int P>
 __global__ __launch_bounds__(BLOCK) void k_drop_hist(const LayerDev* __restrict__ Ls, LayerState* __restrict__ St,
-                                                     int n_layers) {
+                                                     int n_layers, uint32_t total_chunks) {
   __shared__ uint32_t h[NB];
-  const int li = find_layer(Ls, n_layers, blockIdx.x);
-  const LayerDev L = Ls[li];
-  LayerState& S = St[li];
-  const uint32_t cl = blockIdx.x - L.chunk_begin;
-  const SelState sel = S.d;
-  if (P > 0 && sel.mode != 0u) return;
+  uint32_t c0, c1;
+  chunk_range(total_chunks, &c0, &c1);
+  if (c0 >= c1) return;
+  int li = find_layer(Ls, n_layers, c0);
   hist_clear(h);
   __syncthreads();
   uint32_t ones = 0u, gmin = 0xFFFFFFFFu;
+  for (uint32_t c = c0;; ++c) {
+    const bool done = c >= c1;
+    if (done || c >= Ls[li].chunk_begin + Ls[li].n_chunks) {
+      // ---- leave layer li: publish what this workgroup gathered for it
+      LayerState& S0 = St[li];
+      if (P == 0) {
 #pragma unroll
-  for (int j = 0; j < SEGS; ++j) {
-    Pos q = quad_pos(L.n, cl, j);
-    if (q.nvalid == 0) continue;
-    uint32_t nib = L.sdrop ? 0u : load_nibble(L.mask, q);
-    uint32_t key[4];
-    drop_keys(L, q, nib, key);
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      if (v < q.nvalid) {
-        uint32_t bin;
-        if (digit_of<P>(key[v], sel.prefix, &bin)) atomicAdd(&h[bin], 1u);
+        for (int off = 32; off > 0; off >>= 1) {
+          ones += __shfl_xor(ones, off);
+          gmin = min(gmin, __shfl_xor(gmin, off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+          if (ones) atomicAdd(&S0.n_ones, ones);
+          if (Ls[li].fixed_k < 0) atomicMin(&S0.gmin_key, gmin);
+        }
+        ones = 0u; gmin = 0xFFFFFFFFu;
       }
+      __syncthreads();
+      hist_flush(h, S0.hist);
+      if (done) break;
+      __syncthreads();
+      hist_clear(h);
+      __syncthreads();
+      li = find_layer(Ls, n_layers, c);
     }
-    if (P == 0) {
-      uint32_t mnib = L.sdrop ? load_nibble(L.mask, q) : nib;
-      ones += __popc(mnib);
-      if (L.fixed_k < 0) {
-        uint32_t gk[4];
-        grow_scores(L, q, gk);
+    const LayerDev L = Ls[li];
+    const SelState sel = St[li].d;
+    if (P > 0 && sel.mode != 0u) continue;
+    const uint32_t cl = c - L.chunk_begin;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) if (v < q.nvalid) gmin = min(gmin, gk[v]);
+    for (int j = 0; j < SEGS; ++j) {
+      Pos q = quad_pos(L.n, cl, j);
+      if (q.nvalid == 0) continue;
+      uint32_t nib = L.sdrop ? 0u : load_nibble(L.mask, q);
+      uint32_t key[4];
+      drop_keys(L, q, nib, key);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        if (v < q.nvalid) {
+          uint32_t bin = 0u;
+          const bool in = digit_of<P>(key[v], sel.prefix, &bin);
+          hist_add(h, in, bin);
+        }
+      }
+      if (P == 0) {
+        uint32_t mnib = L.sdrop ? load_nibble(L.mask, q) : nib;
+        ones += __popc(mnib);
+        if (L.fixed_k < 0) {
+          uint32_t gk[4];
+          grow_scores(L, q, gk);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) if (v < q.nvalid) gmin = min(gmin, gk[v]);
+        }
       }
     }
   }
-  if (P == 0) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      ones += __shfl_xor(ones, off);
-      gmin = min(gmin, __shfl_xor(gmin, off));
-    }
-    if ((threadIdx.x & 63) == 0) {
-      if (ones) atomicAdd(&S.n_ones, ones);
-      if (L.fixed_k < 0) atomicMin(&S.gmin_key, gmin);
-    }
-  }
-  __syncthreads();
-  hist_flush(h, S.hist);
 }
 
 // Per-layer digit scan: picks the bin holding the k-th largest key.
@@ -489,7 +534,7 @@ __global__ __launch_bounds__(BLOCK) void k_apply1(const LayerDev* __restrict__ L
       for (int v = 0; v < VEC; ++v) {
         if (v < q[j].nvalid) {
           uint32_t k2 = ((in1 >> v) & 1u) ? S.lifted_key : gk[v];
-          atomicAdd(&h[k2 >> 21], 1u);
+          hist_add(h, true, k2 >> 21);
         }
       }
     }
@@ -502,34 +547,49 @@ __global__ __launch_bounds__(BLOCK) void k_apply1(const LayerDev* __restrict__ L
 
 template <int P>
 __global__ __launch_bounds__(BLOCK) void k_grow_hist(const LayerDev* __restrict__ Ls, LayerState* __restrict__ St,
-                                                     int n_layers) {
+                                                     int n_layers, uint32_t total_chunks) {
   __shared__ uint32_t h[NB];
-  const int li = find_layer(Ls, n_layers, blockIdx.x);
-  const LayerDev L = Ls[li];
-  LayerState& S = St[li];
-  const SelState sel = S.g;
-  if (sel.mode != 0u) return;
-  const uint32_t cl = blockIdx.x - L.chunk_begin;
+  uint32_t c0, c1;
+  chunk_range(total_chunks, &c0, &c1);
+  if (c0 >= c1) return;
+  int li = find_layer(Ls, n_layers, c0);
   hist_clear(h);
   __syncthreads();
+  for (uint32_t c = c0;; ++c) {
+    const bool done = c >= c1;
+    if (done || c >= Ls[li].chunk_begin + Ls[li].n_chunks) {
+      __syncthreads();
+      hist_flush(h, St[li].hist);
+      if (done) break;
+      __syncthreads();
+      hist_clear(h);
+      __syncthreads();
+      li = find_layer(Ls, n_layers, c);
+    }
+    const LayerDev L = Ls[li];
+    const LayerState& S = St[li];
+    const SelState sel = S.g;
+    if (sel.mode != 0u) continue;
+    const uint32_t cl = c - L.chunk_begin;
+    const uint32_t lifted = S.lifted_key;
 #pragma unroll
-  for (int j = 0; j < SEGS; ++j) {
-    Pos q = quad_pos(L.n, cl, j);
-    if (q.nvalid == 0) continue;
-    uint32_t m1 = load_nibble(L.mask1, q);
-    uint32_t gk[4];
-    grow_scores(L, q, gk);
+    for (int j = 0; j < SEGS; ++j) {
+      Pos q = quad_pos(L.n, cl, j);
+      if (q.nvalid == 0) continue;
+      uint32_t m1 = load_nibble(L.mask1, q);
+      uint32_t gk[4];
+      grow_scores(L, q, gk);
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      if (v < q.nvalid) {
-        uint32_t k2 = ((m1 >> v) & 1u) ? S.lifted_key : gk[v];
-        uint32_t bin;
-        if (digit_of<P>(k2, sel.prefix, &bin)) atomicAdd(&h[bin], 1u);
+      for (int v = 0; v < VEC; ++v) {
+        if (v < q.nvalid) {
+          uint32_t k2 = ((m1 >> v) & 1u) ? lifted : gk[v];
+          uint32_t bin = 0u;
+          const bool in = digit_of<P>(k2, sel.prefix, &bin);
+          hist_add(h, in, bin);
+        }
       }
     }
   }
-  __syncthreads();
-  hist_flush(h, S.hist);
 }
 
 // mask2 + weight / momentum re-initialisation + new bitmap.
@@ -726,14 +786,16 @@ static int run(const RiglPruneRegrowLayer* layers, int n_layers, const int64_t* 
 
   ProfScope prof(PROF_PRUNE_REGROW, stream);
   const uint32_t C = lo.total_chunks;
+  static const uint32_t hist_wgs = [] { const char* e = getenv("RIGL_K2_HIST_WGS"); return (uint32_t)(e ? atoi(e) : 1024); }();
+  const uint32_t HG = C < hist_wgs ? C : hist_wgs;      // workgroups of the histogram passes
   hipLaunchKernelGGL(k_init_state, dim3(n_layers), dim3(256), 0, stream, dS, n_layers);
   if (C == 0) { RIGL_CHECK_LAUNCH("k_init_state"); return RIGL_OK; }
   // ---- drop selection -------------------------------------------------------
-  hipLaunchKernelGGL(k_drop_hist<0>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers);
+  hipLaunchKernelGGL(k_drop_hist<0>, dim3(HG), dim3(BLOCK), 0, stream, dL, dS, n_layers, C);
   hipLaunchKernelGGL((k_scan<0, 0>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
-  hipLaunchKernelGGL(k_drop_hist<1>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers);
+  hipLaunchKernelGGL(k_drop_hist<1>, dim3(HG), dim3(BLOCK), 0, stream, dL, dS, n_layers, C);
   hipLaunchKernelGGL((k_scan<0, 1>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
-  hipLaunchKernelGGL(k_drop_hist<2>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers);
+  hipLaunchKernelGGL(k_drop_hist<2>, dim3(HG), dim3(BLOCK), 0, stream, dL, dS, n_layers, C);
   hipLaunchKernelGGL((k_scan<0, 2>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
   hipLaunchKernelGGL(k_tiecount<0>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers, tie_cnt);
   hipLaunchKernelGGL(k_tiescan, dim3(n_layers), dim3(BLOCK), 0, stream, dL, tie_cnt, tie_off);
@@ -745,9 +807,9 @@ static int run(const RiglPruneRegrowLayer* layers, int n_layers, const int64_t* 
   hipLaunchKernelGGL(k_apply1<true>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers, tie_cnt, tie_off);
   // ---- grow selection -------------------------------------------------------
   hipLaunchKernelGGL((k_scan<1, 0>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
-  hipLaunchKernelGGL(k_grow_hist<1>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers);
+  hipLaunchKernelGGL(k_grow_hist<1>, dim3(HG), dim3(BLOCK), 0, stream, dL, dS, n_layers, C);
   hipLaunchKernelGGL((k_scan<1, 1>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
-  hipLaunchKernelGGL(k_grow_hist<2>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers);
+  hipLaunchKernelGGL(k_grow_hist<2>, dim3(HG), dim3(BLOCK), 0, stream, dL, dS, n_layers, C);
   hipLaunchKernelGGL((k_scan<1, 2>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
   hipLaunchKernelGGL(k_tiecount<1>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers, tie_cnt);
   hipLaunchKernelGGL(k_tiescan, dim3(n_layers), dim3(BLOCK), 0, stream, dL, tie_cnt, tie_off);
