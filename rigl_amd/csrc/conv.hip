@@ -10,9 +10,12 @@
 // filled outside the image) into an XOR-swizzled LDS tile.  The weight operand
 // is the pre-packed bf16 shadow of mask*W (rigl_pack_weights), so the 1-bit
 // mask costs no bandwidth here.  Workgroup = 256 threads = 4 waves (2x2), each
-// wave owns TMxTN 32x32 MFMA tiles (block tile 64*TM x 64*TN), K-tile BK,
-// double-buffered LDS with register staging (next tile's global loads are in
-// flight while the current tile is multiplied), one barrier per K-tile.
+// wave owns TMxTN 32x32 MFMA tiles (block tile 64*TM x 64*TN), K-tile BK.
+// Staging: a 3-deep LDS-DMA ring (`buffer_load ... lds`, counted vmcnt, one raw
+// barrier per K-tile) for fwd / dgrad / wgrad; wgrad reads its pixel-major tiles
+// through ds_read_b64_tr_b16.  A register-staged double buffer (BK 64/32/16)
+// remains for reductions narrower than 32 channels.  Epilogues optionally leave
+// batch-norm partial statistics (fwd) or add a second gradient (dgrad).
 #include <stdlib.h>
 
 #include "common.hpp"
