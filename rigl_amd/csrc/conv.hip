@@ -281,6 +281,67 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
           okb ? (int)((uint32_t)off * 2u) : (int)OOB, 0, 0, 0);                                       \
     }                                                                                                 \
   }
+  // Fast DMA issue: everything about a gathered row that does not change along the K loop is
+  // hoisted -- the element offset of the row's first visited tap and a bitmask "tap t lies inside
+  // the image" -- so a K-tile costs one add, one bit test and one select per load instead of the
+  // bounds / divisibility / multiply chain above (the igemm kernels were issue-bound: 3 waves per
+  // SIMD each ~38 % of their time issuing, profiles/r1/pmc_sq_k1.txt).  Visited taps are
+  // (r0 + i*r_step, s0 + j*s_step); in all supported cases the gathered pixel moves linearly with
+  // (i, j): fwd +(i*r_step, j*s_step); dgrad stride 1 and parity-class dgrad -(i, j).
+  // Used for dgrad only: measured on the ResNet-50 set it takes 9 % off dgrad (strided layers 10-30 %) and
+  // nothing off fwd, whose bounds math had no divisions (and whose short-K stem pays for the longer prologue).
+  constexpr bool FAST = STAGES != 2 && MODE == 1;
+  const bool fast_ok = FAST && n_r * n_s <= 64 && (CLS || (P.sh == 1 && P.sw == 1));
+  uint32_t f_lo[APASS], f_hi[APASS];
+  int f_base[APASS], fb_base[BPASS];
+  if (FAST) {
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+      f_lo[p] = f_hi[p] = 0u;
+      int gh0, gw0;
+      if (MODE == 0) { gh0 = a_c0[p] + r0; gw0 = a_c1[p] + s0; }
+      else if (CLS) { gh0 = (a_c0[p] - r0) / P.sh; gw0 = (a_c1[p] - s0) / P.sw; }   // exact inside a parity class
+      else { gh0 = a_c0[p] - r0; gw0 = a_c1[p] - s0; }
+      f_base[p] = (a_pix[p] + gh0 * P.GW + gw0) * P.a_pix_stride + dchunk * 8;
+      if (fast_ok && a_ok[p]) {
+        int t = 0;
+        for (int i = 0; i < n_r; ++i)
+          for (int j = 0; j < n_s; ++j, ++t) {
+            const int gh = MODE == 0 ? gh0 + i * r_step : gh0 - i, gw = MODE == 0 ? gw0 + j * s_step : gw0 - j;
+            const bool in = (unsigned)gh < (unsigned)P.GH && (unsigned)gw < (unsigned)P.GW;
+            if (in) { if (t < 32) f_lo[p] |= 1u << t; else f_hi[p] |= 1u << (t - 32); }
+          }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p) fb_base[p] = b_off[p] + dchunk * 8;
+  }
+  const int f_dr = (MODE == 0 ? r_step * P.GW : -P.GW) * P.a_pix_stride;   // offset step per visited filter row
+  const int f_ds = (MODE == 0 ? s_step : -1) * P.a_pix_stride;            // ... per visited filter column
+  // (ti_, ri_, si_): index of the visited tap and its (row, column) position among the visited taps
+#define RIGL_DMA_ISSUE_FAST(ti_, ri_, si_, r_, s_, cb_, stage_)                                       \
+  {                                                                                                   \
+    unsigned char* As_ = smem + (stage_) * STAGE;                                                     \
+    unsigned char* Bs_ = As_ + A_BYTES;                                                               \
+    const int sdelta = (ri_) * f_dr + (si_) * f_ds + (cb_) * BK;                                      \
+    const bool c_ok = (cb_) * BK + dchunk * 8 < P.Cred;                                               \
+    _Pragma("unroll") for (int p = 0; p < APASS; ++p) {                                               \
+      const uint32_t bits = (ti_) < 32 ? f_lo[p] >> (ti_) : f_hi[p] >> ((ti_) - 32);                  \
+      const bool ok = (bits & 1u) != 0u && c_ok;                                                      \
+      const int boff = ok ? (int)((uint32_t)(f_base[p] + sdelta) * 2u) : (int)OOB;                    \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                       \
+          rsrcA, (__attribute__((address_space(3))) void*)(As_ + (p * RPP + wave_u * (64 / CPR)) * (BK * 2)), 16, \
+          boff, 0, 0, 0);                                                                             \
+    }                                                                                                 \
+    const int bdelta = ((r_) * P.KW + (s_)) * P.b_tap_stride + (cb_) * BK;                            \
+    _Pragma("unroll") for (int p = 0; p < BPASS; ++p) {                                               \
+      const bool okb = b_ok[p] && c_ok;                                                               \
+      const int boff = okb ? (int)((uint32_t)(fb_base[p] + bdelta) * 2u) : (int)OOB;                  \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                       \
+          rsrcB, (__attribute__((address_space(3))) void*)(Bs_ + (p * RPP + wave_u * (64 / CPR)) * (BK * 2)), 16, \
+          boff, 0, 0, 0);                                                                             \
+    }                                                                                                 \
+  }
 #define RIGL_COMPUTE_TILE(stage_)                                                                     \
   {                                                                                                   \
     const unsigned char* As = smem + (stage_) * STAGE;                                                \
@@ -307,8 +368,9 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // ---- main loop ------------------------------------------------------------
-  int r = r0, s = s0, cb = 0;
-#define RIGL_ADVANCE() { if (++cb == kc_tiles) { cb = 0; s += s_step; if (s >= P.KW) { s = s0; r += r_step; } } }
+  int r = r0, s = s0, cb = 0, ti = 0, ri = 0, si = 0;
+#define RIGL_ADVANCE() { if (++cb == kc_tiles) { cb = 0; ++ti; ++si; s += s_step; if (s >= P.KW) { s = s0; si = 0; r += r_step; ++ri; } } }
+#define RIGL_DMA_ANY(stage_) { if (fast_ok) RIGL_DMA_ISSUE_FAST(ti, ri, si, r, s, cb, stage_) else RIGL_DMA_ISSUE(r, s, cb, stage_) }
   if constexpr (STAGES == 2) {
     // register-staged double buffer: tile kt+1's global loads are in flight during tile kt's MFMAs
     if (KT > 0) {
@@ -333,12 +395,12 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
     // never vmcnt(0) in steady state.
     constexpr int L = APASS + BPASS;   // DMA instructions per thread per K-tile
     for (int t = 0; t < NST - 1; ++t)
-      if (t < KT) { RIGL_DMA_ISSUE(r, s, cb, t); RIGL_ADVANCE(); }
+      if (t < KT) { RIGL_DMA_ANY(t); RIGL_ADVANCE(); }
     for (int kt = 0; kt < KT; ++kt) {
       if (kt + NST - 1 <= KT) wait_vmcnt<L * (NST - 2)>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
-      if (kt + NST - 1 < KT) { RIGL_DMA_ISSUE(r, s, cb, (kt + NST - 1) % NST); RIGL_ADVANCE(); }
+      if (kt + NST - 1 < KT) { RIGL_DMA_ANY((kt + NST - 1) % NST); RIGL_ADVANCE(); }
       RIGL_COMPUTE_TILE(kt % NST);
     }
     wait_vmcnt<0>();
@@ -347,6 +409,8 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
 #undef RIGL_LOAD_TILE
 #undef RIGL_STORE_TILE
 #undef RIGL_DMA_ISSUE
+#undef RIGL_DMA_ISSUE_FAST
+#undef RIGL_DMA_ANY
 #undef RIGL_COMPUTE_TILE
 #undef RIGL_ADVANCE
 
