@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'librigl_hip.so')
+LIB_PATH = os.environ.get('RIGL_HIP_LIB') or os.path.join(_HERE, 'lib', 'librigl_hip.so')   # override: development builds
 
 RIGL_OK = 0
 RIGL_EINVAL = -1

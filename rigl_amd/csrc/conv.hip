@@ -20,6 +20,14 @@
 
 #include "common.hpp"
 
+// Development ablations (never defined in the product build): RIGL_ABLATE=1 drops the MFMAs of the
+// igemm K loop (fragments stay live through one scalar add), =2 drops its DMA loads.
+#if defined(RIGL_ABLATE) && RIGL_ABLATE == 1
+#define RIGL_MFMA_OR_ABLATE(i, j) acc[i][j][0] += (float)af[i][0] + (float)bfr[j][0];
+#else
+#define RIGL_MFMA_OR_ABLATE(i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+#endif
+
 namespace rigl {
 namespace k1 {
 
@@ -355,7 +363,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
         bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<BK>(wn * 32 * TN + j * 32 + (lane & 31), chunk)); \
       _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);     \
+          RIGL_MFMA_OR_ABLATE(i, j)                                                                   \
     }                                                                                                 \
   }
 
@@ -370,7 +378,11 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
   // ---- main loop ------------------------------------------------------------
   int r = r0, s = s0, cb = 0, ti = 0, ri = 0, si = 0;
 #define RIGL_ADVANCE() { if (++cb == kc_tiles) { cb = 0; ++ti; ++si; s += s_step; if (s >= P.KW) { s = s0; si = 0; r += r_step; ++ri; } } }
+#if defined(RIGL_ABLATE) && RIGL_ABLATE == 2
+#define RIGL_DMA_ANY(stage_) { }
+#else
 #define RIGL_DMA_ANY(stage_) { if (fast_ok) RIGL_DMA_ISSUE_FAST(ti, ri, si, r, s, cb, stage_) else RIGL_DMA_ISSUE(r, s, cb, stage_) }
+#endif
   if constexpr (STAGES == 2) {
     // register-staged double buffer: tile kt+1's global loads are in flight during tile kt's MFMAs
     if (KT > 0) {
