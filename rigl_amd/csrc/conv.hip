@@ -25,13 +25,20 @@
 #if defined(RIGL_ABLATE) && RIGL_ABLATE == 1
 #define RIGL_MFMA_OR_ABLATE(i, j) acc[i][j][0] += (float)af[i][0] + (float)bfr[j][0];
 #else
-#define RIGL_MFMA_OR_ABLATE(i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+// Operands swapped (weights as the MFMA "A", activations as "B"): the accumulator tile is the
+// TRANSPOSE, D[n][m] -- a lane then holds 4 consecutive output CHANNELS of one pixel per register
+// quad, i.e. 8 contiguous bytes of the NHWC output row, so the epilogue packs with
+// v_cvt_pk_bf16_f32 and stages through LDS with 8-byte stores (16 per thread instead of 64
+// 2-byte ones).
+#define RIGL_MFMA_OR_ABLATE(i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
 #endif
 
 namespace rigl {
 namespace k1 {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int THREADS = 256;
@@ -427,7 +434,8 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
 #undef RIGL_ADVANCE
 
   // ---- epilogue -------------------------------------------------------------
-  // C/D layout of 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+  // The accumulators hold the transposed tile (operands swapped): D layout of the 32x32 MFMA is
+  // col = lane & 31 -> output row m, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) -> output column n.
   if (OUT_F32) {
     float* C = static_cast<float*>(P.C);
 #pragma unroll
@@ -436,8 +444,8 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int m = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-          const int n = n0 + wn * 32 * TN + j * 32 + (lane & 31);
+          const int m = m0 + wm * 32 * TM + i * 32 + (lane & 31);
+          const int n = n0 + wn * 32 * TN + j * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
           if (m < P.M && n < P.N) C[(int64_t)m * P.ldc + n] = acc[i][j][e];
         }
   } else {
@@ -455,10 +463,14 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-          const int col = wn * 32 * TN + j * 32 + (lane & 31);
-          Cs[row * CS_LD + col] = f2bf(acc[i][j][e]);
+        for (int q = 0; q < 4; ++q) {
+          const int row = wm * 32 * TM + i * 32 + (lane & 31);
+          const int col = wn * 32 * TN + j * 32 + 8 * q + 4 * (lane >> 5);
+          const f32x2 lo = {acc[i][j][4 * q], acc[i][j][4 * q + 1]}, hi = {acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          uint2 pk;
+          pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
+          pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2));
+          *reinterpret_cast<uint2*>(Cs + row * CS_LD + col) = pk;
         }
     __syncthreads();
     if (MODE == 0 && P.STATS) {
