@@ -100,6 +100,24 @@ __device__ __forceinline__ uint32_t dword_of(const uint4& v, int d) {
   return d == 0 ? v.x : (d == 1 ? v.y : (d == 2 ? v.z : v.w));
 }
 
+// Division by a launch-time constant: q = umulhi(n, magic) >> shift, exact for 0 <= n < 2^31
+// (magic = ceil(2^(31+l) / d), l = ceil(log2 d), shift = l - 1; d == 1 is flagged by magic == 0).
+// The per-thread pixel decompositions in the kernel prologues cost ~40 VALU per runtime division.
+struct FastDiv { uint32_t magic, shift; };
+static inline FastDiv make_fastdiv(int d) {
+  FastDiv f = {0u, 0u};
+  if (d <= 1) return f;
+  int l = 0;
+  while ((1ll << l) < (long long)d) ++l;
+  const unsigned long long p = 1ull << (31 + l);
+  f.magic = (uint32_t)((p + (unsigned long long)d - 1) / (unsigned long long)d);
+  f.shift = (uint32_t)(l - 1);
+  return f;
+}
+__device__ __forceinline__ int fdiv(int n, FastDiv f) {
+  return f.magic ? (int)(__umulhi((uint32_t)n, f.magic) >> f.shift) : n;
+}
+
 struct IgemmArgs {
   const uint16_t* A;   // gathered activation tensor (x for fwd, dy for dgrad), NHWC
   const uint16_t* B;   // packed weights
@@ -122,6 +140,7 @@ struct IgemmArgs {
   int cls_tile_begin[5];       // tile_m prefix per class (sh*sw <= 4 classes)
   int cls_cnt[4], cls_hc[4], cls_wc[4];
   int cls_n, cls_ids[4], cls_interleave;   // non-empty classes and the common tile count they interleave over
+  FastDiv fd_rw, fd_rh, fd_cwc[4], fd_chc[4];
 };
 
 // STAGES: 2 = register-staged double buffer; 3 / 4 = LDS-DMA ring of that depth; 22 = LDS-DMA ring of
@@ -148,6 +167,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
   const int n0 = (int)(tile % (uint32_t)P.tiles_n) * BN;
   int m0 = tile_m * BM;
   int c_ph = 0, c_pw = 0, c_cnt = P.M, c_hc = 1, c_wc = 1;
+  FastDiv c_fwc = {0u, 0u}, c_fhc = {0u, 0u};
   if (CLS) {
     // Classes differ in work (3x3/2: 4, 2, 2, 1 taps; 1x1/2: 1, 0, 0, 0), and the
     // XCD remap hands each XCD a contiguous range of tile_m -- so interleave the
@@ -171,6 +191,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
     m0 = local * BM;                                     // index inside the class
     c_ph = c / P.sw; c_pw = c % P.sw;
     c_cnt = P.cls_cnt[c]; c_hc = P.cls_hc[c]; c_wc = P.cls_wc[c];
+    c_fwc = P.fd_cwc[c]; c_fhc = P.fd_chc[c];
   }
   const int lrow = tid / CPR, lchunk = tid % CPR;
 
@@ -184,10 +205,12 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
     const int mm = a_ok[p] ? m : 0;
     int rw, rh, n;
     if (CLS) {
-      const int w2 = mm % c_wc, t = mm / c_wc;
-      rw = w2 * P.sw + c_pw; rh = (t % c_hc) * P.sh + c_ph; n = t / c_hc;
+      const int t = fdiv(mm, c_fwc), w2 = mm - t * c_wc;
+      n = fdiv(t, c_fhc);
+      rw = w2 * P.sw + c_pw; rh = (t - n * c_hc) * P.sh + c_ph;
     } else {
-      rw = mm % P.RW; const int t = mm / P.RW; rh = t % P.RH; n = t / P.RH;
+      const int t = fdiv(mm, P.fd_rw);
+      rw = mm - t * P.RW; n = fdiv(t, P.fd_rh); rh = t - n * P.RH;
     }
     a_pix[p] = n * P.GH * P.GW;
     a_out[p] = a_ok[p] ? (n * P.RH + rh) * P.RW + rw : -1;
@@ -1040,6 +1063,7 @@ static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, int bk, b
 template <int MODE, bool F32>
 static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
   IgemmArgs a = a0;
+  a.fd_rw = make_fastdiv(a.RW); a.fd_rh = make_fastdiv(a.RH);
   const bool wide_n = a.N > 64;
   const int BM = 128;
   const int BN = wide_n ? 128 : 64;
@@ -1065,6 +1089,7 @@ static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
       int hc = 0, wc = 0;
       if (ph < a.sh && c < a.sh * a.sw) { hc = (a.RH - ph + a.sh - 1) / a.sh; wc = (a.RW - pw + a.sw - 1) / a.sw; }
       a.cls_hc[c] = hc > 0 ? hc : 1; a.cls_wc[c] = wc > 0 ? wc : 1;
+      a.fd_chc[c] = make_fastdiv(a.cls_hc[c]); a.fd_cwc[c] = make_fastdiv(a.cls_wc[c]);
       a.cls_cnt[c] = hc > 0 && wc > 0 ? n_img * hc * wc : 0;
       a.cls_tile_begin[c] = tiles;
       tiles += (a.cls_cnt[c] + BM - 1) / BM;
