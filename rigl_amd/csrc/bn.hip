@@ -27,7 +27,13 @@ __device__ __forceinline__ uint32_t f2bf(float f) {
   u += 0x7FFFu + ((u >> 16) & 1u);
   return u >> 16;
 }
-__device__ __forceinline__ uint32_t pack2(float a, float b) { return f2bf(a) | (f2bf(b) << 16); }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// v_cvt_pk_bf16_f32: hardware round-to-nearest-even pack of two floats
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 __device__ __forceinline__ void unpack8(const uint4& v, float f[8]) {
   f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
   f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
