@@ -288,8 +288,9 @@ int rigl_conv2d_wgrad_ref(const RiglConvDesc* d, const rigl_bf16* x,
  * Statistics are deterministic (fixed-order partial sums).  c % 8 == 0.
  * save_* ([c] fp32 each) carry mean, 1/sqrt(var+eps), gamma*invstd and
  * beta-mean*gamma*invstd to the backward call.  running_* may be NULL.
- * Backward: pass y when relu was applied to (bn + residual) (the mask needs
- * it); with y == NULL the ReLU mask is recomputed from x.  dresidual (nullable)
+ * Backward: the ReLU mask of (bn + residual) comes from relu_bits (1 bit per
+ * element, written by rigl_bn_fwd_stats: 1/16 of the bytes of y) or, failing
+ * that, from y; with both NULL it is recomputed from x (no residual).  dresidual (nullable)
  * receives the relu-masked dy.  dgamma / dbeta are overwritten.
  * ---------------------------------------------------------------------- */
 size_t rigl_bn_workspace_bytes(int64_t m, int32_t c);
@@ -311,10 +312,12 @@ int rigl_bn_fwd_stats(int64_t m, int32_t c, const rigl_bf16* x,
                       float* running_mean, float* running_var, float momentum,
                       float eps, int32_t relu, rigl_bf16* y, float* save_mean,
                       float* save_invstd, float* save_scale, float* save_shift,
-                      const float* stats, int32_t stats_parts, void* workspace,
-                      size_t workspace_bytes, rigl_stream_t stream);
+                      const float* stats, int32_t stats_parts,
+                      uint8_t* relu_bits /* nullable, out: ceil(m*c/8) bytes */,
+                      void* workspace, size_t workspace_bytes, rigl_stream_t stream);
 int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x,
-                const rigl_bf16* y /* nullable */, const rigl_bf16* dy,
+                const rigl_bf16* y /* nullable */,
+                const uint8_t* relu_bits /* nullable */, const rigl_bf16* dy,
                 const float* gamma, const float* save_mean,
                 const float* save_invstd, const float* save_scale,
                 const float* save_shift, int32_t relu, rigl_bf16* dx,

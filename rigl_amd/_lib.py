@@ -99,8 +99,8 @@ SIGNATURES = {
     'rigl_depthwise_conv2d_wgrad': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _SZ, _P]),
     'rigl_bn_workspace_bytes': (_SZ, [_I64, _I32]),
     'rigl_bn_fwd': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P, _P, _SZ, _P]),
-    'rigl_bn_fwd_stats': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _SZ, _P]),
-    'rigl_bn_bwd': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _SZ, _P]),
+    'rigl_bn_fwd_stats': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _SZ, _P]),
+    'rigl_bn_bwd': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _SZ, _P]),
     'rigl_crc32c': (C.c_uint32, [_P, _SZ, C.c_uint32]),
     'rigl_stateless_random': (C.c_int, [_P, _I64, _I32, _I32, _I32, _F, _F, _P]),
     'rigl_maxpool_fwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),

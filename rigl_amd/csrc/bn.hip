@@ -50,8 +50,11 @@ struct Geom {
 // Reduction over rows of up to two per-channel quantities.
 //   MODE 0 (fwd stats): q0 = sum x, q1 = sum x^2
 //   MODE 1 (bwd)      : q0 = sum dz, q1 = sum dz * xhat,  dz = relu-masked dy
-template <int MODE, bool RELU, bool HAS_Y>
+// MSK: where the ReLU mask comes from -- 0 recomputed from x (scale, shift), 1 the saved output y,
+// 2 the 1-bit-per-element mask the forward left (1/16 of y's bytes).
+template <int MODE, bool RELU, int MSK>
 __global__ __launch_bounds__(THREADS) void k_reduce(Geom G, const uint16_t* __restrict__ x, const uint16_t* __restrict__ y,
+                                                    const uint8_t* __restrict__ mbits,
                                                     const uint16_t* __restrict__ dy, const float* __restrict__ mean,
                                                     const float* __restrict__ invstd, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, float* __restrict__ partial) {
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(THREADS) void k_reduce(Geom G, const uint16_t* __re
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       mu[j] = mean[cgi * 8 + j]; is[j] = invstd[cgi * 8 + j];
-      if (RELU && !HAS_Y) { sc[j] = scale[cgi * 8 + j]; sh[j] = shift[cgi * 8 + j]; }
+      if (RELU && MSK == 0) { sc[j] = scale[cgi * 8 + j]; sh[j] = shift[cgi * 8 + j]; }
     }
   }
   if (c_ok) {
@@ -84,11 +87,13 @@ __global__ __launch_bounds__(THREADS) void k_reduce(Geom G, const uint16_t* __re
       } else {
         float dv[8], yv[8];
         unpack8(*reinterpret_cast<const uint4*>(dy + off), dv);
-        if (RELU && HAS_Y) unpack8(*reinterpret_cast<const uint4*>(y + off), yv);
+        uint32_t mb = 0u;
+        if (RELU && MSK == 1) unpack8(*reinterpret_cast<const uint4*>(y + off), yv);
+        if (RELU && MSK == 2) mb = mbits[r * G.cg + cgi];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           bool on = true;
-          if (RELU) on = HAS_Y ? (yv[j] > 0.f) : (fmaf(xv[j], sc[j], sh[j]) > 0.f);
+          if (RELU) on = MSK == 1 ? (yv[j] > 0.f) : (MSK == 2 ? ((mb >> j) & 1u) != 0u : (fmaf(xv[j], sc[j], sh[j]) > 0.f));
           const float dz = on ? dv[j] : 0.f;
           q0[j] += dz;
           q1[j] = fmaf(dz, (xv[j] - mu[j]) * is[j], q1[j]);
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(THREADS) void k_fwd_finalize(Geom G, const float* _
 template <bool RELU, bool HAS_RES>
 __global__ __launch_bounds__(THREADS) void k_fwd_apply(Geom G, const uint16_t* __restrict__ x, const uint16_t* __restrict__ res,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
-                                                        uint16_t* __restrict__ y) {
+                                                        uint16_t* __restrict__ y, uint8_t* __restrict__ mbits) {
   extern __shared__ __attribute__((aligned(16))) float prm[];   // [2][C]
   for (int i = threadIdx.x; i < G.C; i += THREADS) { prm[i] = scale[i]; prm[G.C + i] = shift[i]; }
   __syncthreads();
@@ -197,6 +202,12 @@ __global__ __launch_bounds__(THREADS) void k_fwd_apply(Geom G, const uint16_t* _
     uint4 out;
     out.x = pack2(o[0], o[1]); out.y = pack2(o[2], o[3]); out.z = pack2(o[4], o[5]); out.w = pack2(o[6], o[7]);
     *reinterpret_cast<uint4*>(y + i * 8) = out;
+    if (RELU && mbits) {          // 1 bit per element: was the activation positive
+      uint32_t mb = 0u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mb |= (o[j] > 0.f ? 1u : 0u) << j;
+      mbits[i] = (uint8_t)mb;
+    }
   }
 }
 
@@ -216,8 +227,9 @@ __global__ __launch_bounds__(THREADS) void k_bwd_finalize(Geom G, const float* _
 }
 
 // dx = a * (dz - b - xhat * c);  dres = dz
-template <bool RELU, bool HAS_Y, bool HAS_DRES>
+template <bool RELU, int MSK, bool HAS_DRES>
 __global__ __launch_bounds__(THREADS) void k_bwd_apply(Geom G, const uint16_t* __restrict__ x, const uint16_t* __restrict__ y,
+                                                        const uint8_t* __restrict__ mbits,
                                                         const uint16_t* __restrict__ dy, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, const float* __restrict__ coef,
@@ -226,7 +238,7 @@ __global__ __launch_bounds__(THREADS) void k_bwd_apply(Geom G, const uint16_t* _
   for (int i = threadIdx.x; i < G.C; i += THREADS) {
     prm[i] = mean[i]; prm[G.C + i] = invstd[i];
     prm[2 * G.C + i] = coef[i]; prm[3 * G.C + i] = coef[G.C + i]; prm[4 * G.C + i] = coef[2 * G.C + i];
-    if (RELU && !HAS_Y) { prm[5 * G.C + i] = scale[i]; prm[6 * G.C + i] = shift[i]; }
+    if (RELU && MSK == 0) { prm[5 * G.C + i] = scale[i]; prm[6 * G.C + i] = shift[i]; }
   }
   __syncthreads();
   const int64_t total = G.M * G.cg;
@@ -236,12 +248,15 @@ __global__ __launch_bounds__(THREADS) void k_bwd_apply(Geom G, const uint16_t* _
     float xv[8], dv[8], yv[8];
     unpack8(*reinterpret_cast<const uint4*>(x + i * 8), xv);
     unpack8(*reinterpret_cast<const uint4*>(dy + i * 8), dv);
-    if (RELU && HAS_Y) unpack8(*reinterpret_cast<const uint4*>(y + i * 8), yv);
+    uint32_t mb = 0u;
+    if (RELU && MSK == 1) unpack8(*reinterpret_cast<const uint4*>(y + i * 8), yv);
+    if (RELU && MSK == 2) mb = mbits[i];
     float o[8], z[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       bool on = true;
-      if (RELU) on = HAS_Y ? (yv[j] > 0.f) : (fmaf(xv[j], prm[5 * G.C + c0 + j], prm[6 * G.C + c0 + j]) > 0.f);
+      if (RELU) on = MSK == 1 ? (yv[j] > 0.f) : (MSK == 2 ? ((mb >> j) & 1u) != 0u
+                                                           : (fmaf(xv[j], prm[5 * G.C + c0 + j], prm[6 * G.C + c0 + j]) > 0.f));
       const float dz = on ? dv[j] : 0.f;
       const float xh = (xv[j] - prm[c0 + j]) * prm[G.C + c0 + j];
       o[j] = prm[2 * G.C + c0 + j] * (dz - prm[3 * G.C + c0 + j] - xh * prm[4 * G.C + c0 + j]);
@@ -295,8 +310,8 @@ size_t rigl_bn_workspace_bytes(int64_t m, int32_t c) {
 int rigl_bn_fwd_stats(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* residual, const float* gamma,
                       const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                       int32_t relu, rigl_bf16* y, float* save_mean, float* save_invstd, float* save_scale,
-                      float* save_shift, const float* stats, int32_t stats_parts, void* workspace,
-                      size_t workspace_bytes, rigl_stream_t stream) {
+                      float* save_shift, const float* stats, int32_t stats_parts, uint8_t* relu_bits,
+                      void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
   using namespace rigl;
   using namespace rigl::kbn;
   if (m <= 0 || c <= 0 || !x || !gamma || !beta || !y || !save_mean || !save_invstd || !save_scale || !save_shift)
@@ -312,7 +327,7 @@ int rigl_bn_fwd_stats(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16*
     if (!workspace || workspace_bytes < need) return fail(RIGL_EWORKSPACE, "rigl_bn_fwd: workspace %zu < %zu", workspace_bytes, need);
     float* ws_partial = static_cast<float*>(workspace);
     dim3 rgrid((unsigned)g.parts, (unsigned)((g.cg + g.tpr - 1) / g.tpr));
-    hipLaunchKernelGGL((k_reduce<0, false, false>), rgrid, dim3(THREADS), 0, st, g, x, nullptr, nullptr, nullptr, nullptr,
+    hipLaunchKernelGGL((k_reduce<0, false, 0>), rgrid, dim3(THREADS), 0, st, g, x, nullptr, nullptr, nullptr, nullptr, nullptr,
                        nullptr, nullptr, ws_partial);
     partial = ws_partial;
   } else {
@@ -326,10 +341,10 @@ int rigl_bn_fwd_stats(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16*
                        beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale, save_shift);
   const size_t lds = (size_t)2 * c * 4;
   dim3 agrid(apply_grid(g));
-  if (relu && residual) hipLaunchKernelGGL((k_fwd_apply<true, true>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y);
-  else if (relu) hipLaunchKernelGGL((k_fwd_apply<true, false>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y);
-  else if (residual) hipLaunchKernelGGL((k_fwd_apply<false, true>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y);
-  else hipLaunchKernelGGL((k_fwd_apply<false, false>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y);
+  if (relu && residual) hipLaunchKernelGGL((k_fwd_apply<true, true>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y, relu_bits);
+  else if (relu) hipLaunchKernelGGL((k_fwd_apply<true, false>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y, relu_bits);
+  else if (residual) hipLaunchKernelGGL((k_fwd_apply<false, true>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y, nullptr);
+  else hipLaunchKernelGGL((k_fwd_apply<false, false>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y, nullptr);
   RIGL_CHECK_LAUNCH("rigl_bn_fwd");
   return RIGL_OK;
 }
@@ -339,10 +354,11 @@ int rigl_bn_fwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* resid
                 rigl_bf16* y, float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
                 void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
   return rigl_bn_fwd_stats(m, c, x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, y, save_mean,
-                           save_invstd, save_scale, save_shift, nullptr, 0, workspace, workspace_bytes, stream);
+                           save_invstd, save_scale, save_shift, nullptr, 0, nullptr, workspace, workspace_bytes, stream);
 }
 
-int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* y, const rigl_bf16* dy, const float* gamma,
+int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* y, const uint8_t* relu_bits,
+                const rigl_bf16* dy, const float* gamma,
                 const float* save_mean, const float* save_invstd, const float* save_scale, const float* save_shift,
                 int32_t relu, rigl_bf16* dx, rigl_bf16* dresidual, float* dgamma, float* dbeta, void* workspace,
                 size_t workspace_bytes, rigl_stream_t stream) {
@@ -351,7 +367,8 @@ int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* y, co
   if (m <= 0 || c <= 0 || !x || !dy || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta)
     return fail(RIGL_EINVAL, "rigl_bn_bwd: bad arguments");
   if (c % 8) return fail(RIGL_EUNSUPPORTED, "rigl_bn_bwd: channels %% 8 != 0");
-  if (relu && !y && (!save_scale || !save_shift)) return fail(RIGL_EINVAL, "rigl_bn_bwd: relu needs y or scale/shift");
+  if (relu && !y && !relu_bits && (!save_scale || !save_shift))
+    return fail(RIGL_EINVAL, "rigl_bn_bwd: relu needs y, relu_bits or scale/shift");
   if (7 * (size_t)c * 4 > 65536) return fail(RIGL_EUNSUPPORTED, "rigl_bn_bwd: too many channels for the LDS parameter cache");
   const size_t need = rigl_bn_workspace_bytes(m, c);
   if (!workspace || workspace_bytes < need) return fail(RIGL_EWORKSPACE, "rigl_bn_bwd: workspace %zu < %zu", workspace_bytes, need);
@@ -360,19 +377,23 @@ int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* y, co
   float* partial = static_cast<float*>(workspace);
   float* coef = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)g.parts * 2 * c * 4, 256));
   dim3 rgrid((unsigned)g.parts, (unsigned)((g.cg + g.tpr - 1) / g.tpr));
-  const bool has_y = y != nullptr;
-  if (!relu) hipLaunchKernelGGL((k_reduce<1, false, false>), rgrid, dim3(THREADS), 0, st, g, x, y, dy, save_mean, save_invstd, save_scale, save_shift, partial);
-  else if (has_y) hipLaunchKernelGGL((k_reduce<1, true, true>), rgrid, dim3(THREADS), 0, st, g, x, y, dy, save_mean, save_invstd, save_scale, save_shift, partial);
-  else hipLaunchKernelGGL((k_reduce<1, true, false>), rgrid, dim3(THREADS), 0, st, g, x, y, dy, save_mean, save_invstd, save_scale, save_shift, partial);
+  const int msk = relu_bits ? 2 : (y ? 1 : 0);
+#define RIGL_BWD_REDUCE(R, K) hipLaunchKernelGGL((k_reduce<1, R, K>), rgrid, dim3(THREADS), 0, st, g, x, y, relu_bits, dy, save_mean, save_invstd, save_scale, save_shift, partial)
+  if (!relu) RIGL_BWD_REDUCE(false, 0);
+  else if (msk == 2) RIGL_BWD_REDUCE(true, 2);
+  else if (msk == 1) RIGL_BWD_REDUCE(true, 1);
+  else RIGL_BWD_REDUCE(true, 0);
+#undef RIGL_BWD_REDUCE
   hipLaunchKernelGGL(k_bwd_finalize, dim3((unsigned)((c + 15) / 16)), dim3(THREADS), 0, st, g, partial, gamma,
                      save_invstd, dgamma, dbeta, coef);
   const size_t lds = (size_t)7 * c * 4;
   dim3 agrid(apply_grid(g));
-#define RIGL_BWD_APPLY(R, Y, D) hipLaunchKernelGGL((k_bwd_apply<R, Y, D>), agrid, dim3(THREADS), lds, st, g, x, y, dy, save_mean, save_invstd, save_scale, save_shift, coef, dx, dresidual)
+#define RIGL_BWD_APPLY(R, K, D) hipLaunchKernelGGL((k_bwd_apply<R, K, D>), agrid, dim3(THREADS), lds, st, g, x, y, relu_bits, dy, save_mean, save_invstd, save_scale, save_shift, coef, dx, dresidual)
   const bool dres = dresidual != nullptr;
-  if (!relu) { if (dres) RIGL_BWD_APPLY(false, false, true); else RIGL_BWD_APPLY(false, false, false); }
-  else if (has_y) { if (dres) RIGL_BWD_APPLY(true, true, true); else RIGL_BWD_APPLY(true, true, false); }
-  else { if (dres) RIGL_BWD_APPLY(true, false, true); else RIGL_BWD_APPLY(true, false, false); }
+  if (!relu) { if (dres) RIGL_BWD_APPLY(false, 0, true); else RIGL_BWD_APPLY(false, 0, false); }
+  else if (msk == 2) { if (dres) RIGL_BWD_APPLY(true, 2, true); else RIGL_BWD_APPLY(true, 2, false); }
+  else if (msk == 1) { if (dres) RIGL_BWD_APPLY(true, 1, true); else RIGL_BWD_APPLY(true, 1, false); }
+  else { if (dres) RIGL_BWD_APPLY(true, 0, true); else RIGL_BWD_APPLY(true, 0, false); }
 #undef RIGL_BWD_APPLY
   RIGL_CHECK_LAUNCH("rigl_bn_bwd");
   return RIGL_OK;

@@ -341,10 +341,12 @@ def depthwise_wgrad(d, x, dy, dw):
 # fused batch-norm (+ residual) (+ ReLU)
 # ----------------------------------------------------------------------------
 def bn_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu,
-           residual=None, partials=None):
+           residual=None, partials=None, want_relu_bits=False):
   """x [..., C] bf16 contiguous.  Returns (y, saved) with saved = fp32 [4, C]
   (mean, invstd, scale, shift).  ``partials`` (fp32 [parts, 2, C], from
-  conv_fwd(stats=True)) replaces the statistics pass over x."""
+  conv_fwd(stats=True)) replaces the statistics pass over x.  With
+  ``want_relu_bits`` returns (y, saved, bits): uint8 [numel/8], bit j of byte i =
+  (y[8i+j] > 0), the ReLU mask the backward needs instead of y."""
   _req(x, torch.bfloat16, 'x')
   _req(residual, torch.bfloat16, 'residual', allow_none=True)
   for t, nm in ((gamma, 'gamma'), (beta, 'beta')):
@@ -354,6 +356,8 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu,
   lib = _lib.load()
   y = torch.empty_like(x)
   saved = torch.empty((4, c), dtype=torch.float32, device=x.device)
+  bits = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device) \
+      if (want_relu_bits and relu) else None
   if partials is not None:
     _req(partials, torch.float32, 'partials')
     if partials.dim() != 3 or partials.shape[1] != 2 or partials.shape[2] != c:
@@ -366,13 +370,17 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu,
       _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
       int(bool(relu)), _ptr(y), _ptr(saved[0]), _ptr(saved[1]), _ptr(saved[2]),
       _ptr(saved[3]), _ptr(partials),
-      partials.shape[0] if partials is not None else 0, _ptr(ws),
+      partials.shape[0] if partials is not None else 0, _ptr(bits), _ptr(ws),
       ws.numel() if ws is not None else 0, _stream()))
-  return y, saved
+  return (y, saved, bits) if want_relu_bits else (y, saved)
 
 
-def bn_bwd(x, y, dy, gamma, saved, relu, dgamma, dbeta, want_dres=False):
-  """Returns (dx, dres|None); dgamma / dbeta (fp32 [C]) are overwritten."""
+def bn_bwd(x, y, dy, gamma, saved, relu, dgamma, dbeta, want_dres=False,
+           relu_bits=None):
+  """Returns (dx, dres|None); dgamma / dbeta (fp32 [C]) are overwritten.  The
+  ReLU mask comes from ``relu_bits`` (bn_fwd(want_relu_bits=True)), else ``y``,
+  else it is recomputed from x."""
+  _req(relu_bits, torch.uint8, 'relu_bits', allow_none=True)
   _req(x, torch.bfloat16, 'x')
   _req(dy, torch.bfloat16, 'dy')
   _req(y, torch.bfloat16, 'y', allow_none=True)
@@ -382,7 +390,7 @@ def bn_bwd(x, y, dy, gamma, saved, relu, dgamma, dbeta, want_dres=False):
   dx = torch.empty_like(x)
   dres = torch.empty_like(x) if want_dres else None
   ws = workspace(lib.rigl_bn_workspace_bytes(m, c), x.device)
-  check(lib.rigl_bn_bwd(m, c, _ptr(x), _ptr(y), _ptr(dy), _ptr(gamma),
+  check(lib.rigl_bn_bwd(m, c, _ptr(x), _ptr(y), _ptr(relu_bits), _ptr(dy), _ptr(gamma),
                         _ptr(saved[0]), _ptr(saved[1]), _ptr(saved[2]),
                         _ptr(saved[3]), int(bool(relu)), _ptr(dx), _ptr(dres),
                         _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(),

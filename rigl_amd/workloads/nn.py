@@ -36,14 +36,18 @@ class _FusedBNFn(torch.autograd.Function):
     from rigl_amd import ops  # pylint: disable=import-outside-toplevel
     x = x.contiguous()
     res = residual.contiguous() if residual is not None else None
-    y, saved = ops.bn_fwd(x, bn.gamma.data, bn.beta.data, bn.moving_mean,
-                          bn.moving_variance, 1.0 - bn.decay, bn.eps, relu, res,
-                          partials=partials)
     ctx.bn, ctx.relu, ctx.has_res = bn, relu, res is not None
-    # the ReLU mask of bn+residual needs y; without a residual it is recomputed from x
+    # the ReLU mask of relu(bn + residual) is kept as 1 bit per element (the backward would
+    # otherwise re-read the whole output twice); without a residual it is recomputed from x
     if relu and res is not None:
-      ctx.save_for_backward(x, saved, y)
+      y, saved, bits = ops.bn_fwd(x, bn.gamma.data, bn.beta.data, bn.moving_mean,
+                                  bn.moving_variance, 1.0 - bn.decay, bn.eps, relu, res,
+                                  partials=partials, want_relu_bits=True)
+      ctx.save_for_backward(x, saved, bits)
     else:
+      y, saved = ops.bn_fwd(x, bn.gamma.data, bn.beta.data, bn.moving_mean,
+                            bn.moving_variance, 1.0 - bn.decay, bn.eps, relu, res,
+                            partials=partials)
       ctx.save_for_backward(x, saved)
     return y
 
@@ -52,12 +56,13 @@ class _FusedBNFn(torch.autograd.Function):
     from rigl_amd import ops  # pylint: disable=import-outside-toplevel
     bn = ctx.bn
     if ctx.relu and ctx.has_res:
-      x, saved, y = ctx.saved_tensors
+      x, saved, bits = ctx.saved_tensors
     else:
-      (x, saved), y = ctx.saved_tensors, None
-    dx, dres = ops.bn_bwd(x, y, dy.contiguous(), bn.gamma.data, saved, ctx.relu,
+      (x, saved), bits = ctx.saved_tensors, None
+    dx, dres = ops.bn_bwd(x, None, dy.contiguous(), bn.gamma.data, saved, ctx.relu,
                           bn.gamma.grad, bn.beta.grad,
-                          want_dres=ctx.has_res and ctx.needs_input_grad[1])
+                          want_dres=ctx.has_res and ctx.needs_input_grad[1],
+                          relu_bits=bits)
     return dx, dres, None, None, None
 
 

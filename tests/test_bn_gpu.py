@@ -65,6 +65,33 @@ def test_fused_bn(shape, relu, with_res):
   close(saved[0], x.float().reshape(-1, c).mean(0), 1e-4, 'saved mean')
 
 
+@pytest.mark.parametrize('shape', [(4, 14, 14, 64), (3, 9, 5, 16), (2, 28, 28, 256)])
+@pytest.mark.parametrize('with_res', [True, False])
+def test_fused_bn_relu_bitmask_equals_saved_output(shape, with_res):
+  """The 1-bit ReLU mask the forward can leave (1/16 of y's bytes) gives exactly
+  the backward that reading y gives."""
+  from rigl_amd import ops
+  gen = torch.Generator(device=DEV).manual_seed(3 + sum(shape))
+  c = shape[-1]
+  x = (torch.randn(shape, generator=gen, device=DEV) * 1.7 + 0.3).to(torch.bfloat16)
+  res = torch.randn(shape, generator=gen, device=DEV).to(torch.bfloat16) if with_res else None
+  dy = torch.randn(shape, generator=gen, device=DEV).to(torch.bfloat16)
+  gamma = torch.rand(c, generator=gen, device=DEV) + 0.5
+  beta = torch.randn(c, generator=gen, device=DEV) * 0.2
+  y, saved, bits = ops.bn_fwd(x, gamma, beta, None, None, 0.1, 1e-5, True, res, want_relu_bits=True)
+  y0, saved0 = ops.bn_fwd(x, gamma, beta, None, None, 0.1, 1e-5, True, res)
+  assert torch.equal(y, y0) and torch.equal(saved, saved0)
+  want = (y.reshape(-1, 8) > 0).to(torch.int32)
+  want = (want << torch.arange(8, device=DEV, dtype=torch.int32)).sum(1).to(torch.uint8)
+  assert torch.equal(bits, want)
+  dg0, db0, dg1, db1 = (torch.empty(c, device=DEV) for _ in range(4))
+  dx0, dres0 = ops.bn_bwd(x, y, dy, gamma, saved, True, dg0, db0, want_dres=with_res)
+  dx1, dres1 = ops.bn_bwd(x, None, dy, gamma, saved, True, dg1, db1, want_dres=with_res, relu_bits=bits)
+  assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+  if with_res:
+    assert torch.equal(dres0, dres1)
+
+
 def test_fused_bn_is_deterministic():
   from rigl_amd import ops
   x = torch.randn(8, 28, 28, 128, device=DEV).to(torch.bfloat16)
