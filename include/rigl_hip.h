@@ -249,6 +249,15 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x,
                              const rigl_bf16* dy, float* dw, void* workspace,
                              size_t workspace_bytes, rigl_stream_t stream);
 
+/* dW and (dx != NULL) dX = dgrad (+ addend) of one conv in a single call:
+ * rigl_masked_conv2d_wgrad followed by rigl_masked_conv2d_dgrad_acc on the
+ * same stream.  workspace: rigl_conv2d_workspace_bytes(d, 2).               */
+int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x,
+                           const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                           const rigl_bf16* addend /* nullable */, float* dw,
+                           rigl_bf16* dx /* nullable */, void* workspace,
+                           size_t workspace_bytes, rigl_stream_t stream);
+
 /* K1d: dense depthwise convolution (depth multiplier 1), NHWC bf16, fp32 HWIO
  * weights [kh][kw][c][1] read directly.  Replaces
  * contrib_layers.separable_conv2d(num_outputs=None)

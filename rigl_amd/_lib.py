@@ -88,6 +88,7 @@ SIGNATURES = {
                                                _SZ, _P, _SZ, _P]),
     'rigl_masked_conv2d_dgrad_acc': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P,
                                                _P, _P, _SZ, _P]),
+    'rigl_masked_conv2d_bwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'rigl_masked_conv2d_wgrad': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P,
                                            _SZ, _P]),
     'rigl_conv2d_fwd_ref': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),

@@ -1397,4 +1397,15 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   return RIGL_OK;
 }
 
+// Whole backward of one masked conv in one call: dW (dense) and, when dx is given, dX (+ addend).
+// Same kernels as the two entry points above; one host transition instead of two keeps the launch
+// queue ahead of the 9-us split-K reduce that sits between them.
+int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                           const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
+                           rigl_stream_t stream) {
+  int rc = rigl_masked_conv2d_wgrad(d, x, dy, dw, workspace, workspace_bytes, stream);
+  if (rc || !dx) return rc;
+  return rigl_masked_conv2d_dgrad_acc(d, dy, w_hwio, addend, dx, workspace, workspace_bytes, stream);
+}
+
 }  // extern "C"

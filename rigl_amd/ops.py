@@ -17,7 +17,15 @@ from rigl_amd._lib import (ConvDesc, PackLayer, PruneRegrowLayer,
 _workspaces = {}
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_cur_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def _stream():
+  """hipStream_t of torch's current stream on the current device (the raw-handle
+  query is ~10x cheaper than building a torch.cuda.Stream object per launch)."""
+  if _raw_stream is not None and _cur_device is not None:
+    return C.c_void_p(_raw_stream(_cur_device()))
   return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -247,11 +255,14 @@ def conv_fwd(d, x, w_ohwi, y=None, force_ref=False, stats=False):
     check(lib.rigl_conv2d_fwd_ref(C.byref(d), _ptr(x), _ptr(w_ohwi), _ptr(y),
                                   _stream()))
     return (y, None) if stats else y
-  need = lib.rigl_conv2d_workspace_bytes(C.byref(d), 0)
+  need = getattr(d, '_ws_fwd', None)
+  if need is None:
+    need = d._ws_fwd = lib.rigl_conv2d_workspace_bytes(C.byref(d), 0)
+    d._stats_parts = lib.rigl_conv2d_stats_parts(C.byref(d))
   ws = workspace(need, x.device) if need else None
   part = None
   if stats:
-    parts = lib.rigl_conv2d_stats_parts(C.byref(d))
+    parts = d._stats_parts
     part = torch.empty((parts, 2, d.cout), dtype=torch.float32, device=x.device)
   check(lib.rigl_masked_conv2d_fwd_stats(
       C.byref(d), _ptr(x), _ptr(w_ohwi), _ptr(y), _ptr(part),
@@ -306,6 +317,34 @@ def conv_wgrad(d, x, dy, dw=None, force_ref=False):
                                      ws.numel() if ws is not None else 0,
                                      _stream()))
   return dw
+
+
+def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None):
+  """dW (into ``dw``, dense fp32) and -- when ``need_dx`` -- dX (+ ``addend``) of
+  one conv with a single host transition (rigl_masked_conv2d_bwd).  Returns dX
+  or None."""
+  if not (mfma_supported(d) and (not need_dx or mfma_dgrad_supported(d))):
+    conv_wgrad(d, x, dy, dw)
+    return conv_dgrad(d, dy, w_hwio, addend=addend) if need_dx else None
+  _req(x, torch.bfloat16, 'x')
+  _req(dy, torch.bfloat16, 'dy')
+  _req(dw, torch.float32, 'dw')
+  _req(addend, torch.bfloat16, 'addend', allow_none=True)
+  lib = _lib.load()
+  need = getattr(d, '_ws_wgrad', None)
+  if need is None:
+    need = d._ws_wgrad = lib.rigl_conv2d_workspace_bytes(C.byref(d), 2)
+  ws = workspace(need, x.device) if need else None
+  dx = None
+  if need_dx:
+    _req(w_hwio, torch.bfloat16, 'w_hwio')
+    dx = torch.empty((d.n, d.h, d.w, d.cin), dtype=torch.bfloat16, device=dy.device)
+    if addend is not None and addend.numel() != dx.numel():
+      raise ValueError('addend must have the shape of dx')
+  check(lib.rigl_masked_conv2d_bwd(C.byref(d), _ptr(x), _ptr(dy), _ptr(w_hwio), _ptr(addend),
+                                   _ptr(dw), _ptr(dx), _ptr(ws),
+                                   ws.numel() if ws is not None else 0, _stream()))
+  return dx
 
 
 # ----------------------------------------------------------------------------

@@ -58,14 +58,11 @@ class _MaskedConvFn(torch.autograd.Function):
     if dy is None:                       # output unused: zero gradient
       dy = torch.zeros((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16, device=x.device)
     dy = dy.contiguous()
-    # dense dL/d(mask*W), fp32 HWIO, into this layer's slice of the G arena
-    ops.conv_wgrad(d, x, dy, lv.weights.grad.view(-1))
+    # dense dL/d(mask*W), fp32 HWIO, into this layer's slice of the G arena, and dX -- one call
+    dx = ops.conv_bwd(d, x, dy, lv.hwio, lv.weights.grad.view(-1), need_dx=ctx.need_dx)
     sync = getattr(lv.weights.graph, 'grad_sync', None)
     if sync is not None:
       sync.notify_layer_grad_ready(lv.weights)   # DP: overlap the all-reduce
-    dx = None
-    if ctx.need_dx:
-      dx = ops.conv_dgrad(d, dy, lv.hwio)
     return dx, None, None, None, None
 
 
@@ -96,13 +93,13 @@ class _MaskedConvForkFn(torch.autograd.Function):
     if dy is None:
       dy = torch.zeros((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16, device=x.device)
     dy = dy.contiguous()
-    ops.conv_wgrad(d, x, dy, lv.weights.grad.view(-1))
+    if dalias is not None:
+      dalias = dalias.contiguous()
+    dx = ops.conv_bwd(d, x, dy, lv.hwio, lv.weights.grad.view(-1), need_dx=True, addend=dalias)
     sync = getattr(lv.weights.graph, 'grad_sync', None)
     if sync is not None:
       sync.notify_layer_grad_ready(lv.weights)
-    if dalias is not None:
-      dalias = dalias.contiguous()
-    return ops.conv_dgrad(d, dy, lv.hwio, addend=dalias), None, None, None
+    return dx, None, None, None
 
 
 class _Layer:

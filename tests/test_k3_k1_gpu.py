@@ -254,6 +254,28 @@ def test_conv_fwd_epilogue_bn_statistics(case):
                              atol=1e-5 * float(rows.abs().sum(0).max()) + 1e-6)
 
 
+@pytest.mark.parametrize('case', [CONV_CASES[1], CONV_CASES[4], CONV_CASES[5], CONV_CASES[8], CONV_CASES[15]])
+def test_conv_bwd_single_call_equals_wgrad_then_dgrad(case):
+  """rigl_masked_conv2d_bwd == rigl_masked_conv2d_wgrad + rigl_masked_conv2d_dgrad_acc, bit for bit."""
+  from rigl_amd import ops
+  N, H, W, Cin, Cout, k, stride, pt, pl, Ho, Wo = case
+  g = torch.Generator().manual_seed(23 + sum(case))
+  x = torch.randn(N, H, W, Cin, generator=g).to(torch.bfloat16).to(DEV)
+  dy = torch.randn(N, Ho, Wo, Cout, generator=g).to(torch.bfloat16).to(DEV)
+  hwio = (torch.randn(k * k * Cin * Cout, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+  d = ops.conv_desc(N, H, W, Cin, Cout, k, k, stride, pt, pl, Ho, Wo)
+  dw0 = ops.conv_wgrad(d, x, dy)
+  dw1 = torch.empty_like(dw0)
+  if Cin % 8 == 0:
+    add = torch.randn(N, H, W, Cin, generator=g).to(torch.bfloat16).to(DEV)
+    dx0 = ops.conv_dgrad(d, dy, hwio, addend=add)
+    dx1 = ops.conv_bwd(d, x, dy, hwio, dw1, need_dx=True, addend=add)
+    assert torch.equal(dx0.view(torch.int16), dx1.view(torch.int16))
+  else:
+    assert ops.conv_bwd(d, x, dy, hwio, dw1, need_dx=False) is None
+  assert torch.equal(dw0.view(torch.int32), dw1.view(torch.int32))
+
+
 def test_conv_asymmetric_b_detects_transposes():
   """A = identity-like activations, asymmetric weights: catches swapped
   rows/cols in the MFMA C/D mapping (guide rule 16)."""
