@@ -21,7 +21,7 @@
 #include "common.hpp"
 
 // Development ablations (never defined in the product build): RIGL_ABLATE=1 drops the MFMAs of the
-// igemm K loop (fragments stay live through one scalar add), =2 drops its DMA loads.
+// igemm K loop (fragments stay live through one scalar add), =2 drops its DMA loads, =3 the whole K loop.
 #if defined(RIGL_ABLATE) && RIGL_ABLATE == 1
 #define RIGL_MFMA_OR_ABLATE(i, j) acc[i][j][0] += (float)af[i][0] + (float)bfr[j][0];
 #else
@@ -232,7 +232,11 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
   const int r_step = CLS ? P.sh : 1, s_step = CLS ? P.sw : 1;
   const int n_r = r0 < P.KH ? (P.KH - r0 + r_step - 1) / r_step : 0;
   const int n_s = s0 < P.KW ? (P.KW - s0 + s_step - 1) / s_step : 0;
+#if defined(RIGL_ABLATE) && RIGL_ABLATE == 3
+  const int KT = 0;                       // development ablation: prologue + epilogue only
+#else
   const int KT = n_r * n_s * kc_tiles;
+#endif
   uint4 ra[APASS], rb[BPASS];
   __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.A, P.a_bytes), rsrcB = make_rsrc(P.B, P.b_bytes);
 
