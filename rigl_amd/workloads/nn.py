@@ -212,6 +212,14 @@ def global_avg_pool(x):
 
 def softmax_cross_entropy(logits, labels, label_smoothing=0.0):
   """tf.losses.softmax_cross_entropy(onehot, logits, label_smoothing): targets
-  onehot*(1-eps) + eps/K, mean over the batch (imagenet_train_eval.py:578-584)."""
-  return F.cross_entropy(logits.float(), labels,
-                         label_smoothing=label_smoothing)
+  onehot*(1-eps) + eps/K, mean over the batch (imagenet_train_eval.py:578-584).
+  Written out with log_softmax + gather: F.cross_entropy(label_smoothing=...)
+  synchronises the device on ROCm (measured, tools/sync_probe.py: the host blocks
+  until every queued kernel has finished), which drained the launch queue once
+  per step."""
+  logp = F.log_softmax(logits.float(), dim=-1)
+  nll = -logp.gather(1, labels.reshape(-1, 1)).squeeze(1)
+  if not label_smoothing:
+    return nll.mean()
+  k = logits.shape[-1]
+  return ((1.0 - label_smoothing) * nll - (label_smoothing / k) * logp.sum(dim=1)).mean()
