@@ -523,14 +523,28 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
       }
     }
     uint16_t* C = static_cast<uint16_t*>(P.C);
-    constexpr int CH = BN / 8;
-    for (int idx = tid; idx < BM * CH; idx += THREADS) {
-      const int row = idx / CH, ch = idx % CH;
+    constexpr int CH = BN / 8, ITERS = BM * CH / THREADS;
+    static_assert(BM * CH % THREADS == 0, "whole output chunks per thread");
+    // fully unrolled, addend loads first: all of a thread's chunks are in flight together
+    // instead of one load -> add -> store round trip per chunk
+    uint4 addv[ITERS];
+    if (P.ADD) {
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = it * THREADS + tid, row = idx / CH, ch = idx % CH;
+        const int m = CLS ? rowpix[row] : m0 + row, n = n0 + ch * 8;
+        addv[it] = (m >= 0 && m < P.M && n < P.N) ? *reinterpret_cast<const uint4*>(P.ADD + (int64_t)m * P.ldc + n)
+                                                  : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int idx = it * THREADS + tid, row = idx / CH, ch = idx % CH;
       const int m = CLS ? rowpix[row] : m0 + row, n = n0 + ch * 8;
       if (m >= 0 && m < P.M && n < P.N) {
         uint4 v = *reinterpret_cast<const uint4*>(Cs + row * CS_LD + ch * 8);
         if (P.ADD) {   // fused gradient accumulation: out = bf16(bf16(acc) + addend), as the separate add would give
-          const uint4 q = *reinterpret_cast<const uint4*>(P.ADD + (int64_t)m * P.ldc + n);
+          const uint4 q = addv[it];
           v.x = add_bf16x2(v.x, q.x); v.y = add_bf16x2(v.y, q.y); v.z = add_bf16x2(v.z, q.z); v.w = add_bf16x2(v.w, q.w);
         }
         *reinterpret_cast<uint4*>(C + (int64_t)m * P.ldc + n) = v;
