@@ -76,6 +76,9 @@ class GradSync:
 
   def _launch(self, lo, hi):
     if hi > lo:
+      if self.graph.G.is_cuda:
+        from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+        ops.join_side_stream(self.graph.G.device)   # weight gradients may come from the side stream
       self._handles.append(dist.all_reduce(self.graph.G[lo:hi], group=self.group, async_op=True))
 
   def all_reduce(self, graph=None):

@@ -79,6 +79,7 @@ class GradientDescentOptimizer(Optimizer):
     if loss is not None and self._backward_done_for is not loss:
       g.zero_other_grads()
       loss.backward()
+      ops.join_side_stream(g.device)      # weight gradients may have been produced on the side stream
       self._backward_done_for = loss
       if self._grad_sync is not None:
         self._grad_sync.all_reduce(g)

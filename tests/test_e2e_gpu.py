@@ -234,7 +234,7 @@ def test_resnet50_every_conv_in_situ_and_loss_vs_cpu_oracle(rn50):
   decorrelate to cos 0.6 in the first layers with no kernel involved)."""
   import torch.nn.functional as F
   g, model, opt, images, labels = rn50
-  from rigl_amd import pruning_layers as PL
+  from rigl_amd import ops, pruning_layers as PL
   from oracle.resnet_cpu import ResNet50CPU
   g.refresh_shadows(force=True)
   for v in g.variables.values():
@@ -252,6 +252,7 @@ def test_resnet50_every_conv_in_situ_and_loss_vs_cpu_oracle(rn50):
 
   def bwd(ctx, dy, _dpart=None):
     out = bwd0(ctx, dy)
+    ops.join_side_stream(dy.device)        # RIGL_WGRAD_STREAM=1: dW is produced on the side stream
     ctx.rec.update(dy=dy.detach().clone(), dx=None if out[0] is None else out[0].detach().clone(),
                    dw=ctx.lv.weights.grad.detach().clone())
     return out
@@ -267,6 +268,7 @@ def test_resnet50_every_conv_in_situ_and_loss_vs_cpu_oracle(rn50):
 
   def fbwd(ctx, dy, dalias, _dpart=None):
     out = fbwd0(ctx, dy, dalias)
+    ops.join_side_stream(dy.device)
     ctx.rec.update(dy=dy.detach().clone(), dx=out[0].detach().clone(), dw=ctx.lv.weights.grad.detach().clone(),
                    dadd=None if dalias is None else dalias.detach().clone())
     return out
