@@ -125,8 +125,8 @@ def main():
                    'parallelism': 'dp%d' % world, 'mask_updates_in_timed_region': n_updates},
     }
     if prof is not None:
-      conv_ms = sum(prof[k][0] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad'))
-      launches = sum(prof[k][1] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad'))
+      conv_ms = sum(prof[k][0] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'conv_bwd'))
+      launches = sum(prof[k][1] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'conv_bwd'))
       n_fwd_bwd = args.steps               # every step (update or not) runs fwd + bwd
       achieved = flops_per_step * n_fwd_bwd / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
       # HBM bytes per K1 launch from the PMC passes (rocprofv3 cannot run inside this process: the two
@@ -141,7 +141,7 @@ def main():
           'bound': 'mfma', 'achieved': achieved, 'peak': 2500.0, 'unit': 'TFLOP/s',
           'frac': achieved / 2500.0, 'traffic': traffic,
           'traffic_unit': 'HBM bytes per K1 launch (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes, profiles/r1/pmc_hbm_traffic.csv)',
-          'kernel': 'K1 masked conv implicit-GEMM (fwd+dgrad+wgrad), all %d launches of the timed region' % launches,
+          'kernel': 'K1 masked conv implicit-GEMM (fwd, dgrad, wgrad; conv_bwd = dgrad + wgrad sharing one launch), all %d launches of the timed region' % launches,
           'algorithmic_gflop_per_image': flops_per_step / args.batch / 1e9,
           'avg_launch_ms': conv_ms / max(launches, 1),
           'conv_ms_per_step': conv_ms / n_fwd_bwd,

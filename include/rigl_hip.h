@@ -249,9 +249,12 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x,
                              const rigl_bf16* dy, float* dw, void* workspace,
                              size_t workspace_bytes, rigl_stream_t stream);
 
-/* dW and (dx != NULL) dX = dgrad (+ addend) of one conv in a single call:
- * rigl_masked_conv2d_wgrad followed by rigl_masked_conv2d_dgrad_acc on the
- * same stream.  workspace: rigl_conv2d_workspace_bytes(d, 2).               */
+/* dW and (dx != NULL) dX = dgrad (+ addend) of one conv in a single call, and
+ * for ordinary layers a single launch: the dgrad and the split-K wgrad
+ * workgroups share one grid (they are independent and each alone leaves much
+ * of the chip idle), followed by the split-K reduce.  Results are bit-identical
+ * to rigl_masked_conv2d_wgrad + rigl_masked_conv2d_dgrad_acc.
+ * workspace: rigl_conv2d_workspace_bytes(d, 2).                              */
 int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x,
                            const rigl_bf16* dy, const rigl_bf16* w_hwio,
                            const rigl_bf16* addend /* nullable */, float* dw,
@@ -365,10 +368,11 @@ int rigl_maxpool_bwd(const RiglConvDesc* d, const rigl_bf16* dy,
  * every K1/K2/K3 launch while enabled).  rigl_prof_collect synchronises the
  * recorded events and returns accumulated milliseconds / launch counts per
  * kernel family: 0 conv_fwd, 1 conv_dgrad, 2 conv_wgrad, 3 prune_regrow,
- * 4 sgd_momentum, 5 pack_weights.                                           */
-#define RIGL_PROF_KINDS 6
+ * 4 sgd_momentum, 5 pack_weights, 6 conv_bwd (the fused dgrad + wgrad launch
+ * of rigl_masked_conv2d_bwd, with its split-K reduce).                      */
+#define RIGL_PROF_KINDS 7
 int rigl_prof_enable(int32_t on);
-int rigl_prof_collect(double* ms_per_kind /*[6]*/, int64_t* launches /*[6]*/);
+int rigl_prof_collect(double* ms_per_kind /*[7]*/, int64_t* launches /*[7]*/);
 
 #ifdef __cplusplus
 }

@@ -145,8 +145,21 @@ struct IgemmArgs {
 
 // STAGES: 2 = register-staged double buffer; 3 / 4 = LDS-DMA ring of that depth; 22 = LDS-DMA ring of
 // depth 2 (32 KB: with the 128-VGPR cap of k_igemm_w4 that is 4 workgroups per CU, for short reductions).
+// LDS bytes of one igemm workgroup (the kernels own the array; igemm_body gets a pointer so that
+// a fused launch can run it next to another body in the same allocation).
+template <int TM, int TN, int BK, int MODE, bool OUT_F32, bool CLS, int STAGES>
+constexpr int igemm_smem_bytes() {
+  constexpr int NST = (STAGES == 22) ? 2 : STAGES;
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int STAGE = (BM + BN) * BK * 2;
+  constexpr int EPI = OUT_F32 ? 0 : BM * (BN + 8) * 2;
+  constexpr int EPI_TAB = EPI + (CLS ? BM * 4 : 0);
+  constexpr int EPI_ALL = EPI_TAB + ((MODE == 0 && !OUT_F32) ? THREADS * 8 : 0);
+  return (NST * STAGE > EPI_ALL) ? NST * STAGE : EPI_ALL;
+}
+
 template <int TM, int TN, int BK, int MODE /*0 fwd, 1 dgrad*/, bool OUT_F32, bool CLS, int STAGES>
-__device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
+__device__ __forceinline__ void igemm_body(const IgemmArgs& P, unsigned char* smem, uint32_t bid, uint32_t nblk) {
   constexpr int NST = (STAGES == 22) ? 2 : STAGES;
   constexpr int BM = 64 * TM, BN = 64 * TN, CPR = BK / 8, RPP = THREADS / CPR;
   constexpr int APASS = (BM + RPP - 1) / RPP, BPASS = (BN + RPP - 1) / RPP;
@@ -158,11 +171,11 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
   constexpr int SMEM = (NST * STAGE > EPI_ALL) ? NST * STAGE : EPI_ALL;
   static_assert(SMEM <= 65536, "static LDS limit");
   static_assert(STAGES == 2 || (BM % RPP == 0 && BN % RPP == 0), "LDS-DMA needs whole 1-KB wave rows");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  static_assert(SMEM == igemm_smem_bytes<TM, TN, BK, MODE, OUT_F32, CLS, STAGES>(), "LDS size formula out of sync");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t tile = xcd_remap(bid, nblk);
   const int tile_m = (int)(tile / (uint32_t)P.tiles_n);
   const int n0 = (int)(tile % (uint32_t)P.tiles_n) * BN;
   int m0 = tile_m * BM;
@@ -555,13 +568,15 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P) {
 
 template <int TM, int TN, int BK, int MODE, bool OUT_F32, bool CLS, int STAGES>
 __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
-  igemm_body<TM, TN, BK, MODE, OUT_F32, CLS, STAGES>(P);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[igemm_smem_bytes<TM, TN, BK, MODE, OUT_F32, CLS, STAGES>()];
+  igemm_body<TM, TN, BK, MODE, OUT_F32, CLS, STAGES>(P, smem, blockIdx.x, gridDim.x);
 }
 // Same body compiled for 4 waves per SIMD (<= 128 VGPRs): with the 2-deep ring's 35 KB of LDS that
 // is 4 workgroups per CU for the latency-bound short reductions.
 template <int TM, int TN, int BK, int MODE, bool OUT_F32, bool CLS, int STAGES>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_igemm_w4(IgemmArgs P) {
-  igemm_body<TM, TN, BK, MODE, OUT_F32, CLS, STAGES>(P);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[igemm_smem_bytes<TM, TN, BK, MODE, OUT_F32, CLS, STAGES>()];
+  igemm_body<TM, TN, BK, MODE, OUT_F32, CLS, STAGES>(P, smem, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------ wgrad
@@ -749,18 +764,21 @@ template <int C>
 __device__ __forceinline__ int trswz(int p) { return ((p / (16 / C)) & (C / 4 - 1)) << 2; }
 
 template <int TM, int TN, int STAGES>
-__global__ __launch_bounds__(THREADS) void k_wgrad_tr(WgradArgs P) {
+constexpr int wgrad_tr_smem_bytes() { return STAGES * (64 * TM + 64 * TN) * 32 * 2; }
+
+template <int TM, int TN, int STAGES>
+__device__ __forceinline__ void wgrad_tr_body(const WgradArgs& P, unsigned char* smem, uint32_t bid, uint32_t nblk) {
   constexpr int BK = 32;
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int CA = BM / 8, CB = BN / 8;
   constexpr int A_BYTES = BK * BM * 2, B_BYTES = BK * BN * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int APASS = BK * CA / THREADS, BPASS = BK * CB / THREADS;
   static_assert(STAGES * STAGE <= 65536, "static LDS limit");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * STAGE];
+  static_assert(STAGES * STAGE == wgrad_tr_smem_bytes<TM, TN, STAGES>(), "LDS size formula out of sync");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  uint32_t b = xcd_remap(blockIdx.x, gridDim.x);
+  uint32_t b = xcd_remap(bid, nblk);
   const int tco = b % P.tiles_co; b /= P.tiles_co;
   const int tci = b % P.tiles_ci; b /= P.tiles_ci;
   const int tap = b % (P.KH * P.KW);
@@ -899,6 +917,25 @@ __global__ __launch_bounds__(THREADS) void k_wgrad_tr(WgradArgs P) {
         const int co = co0 + wn * 32 * TN + jj * 32 + (lane & 31);
         if (ci < P.Cin && co < P.Cout) out[(int64_t)ci * P.Cout + co] = acc[i][jj][e];
       }
+}
+
+template <int TM, int TN, int STAGES>
+__global__ __launch_bounds__(THREADS) void k_wgrad_tr(WgradArgs P) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[wgrad_tr_smem_bytes<TM, TN, STAGES>()];
+  wgrad_tr_body<TM, TN, STAGES>(P, smem, blockIdx.x, gridDim.x);
+}
+
+// Whole backward of a conv in ONE launch: the first `nd` workgroups run the dgrad implicit GEMM, the
+// rest the weight-gradient GEMM.  The two are independent (both read dY) and on their own each
+// leaves much of the chip idle (196-784 tiles for 768 workgroup slots), so sharing a launch lets the
+// dispatcher fill the machine with whichever still has tiles -- the overlap a second stream gives,
+// without a second stream.  Same bodies, one LDS allocation (the larger of the two).
+template <int TND, bool CLSD, int TMW, int TNW, int STW>
+__global__ __launch_bounds__(THREADS) void k_bwd_fused(IgemmArgs PD, WgradArgs PW, uint32_t nd) {
+  constexpr int SD = igemm_smem_bytes<2, TND, 32, 1, false, CLSD, 3>(), SW = wgrad_tr_smem_bytes<TMW, TNW, STW>();
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SD > SW ? SD : SW];
+  if (blockIdx.x < nd) igemm_body<2, TND, 32, 1, false, CLSD, 3>(PD, smem, blockIdx.x, nd);
+  else wgrad_tr_body<TMW, TNW, STW>(PW, smem, blockIdx.x - nd, gridDim.x - nd);
 }
 
 // dw[i] = sum_s slab[s][i] in a FIXED order (deterministic => identical masks
@@ -1047,6 +1084,11 @@ static TinyGeom tiny_geom(const RiglConvDesc* d) {
 }
 
 // ------------------------------------------------------------------ dispatch
+static int conv_dma_stages() {
+  static const int stages = [] { const char* e = getenv("RIGL_CONV_STAGES"); return (e && atoi(e) == 4) ? 4 : 3; }();
+  return stages;
+}
+
 template <int MODE, bool F32, bool CLS>
 static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, int bk, bool dma, bool w4, hipStream_t st) {
   dim3 blk(THREADS);
@@ -1057,8 +1099,7 @@ static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, int bk, b
   }
   if (dma) {   // LDS-DMA ring, BK = 32: 3 stages = 48 KB of LDS -> 3 workgroups per CU (the 136-VGPR limit too); 4 stages
     // = 64 KB -> 2 per CU measured 4-7 % slower over the ResNet-50 layer set (RIGL_CONV_STAGES=4 to compare)
-    static const int stages = [] { const char* e = getenv("RIGL_CONV_STAGES"); return (e && atoi(e) == 4) ? 4 : 3; }();
-    if (stages == 3) {
+    if (conv_dma_stages() == 3) {
       if (wide_n) hipLaunchKernelGGL((k_igemm<2, 2, 32, MODE, F32, CLS, 3>), grid, blk, 0, st, a);
       else hipLaunchKernelGGL((k_igemm<2, 1, 32, MODE, F32, CLS, 3>), grid, blk, 0, st, a);
     } else {
@@ -1078,17 +1119,20 @@ static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, int bk, b
   }
 }
 
-template <int MODE, bool F32>
-static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
-  IgemmArgs a = a0;
+struct IgemmPlan { bool wide_n, dma, w4, cls; int bk; unsigned grid; };
+
+// Fills the launch-time parts of `a` (fast divisors, tile counts, parity-class tables) and picks the variant.
+template <int MODE>
+static IgemmPlan plan_igemm(IgemmArgs& a) {
+  IgemmPlan pl;
   a.fd_rw = make_fastdiv(a.RW); a.fd_rh = make_fastdiv(a.RH);
   // 128x64 tiles when the 128x128 grid has fewer tiles than CUs (7x7 layers at batch 128: 196): twice the
   // workgroups, ~5 % faster; at 392 tiles the narrower tile's lower arithmetic intensity already loses.
   static const int narrow_below = [] { const char* e = getenv("RIGL_CONV_NARROW_BELOW"); return e ? atoi(e) : 256; }();
   const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
-  const bool wide_n = a.N > 64 && tiles128 >= narrow_below;
+  pl.wide_n = a.N > 64 && tiles128 >= narrow_below;
   const int BM = 128;
-  const int BN = wide_n ? 128 : 64;
+  const int BN = pl.wide_n ? 128 : 64;
   a.tiles_n = (a.N + BN - 1) / BN;
   int bk = a.Cred >= 64 ? 64 : (a.Cred >= 32 ? 32 : 16);
   // short reductions (<= 4 K-tiles of 64, e.g. 1x1 convs with Cin <= 256) are latency/HBM-bound:
@@ -1098,10 +1142,12 @@ static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
   static const int bk_cap = [] { const char* e = getenv("RIGL_CONV_BK"); return e ? atoi(e) : 64; }();   // tuning knobs
   static const int use_dma = [] { const char* e = getenv("RIGL_CONV_DMA"); return e ? atoi(e) : 1; }();
   if (bk > bk_cap && bk_cap >= 16) bk = bk_cap;
+  pl.bk = bk;
   static const int shortk = [] { const char* e = getenv("RIGL_CONV_SHORTK"); return e ? atoi(e) : 0; }();
-  const bool dma = use_dma && a.Cred >= 32 && a.KH * a.KW * ((a.Cred + 31) / 32) > shortk;
+  pl.dma = use_dma && a.Cred >= 32 && a.KH * a.KW * ((a.Cred + 31) / 32) > shortk;
   static const int w4_kt = [] { const char* e = getenv("RIGL_CONV_W4_KT"); return e ? atoi(e) : 0; }();
-  const bool w4 = dma && a.KH * a.KW * ((a.Cred + 31) / 32) <= w4_kt;   // K-tiles of 32
+  pl.w4 = pl.dma && a.KH * a.KW * ((a.Cred + 31) / 32) <= w4_kt;   // K-tiles of 32
+  pl.cls = false;
   if (MODE == 1 && (a.sh > 1 || a.sw > 1) && a.sh <= 2 && a.sw <= 2) {
     // class-major rows: class c = (h % sh) * sw + (w % sw)
     const int n_img = a.M / (a.RH * a.RW);
@@ -1123,11 +1169,21 @@ static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
       if (tc > 0) { a.cls_ids[a.cls_n++] = c; if (tc < a.cls_interleave) a.cls_interleave = tc; }
     }
     if (a.cls_n == 0) { a.cls_n = 1; a.cls_ids[0] = 0; a.cls_interleave = 0; }
-    launch_igemm_t<MODE, F32, true>(a, dim3((unsigned)(tiles * a.tiles_n)), wide_n, bk, dma, w4, st);
-    return;
+    pl.cls = true;
+    pl.grid = (unsigned)(tiles * a.tiles_n);
+    return pl;
   }
   const int tiles_m = (a.M + BM - 1) / BM;
-  launch_igemm_t<MODE, F32, false>(a, dim3((unsigned)(tiles_m * a.tiles_n)), wide_n, bk, dma, w4, st);
+  pl.grid = (unsigned)(tiles_m * a.tiles_n);
+  return pl;
+}
+
+template <int MODE, bool F32>
+static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
+  IgemmArgs a = a0;
+  const IgemmPlan pl = plan_igemm<MODE>(a);
+  if (pl.cls) launch_igemm_t<MODE, F32, true>(a, dim3(pl.grid), pl.wide_n, pl.bk, pl.dma, pl.w4, st);
+  else launch_igemm_t<MODE, F32, false>(a, dim3(pl.grid), pl.wide_n, pl.bk, pl.dma, pl.w4, st);
 }
 
 static int check_desc(const RiglConvDesc* d, const char* who) {
@@ -1305,6 +1361,19 @@ int rigl_masked_conv2d_fwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl
   return rigl_masked_conv2d_fwd_stats(d, x, w_ohwi, y, nullptr, 0, workspace, workspace_bytes, stream);
 }
 
+static rigl::k1::IgemmArgs dgrad_args(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                                      const rigl_bf16* addend, rigl_bf16* dx) {
+  rigl::k1::IgemmArgs a = {};
+  a.A = dy; a.B = w_hwio; a.C = dx; a.ADD = addend;
+  a.M = d->n * d->h * d->w; a.N = d->cin; a.Cred = d->cout; a.ldc = d->cin;
+  a.KH = d->kh; a.KW = d->kw; a.RH = d->h; a.RW = d->w; a.GH = d->ho; a.GW = d->wo;
+  a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
+  a.b_row_stride = d->cout; a.b_tap_stride = d->cin * d->cout; a.a_pix_stride = d->cout;
+  a.a_bytes = (uint32_t)((size_t)d->n * d->ho * d->wo * d->cout * 2);
+  a.b_bytes = (uint32_t)((size_t)d->kh * d->kw * d->cin * d->cout * 2);
+  return a;
+}
+
 int rigl_masked_conv2d_dgrad_acc(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf16* w_hwio,
                                  const rigl_bf16* addend, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
                                  rigl_stream_t stream) {
@@ -1317,14 +1386,7 @@ int rigl_masked_conv2d_dgrad_acc(const RiglConvDesc* d, const rigl_bf16* dy, con
   if ((d->cin % 8) || (d->cout % 8)) return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_dgrad: cin/cout %% 8 != 0 (use the reference kernel)");
   hipStream_t st = as_stream(stream);
   ProfScope prof(PROF_CONV_DGRAD, st);
-  IgemmArgs a = {};
-  a.A = dy; a.B = w_hwio; a.C = dx; a.ADD = addend;
-  a.M = d->n * d->h * d->w; a.N = d->cin; a.Cred = d->cout; a.ldc = d->cin;
-  a.KH = d->kh; a.KW = d->kw; a.RH = d->h; a.RW = d->w; a.GH = d->ho; a.GW = d->wo;
-  a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
-  a.b_row_stride = d->cout; a.b_tap_stride = d->cin * d->cout; a.a_pix_stride = d->cout;
-  a.a_bytes = (uint32_t)((size_t)d->n * d->ho * d->wo * d->cout * 2);
-  a.b_bytes = (uint32_t)((size_t)d->kh * d->kw * d->cin * d->cout * 2);
+  IgemmArgs a = dgrad_args(d, dy, w_hwio, addend, dx);
   launch_igemm<1, false>(a, st);
   RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
   return RIGL_OK;
@@ -1420,12 +1482,60 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
 }
 
 // Whole backward of one masked conv in one call: dW (dense) and, when dx is given, dX (+ addend).
-// Same kernels as the two entry points above; one host transition instead of two keeps the launch
-// queue ahead of the 9-us split-K reduce that sits between them.
+// Ordinary layers run both GEMMs in ONE launch (k_bwd_fused: dgrad workgroups first, then the split-K
+// weight-gradient ones) followed by the split-K reduce; the tiny-/small-Cin paths (extra repack
+// kernels, no dX for the stem) and non-default tuning knobs fall back to the two separate launches.
 int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
                            const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
                            rigl_stream_t stream) {
-  int rc = rigl_masked_conv2d_wgrad(d, x, dy, dw, workspace, workspace_bytes, stream);
+  using namespace rigl;
+  using namespace rigl::k1;
+  static const bool fuse = [] { const char* e = getenv("RIGL_BWD_FUSED"); return e ? atoi(e) != 0 : true; }();
+  int rc = check_desc(d, "rigl_masked_conv2d_bwd");
+  if (rc) return rc;
+  if (fuse && dx && x && dy && w_hwio && dw && !tiny_cin(d) && !small_cin(d) && (d->cin % 8) == 0 && (d->cout % 8) == 0 &&
+      wgrad_use_tr() && conv_dma_stages() == 3) {
+    IgemmArgs ad = dgrad_args(d, dy, w_hwio, addend, dx);
+    const IgemmPlan pd = plan_igemm<1>(ad);
+    WgradArgs aw = {};
+    aw.DY = dy; aw.M = d->n * d->ho * d->wo; aw.Cout = d->cout;
+    aw.dy_bytes = (uint32_t)((size_t)aw.M * d->cout * 2);
+    aw.X = x; aw.Cin = d->cin; aw.x_pix_stride = d->cin; aw.KH = d->kh; aw.KW = d->kw; aw.H = d->h; aw.W = d->w;
+    aw.Ho = d->ho; aw.Wo = d->wo; aw.sh = d->stride_h; aw.sw = d->stride_w; aw.ph = d->pad_top; aw.pw = d->pad_left;
+    aw.x_bytes = (uint32_t)((size_t)d->n * d->h * d->w * d->cin * 2);
+    const WgradPlan p = plan_wgrad(aw.M, aw.Cin, aw.Cout, aw.KH * aw.KW);
+    const int st_default = (p.tm == 2 && p.tn == 2) ? 3 : 4;
+    if (pd.dma && !pd.w4 && wgrad_stages(p.tm, p.tn) == st_default) {
+      const size_t need = rigl_conv2d_workspace_bytes(d, 2);
+      if (need && (!workspace || workspace_bytes < need))
+        return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
+      hipStream_t st = as_stream(stream);
+      ProfScope prof(PROF_CONV_BWD, st);
+      aw.tiles_ci = p.tiles_ci; aw.tiles_co = p.tiles_co; aw.splits = p.splits; aw.slab_elems = p.slab;
+      const bool two_pass = p.splits > 1;
+      aw.OUT = two_pass ? static_cast<float*>(workspace) : dw;
+      const unsigned nd = pd.grid, nw = (unsigned)((int64_t)p.tiles_ci * p.tiles_co * aw.KH * aw.KW * p.splits);
+      const dim3 grid(nd + nw), blk(THREADS);
+#define RIGL_FUSED(TND, CLSD)                                                                                        \
+      {                                                                                                              \
+        if (p.tm == 2 && p.tn == 2) hipLaunchKernelGGL((k_bwd_fused<TND, CLSD, 2, 2, 3>), grid, blk, 0, st, ad, aw, nd); \
+        else if (p.tm == 2) hipLaunchKernelGGL((k_bwd_fused<TND, CLSD, 2, 1, 4>), grid, blk, 0, st, ad, aw, nd);      \
+        else if (p.tn == 2) hipLaunchKernelGGL((k_bwd_fused<TND, CLSD, 1, 2, 4>), grid, blk, 0, st, ad, aw, nd);      \
+        else hipLaunchKernelGGL((k_bwd_fused<TND, CLSD, 1, 1, 4>), grid, blk, 0, st, ad, aw, nd);                     \
+      }
+      if (pd.wide_n) { if (pd.cls) RIGL_FUSED(2, true) else RIGL_FUSED(2, false) }
+      else { if (pd.cls) RIGL_FUSED(1, true) else RIGL_FUSED(1, false) }
+#undef RIGL_FUSED
+      if (two_pass) {
+        const int64_t n_out = (int64_t)d->kh * d->kw * d->cin * d->cout;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)ceil_div64(n_out, 64)), blk, 0, st,
+                           static_cast<const float*>(workspace), dw, n_out, p.slab, p.splits);
+      }
+      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");
+      return RIGL_OK;
+    }
+  }
+  rc = rigl_masked_conv2d_wgrad(d, x, dy, dw, workspace, workspace_bytes, stream);
   if (rc || !dx) return rc;
   return rigl_masked_conv2d_dgrad_acc(d, dy, w_hwio, addend, dx, workspace, workspace_bytes, stream);
 }
