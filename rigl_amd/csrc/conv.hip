@@ -1505,7 +1505,12 @@ int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl
     aw.x_bytes = (uint32_t)((size_t)d->n * d->h * d->w * d->cin * 2);
     const WgradPlan p = plan_wgrad(aw.M, aw.Cin, aw.Cout, aw.KH * aw.KW);
     const int st_default = (p.tm == 2 && p.tn == 2) ? 3 : 4;
-    if (pd.dma && !pd.w4 && wgrad_stages(p.tm, p.tn) == st_default) {
+    // Launched alone back to back, a large short-reduction (HBM-bound) dgrad -- the 56x56 / 28x28 1x1 "reduce"
+    // convs -- is 9-28 % slower when it shares the launch, the other layers 3-10 % faster; inside the training
+    // step sharing always won (8688 vs 8567 images/s on one box), so the selective rule is off by default.
+    static const bool selective = [] { const char* e = getenv("RIGL_BWD_FUSE_SELECTIVE"); return e ? atoi(e) != 0 : false; }();
+    const bool pays = !selective || !(pd.grid > 1536u && dgrad_ktiles <= 8);
+    if (pays && pd.dma && !pd.w4 && wgrad_stages(p.tm, p.tn) == st_default) {
       const size_t need = rigl_conv2d_workspace_bytes(d, 2);
       if (need && (!workspace || workspace_bytes < need))
         return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);

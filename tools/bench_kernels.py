@@ -80,17 +80,20 @@ def main():
         t_f = timeit(lambda: ops.conv_fwd(d, x, w, y), a.iters)
         t_d = timeit(lambda: ops.conv_dgrad(d, dy, w, dx), a.iters) if Cin % 8 == 0 else 0.0
         t_w = timeit(lambda: ops.conv_wgrad(d, x, dy, dw), a.iters)
-        seen[key] = (t_f, t_d, t_w)
+        # dgrad + wgrad as the training step runs them: one launch (rigl_masked_conv2d_bwd)
+        t_b = timeit(lambda: ops.conv_bwd(d, x, dy, w, dw, need_dx=Cin % 8 == 0), a.iters)
+        seen[key] = (t_f, t_d, t_w, t_b)
         del x, dy, w, y, dx, dw
       except Exception as e:  # pylint: disable=broad-except
-        seen[key] = (float('nan'),) * 3
+        seen[key] = (float('nan'),) * 4
         print('FAILED', name, key, repr(e), flush=True)
-    t_f, t_d, t_w = seen[key]
+    t_f, t_d, t_w, t_b = seen[key]
     tf = lambda t: (2 * macs / (t * 1e-3) / 1e12) if t and t == t else 0.0
-    rep['convs'].append(dict(name=name, shape=key, macs=macs, ms_fwd=t_f, ms_dgrad=t_d, ms_wgrad=t_w,
+    rep['convs'].append(dict(name=name, shape=key, macs=macs, ms_fwd=t_f, ms_dgrad=t_d, ms_wgrad=t_w, ms_bwd=t_b,
                              tflops_fwd=tf(t_f), tflops_dgrad=tf(t_d), tflops_wgrad=tf(t_w)))
-    print('%-10s %-28s fwd %7.3f ms %6.1f TF | dgrad %7.3f ms %6.1f TF | wgrad %7.3f ms %6.1f TF' % (
-        name, key, t_f, tf(t_f), t_d, tf(t_d), t_w, tf(t_w)), flush=True)
+    print('%-10s %-28s fwd %7.3f ms %6.1f TF | dgrad %7.3f ms %6.1f TF | wgrad %7.3f ms %6.1f TF | bwd (one launch) %7.3f ms' % (
+        name, key, t_f, tf(t_f), t_d, tf(t_d), t_w, tf(t_w), t_b), flush=True)
+    tot['bwd'] = tot.get('bwd', 0.0) + t_b
     tot['fwd'] += t_f
     tot['dgrad'] += t_d
     tot['wgrad'] += t_w
@@ -105,6 +108,11 @@ def main():
   print('TOTAL conv: fwd %.2f ms dgrad %.2f ms wgrad %.2f ms = %.2f ms -> %.1f TFLOP/s, %.0f img/s (conv only)' % (
       tot['fwd'], tot['dgrad'], tot['wgrad'], conv_ms, rep['totals']['tflops_conv'],
       rep['totals']['img_per_s_conv_only']), flush=True)
+  fused_ms = tot['fwd'] + tot.get('bwd', 0.0)
+  rep['totals']['ms_bwd_one_launch'] = tot.get('bwd', 0.0)
+  rep['totals']['tflops_conv_fused'] = flops / (fused_ms * 1e-3) / 1e12
+  print('TOTAL with dgrad+wgrad in one launch: fwd %.2f ms + bwd %.2f ms = %.2f ms -> %.1f TFLOP/s' % (
+      tot['fwd'], tot.get('bwd', 0.0), fused_ms, rep['totals']['tflops_conv_fused']), flush=True)
 
   # ---- K2 / K3 on the whole model ------------------------------------------
   shapes = list(layer_shapes.resnet50().values())
