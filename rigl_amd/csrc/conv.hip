@@ -1508,6 +1508,7 @@ int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl
     // Launched alone back to back, a large short-reduction (HBM-bound) dgrad -- the 56x56 / 28x28 1x1 "reduce"
     // convs -- is 9-28 % slower when it shares the launch, the other layers 3-10 % faster; inside the training
     // step sharing always won (8688 vs 8567 images/s on one box), so the selective rule is off by default.
+    const int dgrad_ktiles = d->kh * d->kw * ((d->cout + 31) / 32);
     static const bool selective = [] { const char* e = getenv("RIGL_BWD_FUSE_SELECTIVE"); return e ? atoi(e) != 0 : false; }();
     const bool pays = !selective || !(pd.grid > 1536u && dgrad_ktiles <= 8);
     if (pays && pd.dma && !pd.w4 && wgrad_stages(p.tm, p.tn) == st_default) {
