@@ -45,11 +45,19 @@ def main():
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  torch.cuda.set_device(local_rank)
-  dev = torch.device('cuda', local_rank)
+  # RIGL_BENCH_ONE_DEVICE=1 + RIGL_BENCH_BACKEND=gloo: development smoke of the N > 1 code path on a
+  # single-GPU box (all ranks on cuda:0, gradients exchanged through gloo); never used for numbers.
+  one_device = os.environ.get('RIGL_BENCH_ONE_DEVICE', '0') == '1'
+  backend = os.environ.get('RIGL_BENCH_BACKEND', 'nccl')
+  dev_index = 0 if one_device else local_rank
+  torch.cuda.set_device(dev_index)
+  dev = torch.device('cuda', dev_index)
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', device_id=dev)
+    if backend == 'nccl':
+      dist.init_process_group('nccl', device_id=dev)
+    else:
+      dist.init_process_group(backend)
   assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
   import numpy as np
@@ -103,6 +111,7 @@ def main():
   if not args.no_prof:
     ops.prof_enable(False)
     prof = ops.prof_collect()
+  masks_same = sync.check_masks_identical() if sync is not None else None   # after the timed region: replicas must agree
   t = torch.tensor([dt], dtype=torch.float64, device=dev)
   if world > 1:
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -122,7 +131,8 @@ def main():
                                'drop 0.3 cosine, Nesterov 0.9, wd 1e-4, label smoothing 0.1, 224x224x3 NHWC'
                                % args.sparsity,
                    'global_batch': global_batch, 'per_gpu_batch': args.batch,
-                   'parallelism': 'dp%d' % world, 'mask_updates_in_timed_region': n_updates},
+                   'parallelism': 'dp%d' % world, 'mask_updates_in_timed_region': n_updates,
+                   'masks_identical_across_ranks': masks_same},
     }
     if prof is not None:
       conv_ms = sum(prof[k][0] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'conv_bwd'))
