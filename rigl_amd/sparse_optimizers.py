@@ -297,6 +297,12 @@ class SparseSETOptimizerBase(train.Optimizer):
     mode, div = self._grow_mode()
     if reinit_when_same is None:
       reinit_when_same = self._reinit_when_same
+    sync = getattr(self._optimizer, '_grad_sync', None)
+    if sync is not None and getattr(sync, 'enabled', False):
+      # data parallel: rank 0's value is authoritative (a 4-byte broadcast per mask update; the
+      # fraction is a pure function of global_step, so this only guards against drifted hosts)
+      from rigl_amd import dist as rdist  # pylint: disable=import-outside-toplevel
+      self.drop_fraction = F32(rdist.broadcast_drop_fraction(float(self.drop_fraction), group=sync.group))
     self.last_counts = ops.prune_regrow(
         layers, float(self.drop_fraction), grow_init_mode=mode,
         grow_init_div=div, momentum_reset_mode=self._momentum_reset_mode,
