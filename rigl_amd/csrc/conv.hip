@@ -1093,29 +1093,29 @@ template <int MODE, bool F32, bool CLS>
 static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, int bk, bool dma, bool w4, hipStream_t st) {
   dim3 blk(THREADS);
   if (dma && w4) {
-    if (wide_n) hipLaunchKernelGGL((k_igemm_w4<2, 2, 32, MODE, F32, CLS, 22>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((k_igemm_w4<2, 1, 32, MODE, F32, CLS, 22>), grid, blk, 0, st, a);
+    if (wide_n) RIGL_K_LAUNCH((k_igemm_w4<2, 2, 32, MODE, F32, CLS, 22>), grid, blk, 0, st, a);
+    else RIGL_K_LAUNCH((k_igemm_w4<2, 1, 32, MODE, F32, CLS, 22>), grid, blk, 0, st, a);
     return;
   }
   if (dma) {   // LDS-DMA ring, BK = 32: 3 stages = 48 KB of LDS -> 3 workgroups per CU (the 136-VGPR limit too); 4 stages
     // = 64 KB -> 2 per CU measured 4-7 % slower over the ResNet-50 layer set (RIGL_CONV_STAGES=4 to compare)
     if (conv_dma_stages() == 3) {
-      if (wide_n) hipLaunchKernelGGL((k_igemm<2, 2, 32, MODE, F32, CLS, 3>), grid, blk, 0, st, a);
-      else hipLaunchKernelGGL((k_igemm<2, 1, 32, MODE, F32, CLS, 3>), grid, blk, 0, st, a);
+      if (wide_n) RIGL_K_LAUNCH((k_igemm<2, 2, 32, MODE, F32, CLS, 3>), grid, blk, 0, st, a);
+      else RIGL_K_LAUNCH((k_igemm<2, 1, 32, MODE, F32, CLS, 3>), grid, blk, 0, st, a);
     } else {
-      if (wide_n) hipLaunchKernelGGL((k_igemm<2, 2, 32, MODE, F32, CLS, 4>), grid, blk, 0, st, a);
-      else hipLaunchKernelGGL((k_igemm<2, 1, 32, MODE, F32, CLS, 4>), grid, blk, 0, st, a);
+      if (wide_n) RIGL_K_LAUNCH((k_igemm<2, 2, 32, MODE, F32, CLS, 4>), grid, blk, 0, st, a);
+      else RIGL_K_LAUNCH((k_igemm<2, 1, 32, MODE, F32, CLS, 4>), grid, blk, 0, st, a);
     }
     return;
   }
   if (wide_n) {
-    if (bk == 64) hipLaunchKernelGGL((k_igemm<2, 2, 64, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
-    else if (bk == 32) hipLaunchKernelGGL((k_igemm<2, 2, 32, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((k_igemm<2, 2, 16, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
+    if (bk == 64) RIGL_K_LAUNCH((k_igemm<2, 2, 64, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
+    else if (bk == 32) RIGL_K_LAUNCH((k_igemm<2, 2, 32, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
+    else RIGL_K_LAUNCH((k_igemm<2, 2, 16, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
   } else {
-    if (bk == 64) hipLaunchKernelGGL((k_igemm<2, 1, 64, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
-    else if (bk == 32) hipLaunchKernelGGL((k_igemm<2, 1, 32, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((k_igemm<2, 1, 16, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
+    if (bk == 64) RIGL_K_LAUNCH((k_igemm<2, 1, 64, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
+    else if (bk == 32) RIGL_K_LAUNCH((k_igemm<2, 1, 32, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
+    else RIGL_K_LAUNCH((k_igemm<2, 1, 16, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
   }
 }
 
@@ -1315,7 +1315,7 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, cons
     return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_fwd_stats: stats buffer %zu floats < %zu", stats_floats,
                 (size_t)rigl_conv2d_stats_parts(d) * 2 * d->cout);
   hipStream_t st = as_stream(stream);
-  ProfScope prof(PROF_CONV_FWD, st);
+  ProfFamily prof(PROF_CONV_FWD);
   IgemmArgs a = {};
   a.C = y; a.M = d->n * d->ho * d->wo; a.N = d->cout; a.ldc = d->cout; a.STATS = stats;
   const size_t need = rigl_conv2d_workspace_bytes(d, 0);
@@ -1327,8 +1327,8 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, cons
     uint16_t* xp = static_cast<uint16_t*>(workspace);
     uint16_t* wp = reinterpret_cast<uint16_t*>(static_cast<char*>(workspace) + align_up(xp_bytes, 256));
     PadArgs pa = {x, xp, d->n, d->h, d->w, d->cin, tg.hp, tg.wp, d->pad_top, d->pad_left};
-    hipLaunchKernelGGL(k_pad_input4, dim3(2048), dim3(THREADS), 0, st, pa);
-    hipLaunchKernelGGL(k_stem_weights, dim3(64), dim3(THREADS), 0, st, w_ohwi, wp, d->cout, d->kh, d->kw, d->cin, tg.cred);
+    RIGL_K_LAUNCH(k_pad_input4, dim3(2048), dim3(THREADS), 0, st, pa);
+    RIGL_K_LAUNCH(k_stem_weights, dim3(64), dim3(THREADS), 0, st, w_ohwi, wp, d->cout, d->kh, d->kw, d->cin, tg.cred);
     a.A = xp; a.B = wp; a.Cred = tg.cred; a.a_pix_stride = 4; a.KH = d->kh; a.KW = 1; a.RH = d->ho; a.RW = d->wo;
     a.GH = tg.hp; a.GW = tg.wp; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = a.pw = 0;
     a.b_row_stride = d->kh * tg.cred; a.b_tap_stride = tg.cred;
@@ -1338,8 +1338,8 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, cons
     uint16_t* col = static_cast<uint16_t*>(workspace);
     uint16_t* wp = reinterpret_cast<uint16_t*>(static_cast<char*>(workspace) + align_up((size_t)a.M * Kp * 2, 256));
     Im2colArgs ia = {x, col, a.M, d->cin, d->kh, d->kw, d->h, d->w, d->ho, d->wo, d->stride_h, d->stride_w, d->pad_top, d->pad_left, K, Kp};
-    hipLaunchKernelGGL(k_im2col, dim3(2048), dim3(THREADS), 0, st, ia);
-    hipLaunchKernelGGL(k_pad_rows, dim3(64), dim3(THREADS), 0, st, w_ohwi, wp, d->cout, K, Kp);
+    RIGL_K_LAUNCH(k_im2col, dim3(2048), dim3(THREADS), 0, st, ia);
+    RIGL_K_LAUNCH(k_pad_rows, dim3(64), dim3(THREADS), 0, st, w_ohwi, wp, d->cout, K, Kp);
     // row space = one long row of M pixels in a single "image"
     a.A = col; a.B = wp; a.Cred = Kp; a.a_pix_stride = Kp; a.KH = a.KW = 1; a.RH = 1; a.RW = a.M; a.GH = 1; a.GW = a.M;
     a.sh = a.sw = 1; a.ph = a.pw = 0; a.b_row_stride = Kp; a.b_tap_stride = 0;
@@ -1385,7 +1385,7 @@ int rigl_masked_conv2d_dgrad_acc(const RiglConvDesc* d, const rigl_bf16* dy, con
   if (!dy || !w_hwio || !dx) return fail(RIGL_EINVAL, "rigl_masked_conv2d_dgrad: NULL tensor");
   if ((d->cin % 8) || (d->cout % 8)) return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_dgrad: cin/cout %% 8 != 0 (use the reference kernel)");
   hipStream_t st = as_stream(stream);
-  ProfScope prof(PROF_CONV_DGRAD, st);
+  ProfFamily prof(PROF_CONV_DGRAD);
   IgemmArgs a = dgrad_args(d, dy, w_hwio, addend, dx);
   launch_igemm<1, false>(a, st);
   RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
@@ -1408,7 +1408,7 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   hipStream_t st = as_stream(stream);
   const size_t need = rigl_conv2d_workspace_bytes(d, 2);
   if (need && (!workspace || workspace_bytes < need)) return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
-  ProfScope prof(PROF_CONV_WGRAD, st);
+  ProfFamily prof(PROF_CONV_WGRAD);
   WgradArgs a = {};
   a.DY = dy; a.M = d->n * d->ho * d->wo; a.Cout = d->cout;
   a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
@@ -1422,7 +1422,7 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
     uint16_t* xp = reinterpret_cast<uint16_t*>(ws);
     ws += align_up(xp_bytes, 256);
     PadArgs pa = {x, xp, d->n, d->h, d->w, d->cin, tg.hp, tg.wp, d->pad_top, d->pad_left};
-    hipLaunchKernelGGL(k_pad_input4, dim3(2048), dim3(THREADS), 0, st, pa);
+    RIGL_K_LAUNCH(k_pad_input4, dim3(2048), dim3(THREADS), 0, st, pa);
     a.X = xp; a.Cin = tg.cred; a.x_pix_stride = 4; a.KH = d->kh; a.KW = 1; a.H = tg.hp; a.W = tg.wp;
     a.Ho = d->ho; a.Wo = d->wo; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = a.pw = 0;
     a.x_bytes = (uint32_t)xp_bytes;
@@ -1435,7 +1435,7 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
     uint16_t* col = reinterpret_cast<uint16_t*>(ws);
     ws += align_up((size_t)a.M * Kp * 2, 256);
     Im2colArgs ia = {x, col, a.M, d->cin, d->kh, d->kw, d->h, d->w, d->ho, d->wo, d->stride_h, d->stride_w, d->pad_top, d->pad_left, K, Kp};
-    hipLaunchKernelGGL(k_im2col, dim3(2048), dim3(THREADS), 0, st, ia);
+    RIGL_K_LAUNCH(k_im2col, dim3(2048), dim3(THREADS), 0, st, ia);
     a.X = col; a.Cin = Kp; a.x_pix_stride = Kp; a.KH = a.KW = 1; a.H = 1; a.W = a.M; a.Ho = 1; a.Wo = a.M;
     a.sh = a.sw = 1; a.ph = a.pw = 0;
     a.x_bytes = (uint32_t)((size_t)a.M * Kp * 2);
@@ -1454,29 +1454,29 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   const bool use_tr = wgrad_use_tr();
   if (use_tr) {
     if (wgrad_stages(p.tm, p.tn) == 3) {
-      if (p.tm == 2 && p.tn == 2) hipLaunchKernelGGL((k_wgrad_tr<2, 2, 3>), grid, blk, 0, st, a);
-      else if (p.tm == 2) hipLaunchKernelGGL((k_wgrad_tr<2, 1, 3>), grid, blk, 0, st, a);
-      else if (p.tn == 2) hipLaunchKernelGGL((k_wgrad_tr<1, 2, 3>), grid, blk, 0, st, a);
-      else hipLaunchKernelGGL((k_wgrad_tr<1, 1, 3>), grid, blk, 0, st, a);
+      if (p.tm == 2 && p.tn == 2) RIGL_K_LAUNCH((k_wgrad_tr<2, 2, 3>), grid, blk, 0, st, a);
+      else if (p.tm == 2) RIGL_K_LAUNCH((k_wgrad_tr<2, 1, 3>), grid, blk, 0, st, a);
+      else if (p.tn == 2) RIGL_K_LAUNCH((k_wgrad_tr<1, 2, 3>), grid, blk, 0, st, a);
+      else RIGL_K_LAUNCH((k_wgrad_tr<1, 1, 3>), grid, blk, 0, st, a);
     } else {
-      if (p.tm == 2 && p.tn == 2) hipLaunchKernelGGL((k_wgrad_tr<2, 2, 4>), grid, blk, 0, st, a);
-      else if (p.tm == 2) hipLaunchKernelGGL((k_wgrad_tr<2, 1, 4>), grid, blk, 0, st, a);
-      else if (p.tn == 2) hipLaunchKernelGGL((k_wgrad_tr<1, 2, 4>), grid, blk, 0, st, a);
-      else hipLaunchKernelGGL((k_wgrad_tr<1, 1, 4>), grid, blk, 0, st, a);
+      if (p.tm == 2 && p.tn == 2) RIGL_K_LAUNCH((k_wgrad_tr<2, 2, 4>), grid, blk, 0, st, a);
+      else if (p.tm == 2) RIGL_K_LAUNCH((k_wgrad_tr<2, 1, 4>), grid, blk, 0, st, a);
+      else if (p.tn == 2) RIGL_K_LAUNCH((k_wgrad_tr<1, 2, 4>), grid, blk, 0, st, a);
+      else RIGL_K_LAUNCH((k_wgrad_tr<1, 1, 4>), grid, blk, 0, st, a);
     }
   } else {
-    if (p.tm == 2 && p.tn == 2) hipLaunchKernelGGL((k_wgrad<2, 2>), grid, blk, 0, st, a);
-    else if (p.tm == 2) hipLaunchKernelGGL((k_wgrad<2, 1>), grid, blk, 0, st, a);
-    else if (p.tn == 2) hipLaunchKernelGGL((k_wgrad<1, 2>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((k_wgrad<1, 1>), grid, blk, 0, st, a);
+    if (p.tm == 2 && p.tn == 2) RIGL_K_LAUNCH((k_wgrad<2, 2>), grid, blk, 0, st, a);
+    else if (p.tm == 2) RIGL_K_LAUNCH((k_wgrad<2, 1>), grid, blk, 0, st, a);
+    else if (p.tn == 2) RIGL_K_LAUNCH((k_wgrad<1, 2>), grid, blk, 0, st, a);
+    else RIGL_K_LAUNCH((k_wgrad<1, 1>), grid, blk, 0, st, a);
   }
   if (two_pass) {
     const int64_t blocks = ceil_div64(n_out, 64);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)blocks), blk, 0, st, reinterpret_cast<const float*>(ws),
+    RIGL_K_LAUNCH(k_wgrad_reduce, dim3((unsigned)blocks), blk, 0, st, reinterpret_cast<const float*>(ws),
                        tiny_tmp ? tiny_tmp : dw, n_out, p.slab, p.splits);
   }
   if (tiny_tmp)
-    hipLaunchKernelGGL(k_stem_unpack, dim3(64), blk, 0, st, tiny_tmp, dw, d->kh, d->kw, d->cin, tg.cred, d->cout);
+    RIGL_K_LAUNCH(k_stem_unpack, dim3(64), blk, 0, st, tiny_tmp, dw, d->kh, d->kw, d->cin, tg.cred, d->cout);
   RIGL_CHECK_LAUNCH("rigl_masked_conv2d_wgrad");
   return RIGL_OK;
 }
@@ -1516,7 +1516,7 @@ int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl
       if (need && (!workspace || workspace_bytes < need))
         return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
       hipStream_t st = as_stream(stream);
-      ProfScope prof(PROF_CONV_BWD, st);
+      ProfFamily prof(PROF_CONV_BWD);
       aw.tiles_ci = p.tiles_ci; aw.tiles_co = p.tiles_co; aw.splits = p.splits; aw.slab_elems = p.slab;
       const bool two_pass = p.splits > 1;
       aw.OUT = two_pass ? static_cast<float*>(workspace) : dw;
@@ -1524,17 +1524,17 @@ int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl
       const dim3 grid(nd + nw), blk(THREADS);
 #define RIGL_FUSED(TND, CLSD)                                                                                        \
       {                                                                                                              \
-        if (p.tm == 2 && p.tn == 2) hipLaunchKernelGGL((k_bwd_fused<TND, CLSD, 2, 2, 3>), grid, blk, 0, st, ad, aw, nd); \
-        else if (p.tm == 2) hipLaunchKernelGGL((k_bwd_fused<TND, CLSD, 2, 1, 4>), grid, blk, 0, st, ad, aw, nd);      \
-        else if (p.tn == 2) hipLaunchKernelGGL((k_bwd_fused<TND, CLSD, 1, 2, 4>), grid, blk, 0, st, ad, aw, nd);      \
-        else hipLaunchKernelGGL((k_bwd_fused<TND, CLSD, 1, 1, 4>), grid, blk, 0, st, ad, aw, nd);                     \
+        if (p.tm == 2 && p.tn == 2) RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 2, 2, 3>), grid, blk, 0, st, ad, aw, nd); \
+        else if (p.tm == 2) RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 2, 1, 4>), grid, blk, 0, st, ad, aw, nd);      \
+        else if (p.tn == 2) RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 1, 2, 4>), grid, blk, 0, st, ad, aw, nd);      \
+        else RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 1, 1, 4>), grid, blk, 0, st, ad, aw, nd);                     \
       }
       if (pd.wide_n) { if (pd.cls) RIGL_FUSED(2, true) else RIGL_FUSED(2, false) }
       else { if (pd.cls) RIGL_FUSED(1, true) else RIGL_FUSED(1, false) }
 #undef RIGL_FUSED
       if (two_pass) {
         const int64_t n_out = (int64_t)d->kh * d->kw * d->cin * d->cout;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)ceil_div64(n_out, 64)), blk, 0, st,
+        RIGL_K_LAUNCH(k_wgrad_reduce, dim3((unsigned)ceil_div64(n_out, 64)), blk, 0, st,
                            static_cast<const float*>(workspace), dw, n_out, p.slab, p.splits);
       }
       RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");

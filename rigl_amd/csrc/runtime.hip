@@ -43,6 +43,16 @@ static hipEvent_t get_event() {
   return e;
 }
 
+hipEvent_t prof_get_event() { return get_event(); }
+void prof_add_pair(int kind, hipEvent_t a, hipEvent_t b) {
+  std::lock_guard<std::mutex> l(g_prof_mu);
+  g_pending.push_back({a, b, kind});
+}
+int& prof_current_kind() {
+  static thread_local int k = PROF_CONV_FWD;
+  return k;
+}
+
 void prof_begin(int kind, hipStream_t s) {
   hipEvent_t e = get_event();
   t_open[kind] = e;
