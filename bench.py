@@ -169,6 +169,22 @@ def main():
           'by_kind_ms_per_step': {k: prof[k][0] / n_fwd_bwd for k in prof},
           'conv_share_of_step': (conv_ms / n_fwd_bwd) / ms_per_step,
       }
+      # the two HBM-bound kernels of the path, against the 8 TB/s HBM3E peak (algorithmic bytes: SURVEY 8d)
+      n_params = sum(v.numel for v in g.trainable_variables())
+      n_masked = sum(m.numel for m in g.get_masks())
+      k3_ms, k3_n = prof['sgd_momentum']
+      k2_ms, k2_n = prof['prune_regrow']
+      hbm = {}
+      if k3_ms > 0:
+        steps_k3 = max(n_profiled - (1 if k2_n else 0), 1)      # update iterations skip the weight update (F9)
+        gbs = 20.1 * n_params / (k3_ms / steps_k3 * 1e-3) / 1e9
+        hbm['masked_sgd_momentum'] = {'bound': 'hbm', 'achieved': gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0,
+                                      'algorithmic_bytes_per_param': 20.1, 'ms_per_step': k3_ms / steps_k3}
+      if k2_ms > 0 and k2_n > 0:
+        gbs = 8.25 * n_masked / (k2_ms / k2_n * 1e-3) / 1e9
+        hbm['prune_regrow'] = {'bound': 'hbm', 'achieved': gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0,
+                               'algorithmic_bytes_per_weight': 8.25, 'ms_per_update': k2_ms / k2_n}
+      out['roofline']['hbm_kernels'] = hbm
     if world == 1 and not args.no_cpu_baseline:
       try:
         from oracle import resnet_cpu
