@@ -7,6 +7,7 @@ PyTorch-op fallback; calling one without a GPU / without the built library
 raises ``RiglError``.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -47,13 +48,11 @@ def _req(t, dtype, name, allow_none=False):
     raise ValueError('%s must be contiguous' % name)
 
 
-import os as _os
-
 # RIGL_WGRAD_STREAM=1: weight-gradient GEMMs go to a second HIP stream and overlap the dX chain
 # (measured +4.3 % images/s on ResNet-50 at N = 1).  Off by default: under concurrency every
 # kernel's own duration stretches, so per-launch timings (roofline.achieved, rocprof averages)
 # stop describing the kernels, and the multi-GPU path could not be exercised with it here.
-_SIDE_WGRAD = _os.environ.get('RIGL_WGRAD_STREAM', '0') == '1'
+_SIDE_WGRAD = os.environ.get('RIGL_WGRAD_STREAM', '0') == '1'
 _side_streams = {}
 
 
