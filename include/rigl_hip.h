@@ -261,6 +261,28 @@ int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x,
                            rigl_bf16* dx /* nullable */, void* workspace,
                            size_t workspace_bytes, rigl_stream_t stream);
 
+/* The same with the split-K reduce of dW handed from one layer's backward to the
+ * next launch: `defer` (nullable) receives this layer's pending reduce instead of
+ * running it (splits == 0: nothing pending, dW is complete); `flush` (nullable)
+ * is the pending reduce of the layer before, executed by a third segment of
+ * workgroups inside this layer's launch (or by a kernel of its own on the
+ * fallback paths).  The caller keeps the pending layer's workspace alive and
+ * passes a DIFFERENT workspace here; the last pending reduce of a backward pass
+ * is run by rigl_wgrad_reduce_pending.  Results are bit-identical.             */
+typedef struct RiglPendingReduce {
+  const float* slabs;   /* [splits][slab_elems] partial sums                   */
+  float* dw;            /* destination, n_out elements                          */
+  int64_t n_out, slab_elems;
+  int32_t splits;       /* 0 = nothing pending                                  */
+} RiglPendingReduce;
+int rigl_masked_conv2d_bwd_deferred(const RiglConvDesc* d, const rigl_bf16* x,
+                                    const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                                    const rigl_bf16* addend, float* dw, rigl_bf16* dx,
+                                    void* workspace, size_t workspace_bytes,
+                                    const RiglPendingReduce* flush,
+                                    RiglPendingReduce* defer, rigl_stream_t stream);
+int rigl_wgrad_reduce_pending(const RiglPendingReduce* pending, rigl_stream_t stream);
+
 /* K1d: dense depthwise convolution (depth multiplier 1), NHWC bf16, fp32 HWIO
  * weights [kh][kw][c][1] read directly.  Replaces
  * contrib_layers.separable_conv2d(num_outputs=None)

@@ -61,6 +61,13 @@ class ConvDesc(C.Structure):
               ('pad_top', C.c_int32), ('pad_left', C.c_int32)]
 
 
+class PendingReduce(C.Structure):
+  """RiglPendingReduce: a layer's split-K reduce handed to the next backward launch."""
+  _fields_ = [('slabs', C.c_void_p), ('dw', C.c_void_p), ('n_out', C.c_int64),
+              ('slab_elems', C.c_int64), ('splits', C.c_int32)]
+
+
+
 # name -> (restype, argtypes); every symbol declared in include/rigl_hip.h
 _P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -88,6 +95,9 @@ SIGNATURES = {
                                                _SZ, _P, _SZ, _P]),
     'rigl_masked_conv2d_dgrad_acc': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P,
                                                _P, _P, _SZ, _P]),
+    'rigl_masked_conv2d_bwd_deferred': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ,
+                                                  C.POINTER(PendingReduce), C.POINTER(PendingReduce), _P]),
+    'rigl_wgrad_reduce_pending': (C.c_int, [C.POINTER(PendingReduce), _P]),
     'rigl_masked_conv2d_bwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'rigl_masked_conv2d_wgrad': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P,
                                            _SZ, _P]),

@@ -925,60 +925,80 @@ __global__ __launch_bounds__(THREADS) void k_wgrad_tr(WgradArgs P) {
   wgrad_tr_body<TM, TN, STAGES>(P, smem, blockIdx.x, gridDim.x);
 }
 
-// Whole backward of a conv in ONE launch: the first `nd` workgroups run the dgrad implicit GEMM, the
-// rest the weight-gradient GEMM.  The two are independent (both read dY) and on their own each
-// leaves much of the chip idle (196-784 tiles for 768 workgroup slots), so sharing a launch lets the
-// dispatcher fill the machine with whichever still has tiles -- the overlap a second stream gives,
-// without a second stream.  Same bodies, one LDS allocation (the larger of the two).
-template <int TND, bool CLSD, int TMW, int TNW, int STW>
-__global__ __launch_bounds__(THREADS) void k_bwd_fused(IgemmArgs PD, WgradArgs PW, uint32_t nd) {
-  constexpr int SD = igemm_smem_bytes<2, TND, 32, 1, false, CLSD, 3>(), SW = wgrad_tr_smem_bytes<TMW, TNW, STW>();
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SD > SW ? SD : SW];
-  if (blockIdx.x < nd) igemm_body<2, TND, 32, 1, false, CLSD, 3>(PD, smem, blockIdx.x, nd);
-  else wgrad_tr_body<TMW, TNW, STW>(PW, smem, blockIdx.x - nd, gridDim.x - nd);
-}
-
 // dw[i] = sum_s slab[s][i] in a FIXED order (deterministic => identical masks
 // run to run).  A workgroup owns 64 consecutive outputs; its 256 threads are 16
 // float4 columns x 16 split-groups, so 16 independent 256-B reads are in flight
 // per step instead of one thread walking all splits serially; group partials are
 // combined through LDS in ascending group order.  n_out <= slab_elems lets the
 // small-Cin (im2col) path drop its zero padding rows.
-__global__ __launch_bounds__(THREADS) void k_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw,
-                                                           int64_t n_out, int64_t slab_elems, int splits) {
-  __shared__ float4 part[16][16];
+struct ReduceArgs {
+  const float* slabs;
+  float* dw;
+  int64_t n_out, slab_elems;
+  int splits;
+};
+
+// One workgroup walks the 64-output groups bid, bid + nblk, ... (a standalone launch has one group per
+// workgroup; as the third segment of a fused backward launch a few hundred workgroups share the groups).
+// The summation order of every output is the same in both uses.
+__device__ __forceinline__ void wgrad_reduce_body(const ReduceArgs& R, unsigned char* smem, uint32_t bid, uint32_t nblk) {
+  float4 (*part)[16] = reinterpret_cast<float4 (*)[16]>(smem);      // [16][16]
   const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  const int64_t i0 = (int64_t)blockIdx.x * 64 + col * 4;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i0 + 3 < slab_elems && (slab_elems & 3) == 0) {
+  const int64_t n_groups = (R.n_out + 63) / 64;
+  const bool vec = (R.slab_elems & 3) == 0;
+  for (int64_t gidx = bid; gidx < n_groups; gidx += nblk) {
+    const int64_t i0 = gidx * 64 + col * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec && i0 + 3 < R.slab_elems) {
 #pragma unroll 4
-    for (int s2 = grp; s2 < splits; s2 += 16) {
-      const float4 v = *reinterpret_cast<const float4*>(slabs + (int64_t)s2 * slab_elems + i0);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      for (int s2 = grp; s2 < R.splits; s2 += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(R.slabs + (int64_t)s2 * R.slab_elems + i0);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    } else {
+      for (int s2 = grp; s2 < R.splits; s2 += 16) {
+        const float* p = R.slabs + (int64_t)s2 * R.slab_elems;
+        if (i0 + 0 < R.slab_elems) acc.x += p[i0 + 0];
+        if (i0 + 1 < R.slab_elems) acc.y += p[i0 + 1];
+        if (i0 + 2 < R.slab_elems) acc.z += p[i0 + 2];
+        if (i0 + 3 < R.slab_elems) acc.w += p[i0 + 3];
+      }
     }
-  } else {
-    for (int s2 = grp; s2 < splits; s2 += 16) {
-      const float* p = slabs + (int64_t)s2 * slab_elems;
-      if (i0 + 0 < slab_elems) acc.x += p[i0 + 0];
-      if (i0 + 1 < slab_elems) acc.y += p[i0 + 1];
-      if (i0 + 2 < slab_elems) acc.z += p[i0 + 2];
-      if (i0 + 3 < slab_elems) acc.w += p[i0 + 3];
-    }
-  }
-  part[grp][col] = acc;
-  __syncthreads();
-  if (grp == 0) {
-    float4 r = part[0][col];
+    part[grp][col] = acc;
+    __syncthreads();
+    if (grp == 0) {
+      float4 r = part[0][col];
 #pragma unroll
-    for (int g2 = 1; g2 < 16; ++g2) {
-      const float4 v = part[g2][col];
-      r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+      for (int g2 = 1; g2 < 16; ++g2) {
+        const float4 v = part[g2][col];
+        r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+      }
+      if (i0 + 0 < R.n_out) R.dw[i0 + 0] = r.x;
+      if (i0 + 1 < R.n_out) R.dw[i0 + 1] = r.y;
+      if (i0 + 2 < R.n_out) R.dw[i0 + 2] = r.z;
+      if (i0 + 3 < R.n_out) R.dw[i0 + 3] = r.w;
     }
-    if (i0 + 0 < n_out) dw[i0 + 0] = r.x;
-    if (i0 + 1 < n_out) dw[i0 + 1] = r.y;
-    if (i0 + 2 < n_out) dw[i0 + 2] = r.z;
-    if (i0 + 3 < n_out) dw[i0 + 3] = r.w;
+    __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(THREADS) void k_wgrad_reduce(ReduceArgs R) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[16 * 16 * 16];
+  wgrad_reduce_body(R, smem, blockIdx.x, gridDim.x);
+}
+
+// Whole backward of a conv in ONE launch: the first `nd` workgroups run the dgrad implicit GEMM, the
+// next `nw` the weight-gradient GEMM, any further ones the deferred split-K reduce of the layer before.  The two are independent (both read dY) and on their own each
+// leaves much of the chip idle (196-784 tiles for 768 workgroup slots), so sharing a launch lets the
+// dispatcher fill the machine with whichever still has tiles -- the overlap a second stream gives,
+// without a second stream.  Same bodies, one LDS allocation (the larger of the two).
+template <int TND, bool CLSD, int TMW, int TNW, int STW>
+__global__ __launch_bounds__(THREADS) void k_bwd_fused(IgemmArgs PD, WgradArgs PW, ReduceArgs PR, uint32_t nd, uint32_t nw) {
+  constexpr int SD = igemm_smem_bytes<2, TND, 32, 1, false, CLSD, 3>(), SW = wgrad_tr_smem_bytes<TMW, TNW, STW>();
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SD > SW ? SD : SW];
+  if (blockIdx.x < nd) igemm_body<2, TND, 32, 1, false, CLSD, 3>(PD, smem, blockIdx.x, nd);
+  else if (blockIdx.x < nd + nw) wgrad_tr_body<TMW, TNW, STW>(PW, smem, blockIdx.x - nd, nw);
+  else wgrad_reduce_body(PR, smem, blockIdx.x - nd - nw, gridDim.x - nd - nw);   // the PREVIOUS layer's split-K reduce
 }
 
 // ------------------------------------------------------------------ small-Cin (stem) path
@@ -1472,8 +1492,8 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   }
   if (two_pass) {
     const int64_t blocks = ceil_div64(n_out, 64);
-    RIGL_K_LAUNCH(k_wgrad_reduce, dim3((unsigned)blocks), blk, 0, st, reinterpret_cast<const float*>(ws),
-                       tiny_tmp ? tiny_tmp : dw, n_out, p.slab, p.splits);
+    ReduceArgs ra = {reinterpret_cast<const float*>(ws), tiny_tmp ? tiny_tmp : dw, n_out, p.slab, p.splits};
+    RIGL_K_LAUNCH(k_wgrad_reduce, dim3((unsigned)blocks), blk, 0, st, ra);
   }
   if (tiny_tmp)
     RIGL_K_LAUNCH(k_stem_unpack, dim3(64), blk, 0, st, tiny_tmp, dw, d->kh, d->kw, d->cin, tg.cred, d->cout);
@@ -1481,18 +1501,36 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   return RIGL_OK;
 }
 
-// Whole backward of one masked conv in one call: dW (dense) and, when dx is given, dX (+ addend).
-// Ordinary layers run both GEMMs in ONE launch (k_bwd_fused: dgrad workgroups first, then the split-K
-// weight-gradient ones) followed by the split-K reduce; the tiny-/small-Cin paths (extra repack
-// kernels, no dX for the stem) and non-default tuning knobs fall back to the two separate launches.
-int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
-                           const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
-                           rigl_stream_t stream) {
+static void launch_pending_reduce(const RiglPendingReduce* pr, hipStream_t st) {
+  using namespace rigl;
+  using namespace rigl::k1;
+  ReduceArgs ra = {pr->slabs, pr->dw, pr->n_out, pr->slab_elems, pr->splits};
+  RIGL_K_LAUNCH(k_wgrad_reduce, dim3((unsigned)ceil_div64(pr->n_out, 64)), dim3(THREADS), 0, st, ra);
+}
+
+int rigl_wgrad_reduce_pending(const RiglPendingReduce* pending, rigl_stream_t stream) {
+  using namespace rigl;
+  if (!pending || pending->splits <= 0) return RIGL_OK;
+  if (!pending->slabs || !pending->dw) return fail(RIGL_EINVAL, "rigl_wgrad_reduce_pending: NULL buffer");
+  ProfFamily prof(PROF_CONV_BWD);
+  launch_pending_reduce(pending, as_stream(stream));
+  RIGL_CHECK_LAUNCH("rigl_wgrad_reduce_pending");
+  return RIGL_OK;
+}
+
+int rigl_masked_conv2d_bwd_deferred(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy,
+                                    const rigl_bf16* w_hwio, const rigl_bf16* addend, float* dw, rigl_bf16* dx,
+                                    void* workspace, size_t workspace_bytes, const RiglPendingReduce* flush,
+                                    RiglPendingReduce* defer, rigl_stream_t stream) {
   using namespace rigl;
   using namespace rigl::k1;
   static const bool fuse = [] { const char* e = getenv("RIGL_BWD_FUSED"); return e ? atoi(e) != 0 : true; }();
   int rc = check_desc(d, "rigl_masked_conv2d_bwd");
   if (rc) return rc;
+  if (defer) defer->splits = 0;
+  const bool have_flush = flush && flush->splits > 0;
+  if (have_flush && (!flush->slabs || !flush->dw)) return fail(RIGL_EINVAL, "rigl_masked_conv2d_bwd: NULL buffer in the pending reduce");
+  hipStream_t st = as_stream(stream);
   if (fuse && dx && x && dy && w_hwio && dw && !tiny_cin(d) && !small_cin(d) && (d->cin % 8) == 0 && (d->cout % 8) == 0 &&
       wgrad_use_tr() && conv_dma_stages() == 3) {
     IgemmArgs ad = dgrad_args(d, dy, w_hwio, addend, dx);
@@ -1515,35 +1553,64 @@ int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl
       const size_t need = rigl_conv2d_workspace_bytes(d, 2);
       if (need && (!workspace || workspace_bytes < need))
         return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
-      hipStream_t st = as_stream(stream);
+      if (have_flush && need && flush->slabs == static_cast<const float*>(workspace))
+        return fail(RIGL_EINVAL, "rigl_masked_conv2d_bwd: the pending reduce still reads this workspace");
       ProfFamily prof(PROF_CONV_BWD);
       aw.tiles_ci = p.tiles_ci; aw.tiles_co = p.tiles_co; aw.splits = p.splits; aw.slab_elems = p.slab;
       const bool two_pass = p.splits > 1;
       aw.OUT = two_pass ? static_cast<float*>(workspace) : dw;
       const unsigned nd = pd.grid, nw = (unsigned)((int64_t)p.tiles_ci * p.tiles_co * aw.KH * aw.KW * p.splits);
-      const dim3 grid(nd + nw), blk(THREADS);
-#define RIGL_FUSED(TND, CLSD)                                                                                        \
-      {                                                                                                              \
-        if (p.tm == 2 && p.tn == 2) RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 2, 2, 3>), grid, blk, 0, st, ad, aw, nd); \
-        else if (p.tm == 2) RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 2, 1, 4>), grid, blk, 0, st, ad, aw, nd);      \
-        else if (p.tn == 2) RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 1, 2, 4>), grid, blk, 0, st, ad, aw, nd);      \
-        else RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 1, 1, 4>), grid, blk, 0, st, ad, aw, nd);                     \
+      // the layer before left its split-K reduce for this launch: a third segment of a few hundred workgroups
+      ReduceArgs pr = {nullptr, nullptr, 0, 0, 0};
+      unsigned nr = 0;
+      if (have_flush) {
+        pr.slabs = flush->slabs; pr.dw = flush->dw; pr.n_out = flush->n_out; pr.slab_elems = flush->slab_elems; pr.splits = flush->splits;
+        const int64_t groups = ceil_div64(flush->n_out, 64);
+        nr = (unsigned)(groups < 3 * (int64_t)num_cus() ? groups : 3 * (int64_t)num_cus());
+      }
+      const dim3 grid(nd + nw + nr), blk(THREADS);
+#define RIGL_FUSED(TND, CLSD)                                                                                          \
+      {                                                                                                                \
+        if (p.tm == 2 && p.tn == 2) RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 2, 2, 3>), grid, blk, 0, st, ad, aw, pr, nd, nw); \
+        else if (p.tm == 2) RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 2, 1, 4>), grid, blk, 0, st, ad, aw, pr, nd, nw);      \
+        else if (p.tn == 2) RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 1, 2, 4>), grid, blk, 0, st, ad, aw, pr, nd, nw);      \
+        else RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 1, 1, 4>), grid, blk, 0, st, ad, aw, pr, nd, nw);                     \
       }
       if (pd.wide_n) { if (pd.cls) RIGL_FUSED(2, true) else RIGL_FUSED(2, false) }
       else { if (pd.cls) RIGL_FUSED(1, true) else RIGL_FUSED(1, false) }
 #undef RIGL_FUSED
       if (two_pass) {
         const int64_t n_out = (int64_t)d->kh * d->kw * d->cin * d->cout;
-        RIGL_K_LAUNCH(k_wgrad_reduce, dim3((unsigned)ceil_div64(n_out, 64)), blk, 0, st,
-                           static_cast<const float*>(workspace), dw, n_out, p.slab, p.splits);
+        if (defer) {           // the next backward launch (or rigl_wgrad_reduce_pending) finishes dW
+          defer->slabs = static_cast<const float*>(workspace); defer->dw = dw; defer->n_out = n_out;
+          defer->slab_elems = p.slab; defer->splits = p.splits;
+        } else {
+          ReduceArgs ra = {static_cast<const float*>(workspace), dw, n_out, p.slab, p.splits};
+          RIGL_K_LAUNCH(k_wgrad_reduce, dim3((unsigned)ceil_div64(n_out, 64)), blk, 0, st, ra);
+        }
       }
       RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");
       return RIGL_OK;
     }
   }
+  if (have_flush) {
+    ProfFamily prof(PROF_CONV_BWD);
+    launch_pending_reduce(flush, st);
+  }
   rc = rigl_masked_conv2d_wgrad(d, x, dy, dw, workspace, workspace_bytes, stream);
   if (rc || !dx) return rc;
   return rigl_masked_conv2d_dgrad_acc(d, dy, w_hwio, addend, dx, workspace, workspace_bytes, stream);
+}
+
+// Whole backward of one masked conv in one call: dW (dense) and, when dx is given, dX (+ addend).
+// Ordinary layers run both GEMMs in ONE launch (k_bwd_fused: dgrad workgroups first, then the split-K
+// weight-gradient ones) followed by the split-K reduce; the tiny-/small-Cin paths (extra repack
+// kernels, no dX for the stem) and non-default tuning knobs fall back to the two separate launches.
+int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                           const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
+                           rigl_stream_t stream) {
+  return rigl_masked_conv2d_bwd_deferred(d, x, dy, w_hwio, addend, dw, dx, workspace, workspace_bytes, nullptr, nullptr,
+                                         stream);
 }
 
 }  // extern "C"

@@ -185,6 +185,7 @@ class MaskUpdater:
     g.zero_other_grads()
     loss = self._loss_fn(self.val_x, self.val_y)
     loss.backward()
+    ops.flush_pending_wgrad(g.device)
     sync = getattr(self._optimizer, '_grad_sync', None)
     if sync is not None:
       sync.all_reduce(g)

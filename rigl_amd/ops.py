@@ -345,12 +345,40 @@ def conv_wgrad(d, x, dy, dw=None, force_ref=False):
   return dw
 
 
-def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None):
+# RIGL_WGRAD_DEFER=1 hands every layer's split-K reduce to the next backward launch (as a third
+# workgroup segment) instead of launching it right after its own.  Measured neutral on ResNet-50
+# (the reduce workgroups still run in the launch's tail; 14.35 vs 14.36 ms/step), so it is opt-in.
+_DEFER = os.environ.get('RIGL_WGRAD_DEFER', '0') == '1'
+_pending = {}        # device index -> [PendingReduce, workspace tag, done_callback]
+
+
+def flush_pending_wgrad(device=None):
+  """Runs the split-K reduce a backward launch left for its successor (the last layer of a
+  backward pass has none).  Called after backward and before anything reads the gradients."""
+  keys = list(_pending) if device is None else [torch.device(device).index or 0]
+  for key in keys:
+    ent = _pending.pop(key, None)
+    if ent is None:
+      continue
+    pr, _tag, done = ent
+    check(_lib.load().rigl_wgrad_reduce_pending(C.byref(pr), _stream()))
+    if done is not None:
+      done()
+
+
+def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None):
   """dW (into ``dw``, dense fp32) and -- when ``need_dx`` -- dX (+ ``addend``) of
-  one conv with a single host transition (rigl_masked_conv2d_bwd).  Returns dX
-  or None."""
+  one conv with a single host transition and, for ordinary layers, a single launch
+  (rigl_masked_conv2d_bwd_deferred) followed by the split-K reduce that completes dW.
+  With RIGL_WGRAD_DEFER=1 that reduce is handed to the NEXT conv_bwd call, which runs it
+  as a third segment of its own launch; ``flush_pending_wgrad`` finishes the last one.
+  ``on_dw_ready`` is called once dW's reduce has been enqueued (now, or when the next
+  call / the flush picks it up).  Returns dX or None."""
   if not (mfma_supported(d) and (not need_dx or mfma_dgrad_supported(d))):
+    flush_pending_wgrad(x.device)
     conv_wgrad(d, x, dy, dw)
+    if on_dw_ready is not None:
+      on_dw_ready()
     return conv_dgrad(d, dy, w_hwio, addend=addend) if need_dx else None
   _req(x, torch.bfloat16, 'x')
   _req(dy, torch.bfloat16, 'dy')
@@ -362,6 +390,9 @@ def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None):
     need = d._ws_wgrad = lib.rigl_conv2d_workspace_bytes(C.byref(d), 2)
   if _SIDE_WGRAD:
     # wgrad on the side stream (own workspace), dgrad on the main one: the two overlap
+    flush_pending_wgrad(x.device)
+    if on_dw_ready is not None:
+      on_dw_ready()
     main, side = torch.cuda.current_stream(x.device), side_stream(x.device)
     side.wait_stream(main)
     ws = workspace(need, x.device, 'side') if need else None
@@ -370,16 +401,28 @@ def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None):
     x.record_stream(side)
     dy.record_stream(side)
     return conv_dgrad(d, dy, w_hwio, addend=addend) if need_dx else None
-  ws = workspace(need, x.device) if need else None
+  key = x.device.index or 0
+  prev = _pending.pop(key, None)
+  # slabs are double-buffered: the layer before may still be waiting for its reduce
+  tag = 'wgB' if (prev is not None and prev[1] == 'wgA') else 'wgA'
+  ws = workspace(need, x.device, tag) if need else None
   dx = None
   if need_dx:
     _req(w_hwio, torch.bfloat16, 'w_hwio')
     dx = torch.empty((d.n, d.h, d.w, d.cin), dtype=torch.bfloat16, device=dy.device)
     if addend is not None and addend.numel() != dx.numel():
       raise ValueError('addend must have the shape of dx')
-  check(lib.rigl_masked_conv2d_bwd(C.byref(d), _ptr(x), _ptr(dy), _ptr(w_hwio), _ptr(addend),
-                                   _ptr(dw), _ptr(dx), _ptr(ws),
-                                   ws.numel() if ws is not None else 0, _stream()))
+  mine = _lib.PendingReduce() if _DEFER else None
+  check(lib.rigl_masked_conv2d_bwd_deferred(
+      C.byref(d), _ptr(x), _ptr(dy), _ptr(w_hwio), _ptr(addend), _ptr(dw), _ptr(dx), _ptr(ws),
+      ws.numel() if ws is not None else 0, C.byref(prev[0]) if prev is not None else None,
+      C.byref(mine) if mine is not None else None, _stream()))
+  if prev is not None and prev[2] is not None:
+    prev[2]()                              # the previous layer's dW is now complete in stream order
+  if mine is not None and mine.splits > 0:
+    _pending[key] = [mine, tag, on_dw_ready]
+  elif on_dw_ready is not None:
+    on_dw_ready()
   return dx
 
 

@@ -59,10 +59,9 @@ class _MaskedConvFn(torch.autograd.Function):
       dy = torch.zeros((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16, device=x.device)
     dy = dy.contiguous()
     # dense dL/d(mask*W), fp32 HWIO, into this layer's slice of the G arena, and dX -- one call
-    dx = ops.conv_bwd(d, x, dy, lv.hwio, lv.weights.grad.view(-1), need_dx=ctx.need_dx)
     sync = getattr(lv.weights.graph, 'grad_sync', None)
-    if sync is not None:
-      sync.notify_layer_grad_ready(lv.weights)   # DP: overlap the all-reduce
+    ready = (lambda: sync.notify_layer_grad_ready(lv.weights)) if sync is not None else None   # DP: overlap the all-reduce
+    dx = ops.conv_bwd(d, x, dy, lv.hwio, lv.weights.grad.view(-1), need_dx=ctx.need_dx, on_dw_ready=ready)
     return dx, None, None, None, None
 
 
@@ -95,10 +94,9 @@ class _MaskedConvForkFn(torch.autograd.Function):
     dy = dy.contiguous()
     if dalias is not None:
       dalias = dalias.contiguous()
-    dx = ops.conv_bwd(d, x, dy, lv.hwio, lv.weights.grad.view(-1), need_dx=True, addend=dalias)
     sync = getattr(lv.weights.graph, 'grad_sync', None)
-    if sync is not None:
-      sync.notify_layer_grad_ready(lv.weights)
+    ready = (lambda: sync.notify_layer_grad_ready(lv.weights)) if sync is not None else None
+    dx = ops.conv_bwd(d, x, dy, lv.hwio, lv.weights.grad.view(-1), need_dx=True, addend=dalias, on_dw_ready=ready)
     return dx, None, None, None
 
 

@@ -79,6 +79,7 @@ class GradientDescentOptimizer(Optimizer):
     if loss is not None and self._backward_done_for is not loss:
       g.zero_other_grads()
       loss.backward()
+      ops.flush_pending_wgrad(g.device)   # the last layer's split-K reduce has no successor launch to ride on
       ops.join_side_stream(g.device)      # weight gradients may have been produced on the side stream
       self._backward_done_for = loss
       if self._grad_sync is not None:

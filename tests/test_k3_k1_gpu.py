@@ -255,7 +255,7 @@ def test_conv_fwd_epilogue_bn_statistics(case):
 
 
 @pytest.mark.parametrize('case', [CONV_CASES[1], CONV_CASES[4], CONV_CASES[5], CONV_CASES[8], CONV_CASES[15]])
-def test_conv_bwd_single_call_equals_wgrad_then_dgrad(case):
+def test_conv_bwd_single_call_equals_wgrad_then_dgrad(case, monkeypatch):
   """rigl_masked_conv2d_bwd == rigl_masked_conv2d_wgrad + rigl_masked_conv2d_dgrad_acc, bit for bit."""
   from rigl_amd import ops
   N, H, W, Cin, Cout, k, stride, pt, pl, Ho, Wo = case
@@ -273,7 +273,20 @@ def test_conv_bwd_single_call_equals_wgrad_then_dgrad(case):
     assert torch.equal(dx0.view(torch.int16), dx1.view(torch.int16))
   else:
     assert ops.conv_bwd(d, x, dy, hwio, dw1, need_dx=False) is None
+  ops.flush_pending_wgrad()
   assert torch.equal(dw0.view(torch.int32), dw1.view(torch.int32))
+  # a chain of backward launches: each one runs the split-K reduce of the one before as a third segment
+  if Cin % 8 == 0:
+    monkeypatch.setattr(ops, '_DEFER', True)
+    dws = [torch.full_like(dw0, float('nan')) for _ in range(3)]
+    done = []
+    for i, t in enumerate(dws):
+      ops.conv_bwd(d, x, dy, hwio, t, need_dx=True, on_dw_ready=lambda i=i: done.append(i))
+    assert done in ([0, 1], [0, 1, 2])          # the last one is still pending unless the layer needs no split
+    ops.flush_pending_wgrad()
+    assert done == [0, 1, 2]
+    for t in dws:
+      assert torch.equal(t.view(torch.int32), dw0.view(torch.int32))
 
 
 def test_conv_asymmetric_b_detects_transposes():
