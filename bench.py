@@ -169,6 +169,13 @@ def main():
           'by_kind_ms_per_step': {k: prof[k][0] / n_fwd_bwd for k in prof},
           'conv_share_of_step': (conv_ms / n_fwd_bwd) / ms_per_step,
       }
+      # what the same three GEMMs per layer could reach: each layer at the better of its MFMA and HBM bounds
+      lb, lb_mfma, lb_hbm = shapes.resnet50_layerwise_bound(args.batch)
+      out['roofline']['layerwise_bound'] = {
+          'ms_per_step': lb * 1e3, 'mfma_only_ms': lb_mfma * 1e3, 'hbm_only_ms': lb_hbm * 1e3,
+          'frac_of_bound': lb * 1e3 / (conv_ms / n_fwd_bwd) if conv_ms > 0 else 0.0,
+          'note': 'sum over layers and fwd/dgrad/wgrad of max(flops / 2.5 PF, algorithmic bytes / 8 TB/s); '
+                  'mfma_only_ms / ms_per_step is the highest `frac` any implementation of these layers can reach'}
       # the two HBM-bound kernels of the path, against the 8 TB/s HBM3E peak (algorithmic bytes: SURVEY 8d)
       n_params = sum(v.numel for v in g.trainable_variables())
       n_masked = sum(m.numel for m in g.get_masks())

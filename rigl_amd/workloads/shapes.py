@@ -126,3 +126,35 @@ def resnet50_macs_per_image(num_classes=1000):
     hw = out
   fwd += 2048 * num_classes
   return fwd, fwd - stem
+
+
+def resnet50_layerwise_bound(batch, mfma_flops=2.5e15, hbm_bytes=8.0e12, num_classes=1000):
+  """Per-layer roofline of the conv path, summed: every conv's fwd, dgrad and wgrad is charged
+  max(2*MACs / MFMA peak, algorithmic bytes / HBM peak) -- bf16 activations in and out once,
+  bf16 weights (fp32 dW for wgrad).  ResNet-50's 1x1 convs sit below the machine balance
+  (312 flop/B), so the whole-net bound is well above total-flops / MFMA-peak.
+  Returns (bound_s, mfma_only_s, hbm_only_s) for one step of `batch` images on one GPU."""
+  layers = [(7, 3, 64, 224, 112, False)]          # (k, cin, cout, in_res, out_res, has_dgrad)
+  hw = 56
+  for _, _, convs in resnet50_blocks():
+    stride = [c.stride for c in convs if c.role == 'c2'][0]
+    out = hw // stride
+    for c in convs:
+      res_out = hw if c.role == 'c1' else out
+      res_in = res_out if c.k == 1 else hw        # a strided 1x1 only needs the rows it samples
+      layers.append((c.k, c.cin, c.cout, res_in, res_out, True))
+    hw = out
+  layers.append((1, 2048, num_classes, 1, 1, True))
+  bound = t_mfma = t_hbm = 0.0
+  for k, cin, cout, ri, ro, has_dgrad in layers:
+    flops = 2.0 * batch * ro * ro * k * k * cin * cout
+    act = 2.0 * batch * (ri * ri * cin + ro * ro * cout)
+    w = k * k * cin * cout
+    for wbytes, on in ((2 * w, True), (2 * w, has_dgrad), (4 * w, True)):   # fwd, dgrad, wgrad
+      if not on:
+        continue
+      tc, tm = flops / mfma_flops, (act + wbytes) / hbm_bytes
+      bound += max(tc, tm)
+      t_mfma += tc
+      t_hbm += tm
+  return bound, t_mfma, t_hbm
