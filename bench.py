@@ -120,6 +120,27 @@ def main():
     ops.prof_enable(False)
     prof = ops.prof_collect()
   masks_same = sync.check_masks_identical() if sync is not None else None   # after the timed region: replicas must agree
+  # C1 on its own, after the timed region: the gradient arena all-reduced in GradSync's buckets, nothing
+  # to overlap with -- what the step would pay if none of it hid behind the backward pass.
+  ar = None
+  if sync is not None:
+    buf = torch.zeros_like(g.G)
+    be = sync.bucket_elems
+    chunks = [buf[i:i + be] for i in range(0, buf.numel(), be)]
+    for rep in range(6):
+      if rep == 1:                          # first repetition warms the communicator up
+        fence()
+        ta = time.perf_counter()
+      for h in [dist.all_reduce(c, async_op=True) for c in chunks]:
+        h.wait()
+    fence()
+    t_ar = (time.perf_counter() - ta) / 5
+    nbytes = buf.numel() * 4
+    ar = {'bytes': nbytes, 'buckets': len(chunks), 'ms': t_ar * 1e3,
+          'bus_GBps': 2.0 * (world - 1) / world * nbytes / t_ar / 1e9, 'peak_GBps': 7 * 153.0,
+          'note': 'fp32 gradient arena, bucketed all-reduce alone (outside the timed region); bus = 2(N-1)/N x bytes / time, '
+                  'peak = 7 xGMI links x 153 GB/s per GPU'}
+    del buf, chunks
   t = torch.tensor([dt], dtype=torch.float64, device=dev)
   if world > 1:
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -142,6 +163,8 @@ def main():
                    'parallelism': 'dp%d' % world, 'mask_updates_in_timed_region': n_updates,
                    'masks_identical_across_ranks': masks_same},
     }
+    if ar is not None:
+      out['allreduce'] = ar
     if prof is not None:
       conv_ms = sum(prof[k][0] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'conv_bwd'))
       launches = sum(prof[k][1] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'conv_bwd'))

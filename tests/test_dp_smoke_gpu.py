@@ -27,3 +27,4 @@ def test_two_ranks_on_one_gpu_keep_identical_masks():
   assert d['config']['mask_updates_in_timed_region'] == 1          # step 0 is a mask update (begin_step = 0)
   assert d['config']['masks_identical_across_ranks'] is True
   assert d['value'] > 0 and d['roofline']['frac'] > 0
+  assert d['allreduce']['bytes'] > 4 * 25_000_000 and d['allreduce']['bus_GBps'] > 0 and d['allreduce']['buckets'] >= 3
