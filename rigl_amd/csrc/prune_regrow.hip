@@ -52,7 +52,8 @@ struct SelState {
   uint32_t T;
   uint32_t r;
   uint32_t mode;  // 0 = threshold select, 1 = select none, 2 = select all
-  uint32_t pad[3];
+  uint32_t ties;  // number of keys equal to T (r of them are admitted, in index order)
+  uint32_t pad[2];
 };
 
 struct LayerState {
@@ -183,12 +184,15 @@ __device__ __forceinline__ void hist_clear(uint32_t* h) {
 // Histogram increment with wave-level aggregation of the dominant bins.  RigL's scores are
 // degenerate by construction -- |mask*w| is exactly 0 for the 80-99 % inactive weights and every
 // kept weight's lifted grow score is one sentinel value -- so most lanes of a wave would hit ONE
-// LDS address and the atomics serialise.  Two rounds of "everyone who shares the first active
-// lane's bin adds through that lane" absorb the hot bins; what is left is spread out.  Safe under
+// LDS address and the atomics serialise.  A round of "everyone who shares the first active
+// lane's bin adds through that lane" absorbs the hot bin; what is left is spread out.  Safe under
 // divergence: ballot / readlane only involve the lanes that reach the call.
 __device__ __forceinline__ void hist_add(uint32_t* h, bool ok, uint32_t bin) {
+#ifndef RIGL_K2_HIST_ROUNDS
+#define RIGL_K2_HIST_ROUNDS 1   // measured on ResNet-50: 1 round 420 us per update, 2 rounds 433, 3 rounds 451
+#endif
 #pragma unroll
-  for (int round = 0; round < 2; ++round) {
+  for (int round = 0; round < RIGL_K2_HIST_ROUNDS; ++round) {
     const uint64_t act = __ballot(ok);
     if (act == 0) return;
     const int leader = __ffsll((unsigned long long)act) - 1;
@@ -388,6 +392,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const LayerDev* __restrict__ Ls,
         k = S.n_prune;
       }
       sel.prefix = 0u;
+      sel.ties = 0u;
       if (k <= 0) { sel.mode = 1u; sel.T = 0xFFFFFFFFu; sel.r = 0u; sel.k_rem = 0u; }
       else if (k >= L.n) { sel.mode = 2u; sel.T = 0u; sel.r = (uint32_t)L.n; sel.k_rem = 0u; }
       else { sel.mode = 0u; sel.k_rem = (uint32_t)k; }
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const LayerDev* __restrict__ Ls,
         const uint32_t krem = k - acc;  // 1..c
         if (P == 0) sel.prefix = bin;
         else if (P == 1) sel.prefix = (sel.prefix << 11) | bin;
-        else { sel.T = (sel.prefix << 10) | bin; sel.r = krem; }
+        else { sel.T = (sel.prefix << 10) | bin; sel.r = krem; sel.ties = c; }
         sel.k_rem = krem;
         break;
       }
@@ -447,10 +452,17 @@ __global__ __launch_bounds__(BLOCK) void k_tiecount(const LayerDev* __restrict__
   const LayerState& S = St[li];
   const SelState sel = WHICH ? S.g : S.d;
   const uint32_t cl = blockIdx.x - L.chunk_begin;
+  // Index ranks of the ties only matter when some of them are left out (r < ties).  With
+  // continuous scores the threshold is usually a single key: nothing to count, no data read,
+  // and the zero makes the apply pass admit every tie of the chunk.
+  if (!(sel.mode == 0u && sel.r < sel.ties)) {
+    if (threadIdx.x == 0) tie_cnt[blockIdx.x] = 0u;
+    return;
+  }
   if (threadIdx.x == 0) s_cnt = 0u;
   __syncthreads();
   uint32_t cnt = 0u;
-  if (sel.mode == 0u) {
+  {
 #pragma unroll
     for (int j = 0; j < SEGS; ++j) {
       Pos q = quad_pos(L.n, cl, j);
@@ -493,55 +505,77 @@ __global__ __launch_bounds__(BLOCK) void k_tiescan(const LayerDev* __restrict__ 
 }
 
 // mask1 = top-n_keep of the drop scores; fused with pass A of the grow select.
+// Like the histogram passes, a workgroup walks a contiguous range of chunks and publishes its LDS
+// histogram once per layer: one chunk per workgroup meant ~100 global atomics from each of a layer's
+// up to 576 workgroups onto the same ~100 addresses, and those serialise.
 template <bool WITH_GROW>
 __global__ __launch_bounds__(BLOCK) void k_apply1(const LayerDev* __restrict__ Ls, LayerState* __restrict__ St,
                                                   int n_layers, const uint32_t* __restrict__ tie_cnt,
-                                                  const uint32_t* __restrict__ tie_off) {
+                                                  const uint32_t* __restrict__ tie_off, uint32_t total_chunks) {
   __shared__ uint32_t h[NB];
   __shared__ uint32_t sh[BLOCK];
-  const int li = find_layer(Ls, n_layers, blockIdx.x);
-  const LayerDev L = Ls[li];
-  LayerState& S = St[li];
-  const SelState sel = S.d;
-  const uint32_t cl = blockIdx.x - L.chunk_begin;
-  if (WITH_GROW) { hist_clear(h); }
-  uint32_t key[SEGS][4], tie_nib[SEGS], rank_base[SEGS];
-  Pos q[SEGS];
-#pragma unroll
-  for (int j = 0; j < SEGS; ++j) {
-    q[j] = quad_pos(L.n, cl, j);
-    tie_nib[j] = 0u;
-    if (q[j].nvalid) {
-      uint32_t nib = L.sdrop ? 0u : load_nibble(L.mask, q[j]);
-      drop_keys(L, q[j], nib, key[j]);
-#pragma unroll
-      for (int v = 0; v < VEC; ++v)
-        tie_nib[j] |= ((v < q[j].nvalid && key[j][v] == sel.T) ? 1u : 0u) << v;
-    }
+  uint32_t c0, c1;
+  chunk_range(total_chunks, &c0, &c1);
+  if (c0 >= c1) return;
+  int li = find_layer(Ls, n_layers, c0);
+  if (WITH_GROW) {
+    hist_clear(h);
+    __syncthreads();
   }
-  const uint32_t c_ties = sel.mode == 0u ? tie_cnt[blockIdx.x] : 0u;
-  const uint32_t c_off = sel.mode == 0u ? tie_off[blockIdx.x] : 0u;
-  tie_rank_bases(tie_nib, c_off, c_ties, sel.r, sh, rank_base);
-  __syncthreads();
+  for (uint32_t c = c0;; ++c) {
+    const bool done = c >= c1;
+    if (done || c >= Ls[li].chunk_begin + Ls[li].n_chunks) {
+      if (WITH_GROW) {
+        __syncthreads();
+        hist_flush(h, St[li].hist);
+      }
+      if (done) break;
+      if (WITH_GROW) {
+        __syncthreads();
+        hist_clear(h);
+        __syncthreads();
+      }
+      li = find_layer(Ls, n_layers, c);
+    }
+    const LayerDev L = Ls[li];
+    const LayerState& S = St[li];
+    const SelState sel = S.d;
+    const uint32_t lifted = S.lifted_key;
+    const uint32_t cl = c - L.chunk_begin;
+    uint32_t key[SEGS][4], tie_nib[SEGS], rank_base[SEGS];
+    Pos q[SEGS];
 #pragma unroll
-  for (int j = 0; j < SEGS; ++j) {
-    uint32_t in1 = q[j].nvalid ? select_nibble(key[j], q[j].nvalid, sel, rank_base[j]) : 0u;
-    store_nibble(L.mask1, q[j], in1);
-    if (WITH_GROW && q[j].nvalid) {
-      uint32_t gk[4];
-      grow_scores(L, q[j], gk);
+    for (int j = 0; j < SEGS; ++j) {
+      q[j] = quad_pos(L.n, cl, j);
+      tie_nib[j] = 0u;
+      if (q[j].nvalid) {
+        uint32_t nib = L.sdrop ? 0u : load_nibble(L.mask, q[j]);
+        drop_keys(L, q[j], nib, key[j]);
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        if (v < q[j].nvalid) {
-          uint32_t k2 = ((in1 >> v) & 1u) ? S.lifted_key : gk[v];
-          hist_add(h, true, k2 >> 21);
+        for (int v = 0; v < VEC; ++v)
+          tie_nib[j] |= ((v < q[j].nvalid && key[j][v] == sel.T) ? 1u : 0u) << v;
+      }
+    }
+    const uint32_t c_ties = sel.mode == 0u ? tie_cnt[c] : 0u;
+    const uint32_t c_off = sel.mode == 0u ? tie_off[c] : 0u;
+    tie_rank_bases(tie_nib, c_off, c_ties, sel.r, sh, rank_base);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SEGS; ++j) {
+      uint32_t in1 = q[j].nvalid ? select_nibble(key[j], q[j].nvalid, sel, rank_base[j]) : 0u;
+      store_nibble(L.mask1, q[j], in1);
+      if (WITH_GROW && q[j].nvalid) {
+        uint32_t gk[4];
+        grow_scores(L, q[j], gk);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          if (v < q[j].nvalid) {
+            uint32_t k2 = ((in1 >> v) & 1u) ? lifted : gk[v];
+            hist_add(h, true, k2 >> 21);
+          }
         }
       }
     }
-  }
-  if (WITH_GROW) {
-    __syncthreads();
-    hist_flush(h, S.hist);
   }
 }
 
@@ -667,10 +701,20 @@ __global__ __launch_bounds__(BLOCK) void k_apply2(const LayerDev* __restrict__ L
     ones += __shfl_xor(ones, off);
     overlap |= __shfl_xor(overlap, off);
   }
+  // one set of global atomics per workgroup (a 2.4 M-weight layer is 576 workgroups on one address)
+  __syncthreads();
   if ((threadIdx.x & 63) == 0) {
-    if (grown) atomicAdd(&S.n_grown, grown);
-    if (ones) atomicAdd(&S.n_new_ones, ones);
-    if (overlap) atomicOr(&S.overlap, 1u);
+    const int wv = threadIdx.x >> 6;
+    sh[wv * 3 + 0] = grown; sh[wv * 3 + 1] = ones; sh[wv * 3 + 2] = overlap;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t g = 0u, o = 0u, ov = 0u;
+#pragma unroll
+    for (int wv = 0; wv < BLOCK / 64; ++wv) { g += sh[wv * 3 + 0]; o += sh[wv * 3 + 1]; ov |= sh[wv * 3 + 2]; }
+    if (g) atomicAdd(&S.n_grown, g);
+    if (o) atomicAdd(&S.n_new_ones, o);
+    if (ov) atomicOr(&S.overlap, 1u);
   }
 }
 
@@ -786,30 +830,37 @@ static int run(const RiglPruneRegrowLayer* layers, int n_layers, const int64_t* 
 
   ProfScope prof(PROF_PRUNE_REGROW, stream);
   const uint32_t C = lo.total_chunks;
-  static const uint32_t hist_wgs = [] { const char* e = getenv("RIGL_K2_HIST_WGS"); return (uint32_t)(e ? atoi(e) : 1024); }();
-  const uint32_t HG = C < hist_wgs ? C : hist_wgs;      // workgroups of the histogram passes
+  // Workgroups of the histogram passes.  The first digit pass histograms every active weight and flushes
+  // ~100 bins per workgroup and layer (fewer, fatter workgroups win); the refinement passes only count the
+  // keys under the chosen prefix, are pure streaming, and want more loads in flight.
+  static const uint32_t hist_wgs = [] { const char* e = getenv("RIGL_K2_HIST_WGS"); return (uint32_t)(e ? atoi(e) : 1536); }();
+  static const uint32_t refine_wgs = [] { const char* e = getenv("RIGL_K2_REFINE_WGS"); return (uint32_t)(e ? atoi(e) : 2048); }();
+  static const uint32_t apply_wgs = [] { const char* e = getenv("RIGL_K2_APPLY_WGS"); return (uint32_t)(e ? atoi(e) : 4096); }();
+  const uint32_t HG = C < hist_wgs ? C : hist_wgs;
+  const uint32_t HR = C < refine_wgs ? C : refine_wgs;
+  const uint32_t HA = C < apply_wgs ? C : apply_wgs;     // k_apply1 (it also builds the first grow histogram)
   hipLaunchKernelGGL(k_init_state, dim3(n_layers), dim3(256), 0, stream, dS, n_layers);
   if (C == 0) { RIGL_CHECK_LAUNCH("k_init_state"); return RIGL_OK; }
   // ---- drop selection -------------------------------------------------------
   hipLaunchKernelGGL(k_drop_hist<0>, dim3(HG), dim3(BLOCK), 0, stream, dL, dS, n_layers, C);
   hipLaunchKernelGGL((k_scan<0, 0>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
-  hipLaunchKernelGGL(k_drop_hist<1>, dim3(HG), dim3(BLOCK), 0, stream, dL, dS, n_layers, C);
+  hipLaunchKernelGGL(k_drop_hist<1>, dim3(HR), dim3(BLOCK), 0, stream, dL, dS, n_layers, C);
   hipLaunchKernelGGL((k_scan<0, 1>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
-  hipLaunchKernelGGL(k_drop_hist<2>, dim3(HG), dim3(BLOCK), 0, stream, dL, dS, n_layers, C);
+  hipLaunchKernelGGL(k_drop_hist<2>, dim3(HR), dim3(BLOCK), 0, stream, dL, dS, n_layers, C);
   hipLaunchKernelGGL((k_scan<0, 2>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
   hipLaunchKernelGGL(k_tiecount<0>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers, tie_cnt);
   hipLaunchKernelGGL(k_tiescan, dim3(n_layers), dim3(BLOCK), 0, stream, dL, tie_cnt, tie_off);
   if (!with_grow) {
-    hipLaunchKernelGGL(k_apply1<false>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers, tie_cnt, tie_off);
+    hipLaunchKernelGGL(k_apply1<false>, dim3(HA), dim3(BLOCK), 0, stream, dL, dS, n_layers, tie_cnt, tie_off, C);
     RIGL_CHECK_LAUNCH("topk_mask");
     return RIGL_OK;
   }
-  hipLaunchKernelGGL(k_apply1<true>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers, tie_cnt, tie_off);
+  hipLaunchKernelGGL(k_apply1<true>, dim3(HA), dim3(BLOCK), 0, stream, dL, dS, n_layers, tie_cnt, tie_off, C);
   // ---- grow selection -------------------------------------------------------
   hipLaunchKernelGGL((k_scan<1, 0>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
-  hipLaunchKernelGGL(k_grow_hist<1>, dim3(HG), dim3(BLOCK), 0, stream, dL, dS, n_layers, C);
+  hipLaunchKernelGGL(k_grow_hist<1>, dim3(HR), dim3(BLOCK), 0, stream, dL, dS, n_layers, C);
   hipLaunchKernelGGL((k_scan<1, 1>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
-  hipLaunchKernelGGL(k_grow_hist<2>, dim3(HG), dim3(BLOCK), 0, stream, dL, dS, n_layers, C);
+  hipLaunchKernelGGL(k_grow_hist<2>, dim3(HR), dim3(BLOCK), 0, stream, dL, dS, n_layers, C);
   hipLaunchKernelGGL((k_scan<1, 2>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
   hipLaunchKernelGGL(k_tiecount<1>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers, tie_cnt);
   hipLaunchKernelGGL(k_tiescan, dim3(n_layers), dim3(BLOCK), 0, stream, dL, tie_cnt, tie_off);
