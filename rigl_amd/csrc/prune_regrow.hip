@@ -294,6 +294,7 @@ template <int P>
 __global__ __launch_bounds__(BLOCK) void k_drop_hist(const LayerDev* __restrict__ Ls, LayerState* __restrict__ St,
                                                      int n_layers, uint32_t total_chunks) {
   __shared__ uint32_t h[NB];
+  __shared__ uint32_t s_red[2 * (BLOCK / 64)];
   uint32_t c0, c1;
   chunk_range(total_chunks, &c0, &c1);
   if (c0 >= c1) return;
@@ -312,9 +313,14 @@ __global__ __launch_bounds__(BLOCK) void k_drop_hist(const LayerDev* __restrict_
           ones += __shfl_xor(ones, off);
           gmin = min(gmin, __shfl_xor(gmin, off));
         }
-        if ((threadIdx.x & 63) == 0) {
-          if (ones) atomicAdd(&S0.n_ones, ones);
-          if (Ls[li].fixed_k < 0) atomicMin(&S0.gmin_key, gmin);
+        if ((threadIdx.x & 63) == 0) { s_red[(threadIdx.x >> 6) * 2] = ones; s_red[(threadIdx.x >> 6) * 2 + 1] = gmin; }
+        __syncthreads();
+        if (threadIdx.x == 0) {      // one pair of global atomics per workgroup: same-address atomics serialise
+          uint32_t o = 0u, gm = 0xFFFFFFFFu;
+#pragma unroll
+          for (int wv = 0; wv < BLOCK / 64; ++wv) { o += s_red[wv * 2]; gm = min(gm, s_red[wv * 2 + 1]); }
+          if (o) atomicAdd(&S0.n_ones, o);
+          if (Ls[li].fixed_k < 0) atomicMin(&S0.gmin_key, gm);
         }
         ones = 0u; gmin = 0xFFFFFFFFu;
       }
