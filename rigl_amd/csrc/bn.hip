@@ -278,7 +278,10 @@ static Geom make_geom(int64_t m, int c) {
   int tpr = 1;
   while (tpr < g.cg && tpr < THREADS) tpr <<= 1;
   g.tpr = tpr; g.rpb = THREADS / tpr;
-  int64_t parts = (m + (int64_t)g.rpb * 16 - 1) / ((int64_t)g.rpb * 16);   // >= 16 rows per row-lane
+#ifndef RIGL_BN_ROWS_PER_LANE
+#define RIGL_BN_ROWS_PER_LANE 8    // 16 left the 14x14 layers with 196 workgroups for 256 CUs (19.9 -> 18.1 us)
+#endif
+  int64_t parts = (m + (int64_t)g.rpb * RIGL_BN_ROWS_PER_LANE - 1) / ((int64_t)g.rpb * RIGL_BN_ROWS_PER_LANE);   // rows per row-lane
   if (parts > MAX_PARTS) parts = MAX_PARTS;
   if (parts < 1) parts = 1;
   int64_t rpp = (m + parts - 1) / parts;
