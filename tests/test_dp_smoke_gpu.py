@@ -28,3 +28,30 @@ def test_two_ranks_on_one_gpu_keep_identical_masks():
   assert d['config']['masks_identical_across_ranks'] is True
   assert d['value'] > 0 and d['roofline']['frac'] > 0
   assert d['allreduce']['bytes'] > 4 * 25_000_000 and d['allreduce']['bus_GBps'] > 0 and d['allreduce']['buckets'] >= 3
+
+
+@pytest.mark.gpu
+def test_bench_contract_single_gpu():
+  """The JSON line the driver parses: contract keys, the roofline and cpu_baseline objects."""
+  cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '1', '--prof-every', '2']
+  out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+  assert out.returncode == 0, out.stderr[-2000:]
+  lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1                                   # exactly one JSON line
+  d = json.loads(lines[0])
+  for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+            'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+    assert k in d, k
+  assert d['n_gpus'] == 1 and d['steps'] == 4 and d['warmup'] == 1 and d['unit'] == 'images/sec'
+  assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+  assert d['dtype'] == 'bf16' and d['data'] == 'synthetic' and 'workload' in d['config']
+  assert abs(d['value'] - d['config']['global_batch'] * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+  r = d['roofline']
+  for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+    assert k in r, k
+  assert r['bound'] == 'mfma' and r['peak'] == 2500.0 and r['unit'] == 'TFLOP/s'
+  assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0.0 < r['frac'] < r['layerwise_bound']['mfma_only_ms'] / r['layerwise_bound']['ms_per_step']
+  c = d['cpu_baseline']
+  for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+    assert k in c, k
+  assert c['kind'] == 'port' and c['value'] > 0 and c['cores'] >= 1
