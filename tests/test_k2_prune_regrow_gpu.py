@@ -178,6 +178,37 @@ def test_topk_mask():
     _diff('topk n=%d k=%d' % (n, k), got, ref)
 
 
+@pytest.mark.parametrize('ties', [2, 5, 130, 9000])
+def test_topk_threshold_admits_all_some_or_one_of_its_ties(ties):
+  """The tie-rank pass is skipped when the threshold key admits ALL of its duplicates (r == ties) and must
+  run when only some are admitted (r < ties): plant `ties` copies of one value -- scattered over several
+  4096-element chunks, some sharing a 4-element quad -- in otherwise distinct scores and cut at every
+  interesting rank."""
+  from rigl_amd import ops
+  rs = np.random.RandomState(ties)
+  n = 50021
+  s = rs.permutation(n).astype(np.float32) + 1000.0           # distinct, all above / below the planted value
+  pos = np.sort(rs.choice(n - 8, size=ties, replace=False))
+  pos[:min(ties, 3)] = pos[0] - pos[0] % 4 + np.arange(min(ties, 3))   # a few ties inside one quad
+  pos = np.unique(pos)
+  ties = pos.size
+  n_above = 20000
+  order = rs.permutation(np.setdiff1d(np.arange(n), pos))
+  s[order[:n_above]] += 1e6                                   # exactly n_above scores above the planted value
+  s[order[n_above:]] -= 1e6 + 2000.0
+  s[pos] = 777.0
+  for k in (n_above, n_above + 1, n_above + ties - 1, n_above + ties, n_above + ties + 1, n_above + ties // 2):
+    bits = ops.topk_mask(_t(s), k)
+    got = ops.mask_unpack(bits, (n,)).cpu().numpy()
+    ref = np.zeros(n, np.float32)
+    ref[O.topk_order(s)[:k]] = 1
+    _diff('ties=%d k=%d' % (ties, k), got, ref)
+    admitted = int(got[pos].sum())
+    assert admitted == min(max(k - n_above, 0), ties)
+    if 0 < admitted < ties:
+      np.testing.assert_array_equal(np.nonzero(got[pos])[0], np.arange(admitted))   # lowest indices win
+
+
 def test_mask_pack_roundtrip_and_layout():
   from rigl_amd import ops
   rs = np.random.RandomState(0)
