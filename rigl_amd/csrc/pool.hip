@@ -121,6 +121,50 @@ __global__ __launch_bounds__(THREADS) void k_bwd(Geom G, const uint16_t* __restr
   }
 }
 
+// The ResNet case (3x3 window, stride 2) with compile-time window constants and 32-bit index math: the
+// generic kernel above spends its time in runtime divisions (151 us for the 205 MB stem gradient; this one 2x faster).
+// A pixel belongs to <= 2 x 2 windows: r = (h + pt) & 1, r + 2 while r < 3 (same for s).
+__global__ __launch_bounds__(THREADS) void k_bwd_3x3s2(Geom G, const uint16_t* __restrict__ dy,
+                                                        const uint8_t* __restrict__ idx, uint16_t* __restrict__ dx) {
+  const uint32_t total = (uint32_t)G.n * G.h * G.w * G.cg;     // < 2^31, checked by the caller
+  for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < total; i += gridDim.x * THREADS) {
+    const uint32_t cgi = i % (uint32_t)G.cg;
+    uint32_t p = i / (uint32_t)G.cg;
+    const int w = (int)(p % (uint32_t)G.w); p /= (uint32_t)G.w;
+    const int h = (int)(p % (uint32_t)G.h);
+    const int n = (int)(p / (uint32_t)G.h);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const int hp = h + G.pt, wp = w + G.pl;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int r = (hp & 1) + 2 * a, ho = (hp - r) >> 1;
+      if (r > 2 || hp < r || ho >= G.ho) continue;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int s = (wp & 1) + 2 * b, wo = (wp - s) >> 1;
+        if (s > 2 || wp < s || wo >= G.wo) continue;
+        const uint32_t o = ((uint32_t)(n * G.ho + ho) * (uint32_t)G.wo + (uint32_t)wo) * (uint32_t)G.cg + cgi;
+        const uint2 av = *reinterpret_cast<const uint2*>(idx + (size_t)o * 8);
+        const uint4 v = *reinterpret_cast<const uint4*>(dy + (size_t)o * 8);
+        float f[8];
+        unpack8(v, f);
+        const uint32_t code = (uint32_t)(r * 3 + s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t aj = ((j < 4 ? av.x : av.y) >> (8 * (j & 3))) & 0xFFu;
+          if (aj == code) acc[j] += f[j];
+        }
+      }
+    }
+    uint4 out;
+    out.x = f2bf(acc[0]) | (f2bf(acc[1]) << 16); out.y = f2bf(acc[2]) | (f2bf(acc[3]) << 16);
+    out.z = f2bf(acc[4]) | (f2bf(acc[5]) << 16); out.w = f2bf(acc[6]) | (f2bf(acc[7]) << 16);
+    *reinterpret_cast<uint4*>(dx + (size_t)i * 8) = out;
+  }
+}
+
 static int make_geom(const RiglConvDesc* d, Geom* g, const char* who) {
   if (!d) return fail(RIGL_EINVAL, "%s: NULL descriptor", who);
   if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->ho <= 0 || d->wo <= 0 || d->kh <= 0 || d->kw <= 0 ||
@@ -171,7 +215,11 @@ int rigl_maxpool_bwd(const RiglConvDesc* d, const rigl_bf16* dy, const uint8_t* 
   if (rc) return rc;
   if (!dy || !dx || !argmax) return fail(RIGL_EINVAL, "rigl_maxpool_bwd: NULL tensor");
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(k_bwd, dim3(grid_for((int64_t)g.n * g.h * g.w * g.cg)), dim3(THREADS), 0, st, g, dy, argmax, dx);
+  const int64_t items = (int64_t)g.n * g.h * g.w * g.cg;
+  if (g.kh == 3 && g.kw == 3 && g.sh == 2 && g.sw == 2 && items < (int64_t(1) << 31))
+    hipLaunchKernelGGL(k_bwd_3x3s2, dim3(grid_for(items)), dim3(THREADS), 0, st, g, dy, argmax, dx);
+  else
+    hipLaunchKernelGGL(k_bwd, dim3(grid_for(items)), dim3(THREADS), 0, st, g, dy, argmax, dx);
   RIGL_CHECK_LAUNCH("rigl_maxpool_bwd");
   return RIGL_OK;
 }
