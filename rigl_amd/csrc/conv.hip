@@ -147,21 +147,25 @@ struct IgemmArgs {
 // depth 2 (32 KB: with the 128-VGPR cap of k_igemm_w4 that is 4 workgroups per CU, for short reductions).
 // LDS bytes of one igemm workgroup (the kernels own the array; igemm_body gets a pointer so that
 // a fused launch can run it next to another body in the same allocation).
-template <int TM, int TN, int BK, int MODE, bool OUT_F32, bool CLS, int STAGES>
+// WM = wave rows of the workgroup (2 x WM waves of TM x TN 32x32 tiles each): 2 -> 256 threads, BM = 64*TM;
+// 4 -> 512 threads, BM = 128*TM (the 256x128 tile: 24 KB of operands per K-tile for twice the MFMA work).
+template <int TM, int TN, int BK, int MODE, bool OUT_F32, bool CLS, int STAGES, int WM = 2>
 constexpr int igemm_smem_bytes() {
   constexpr int NST = (STAGES == 22) ? 2 : STAGES;
-  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int NT = 128 * WM;
+  constexpr int BM = 32 * WM * TM, BN = 64 * TN;
   constexpr int STAGE = (BM + BN) * BK * 2;
   constexpr int EPI = OUT_F32 ? 0 : BM * (BN + 8) * 2;
   constexpr int EPI_TAB = EPI + (CLS ? BM * 4 : 0);
-  constexpr int EPI_ALL = EPI_TAB + ((MODE == 0 && !OUT_F32) ? THREADS * 8 : 0);
+  constexpr int EPI_ALL = EPI_TAB + ((MODE == 0 && !OUT_F32) ? NT * 8 : 0);
   return (NST * STAGE > EPI_ALL) ? NST * STAGE : EPI_ALL;
 }
 
-template <int TM, int TN, int BK, int MODE /*0 fwd, 1 dgrad*/, bool OUT_F32, bool CLS, int STAGES>
+template <int TM, int TN, int BK, int MODE /*0 fwd, 1 dgrad*/, bool OUT_F32, bool CLS, int STAGES, int WM = 2>
 __device__ __forceinline__ void igemm_body(const IgemmArgs& P, unsigned char* smem, uint32_t bid, uint32_t nblk) {
   constexpr int NST = (STAGES == 22) ? 2 : STAGES;
-  constexpr int BM = 64 * TM, BN = 64 * TN, CPR = BK / 8, RPP = THREADS / CPR;
+  constexpr int THREADS = 128 * WM;        // (shadows the file-wide 256 inside this body)
+  constexpr int BM = 32 * WM * TM, BN = 64 * TN, CPR = BK / 8, RPP = THREADS / CPR;
   constexpr int APASS = (BM + RPP - 1) / RPP, BPASS = (BN + RPP - 1) / RPP;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int CS_LD = BN + 8;
@@ -169,9 +173,9 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P, unsigned char* sm
   constexpr int EPI_TAB = EPI + (CLS ? BM * 4 : 0);       // + per-row output pixel table
   constexpr int EPI_ALL = EPI_TAB + ((MODE == 0 && !OUT_F32) ? THREADS * 8 : 0);   // + column-statistics scratch
   constexpr int SMEM = (NST * STAGE > EPI_ALL) ? NST * STAGE : EPI_ALL;
-  static_assert(SMEM <= 65536, "static LDS limit");
+  static_assert(SMEM <= 65536 || WM == 4, "static LDS limit (the 512-thread variant uses dynamic LDS)");
   static_assert(STAGES == 2 || (BM % RPP == 0 && BN % RPP == 0), "LDS-DMA needs whole 1-KB wave rows");
-  static_assert(SMEM == igemm_smem_bytes<TM, TN, BK, MODE, OUT_F32, CLS, STAGES>(), "LDS size formula out of sync");
+  static_assert(SMEM == igemm_smem_bytes<TM, TN, BK, MODE, OUT_F32, CLS, STAGES, WM>(), "LDS size formula out of sync");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -517,7 +521,9 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P, unsigned char* sm
       // Batch-norm statistics of this row tile, from the bf16-rounded outputs the BN will
       // read: PARTS row-slices per column, combined in a fixed order (deterministic).
       // Rows beyond M hold exact zeros (their gathers were zero-filled).
-      constexpr int PARTS = THREADS / BN, RPS = BM / PARTS;
+      // One partial row per 128 output rows whatever the tile height (the batch-norm side counts
+      // ceil(M / 128) of them), each the same slice-by-slice sum: a 256-row tile writes two.
+      constexpr int PARTS = THREADS / BN, RPS = BM / PARTS, UNITS = BM / 128, SPU = PARTS / UNITS;
       const int col = tid % BN, part = tid / BN;
       float sy = 0.f, sq = 0.f;
 #pragma unroll 8
@@ -528,10 +534,11 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P, unsigned char* sm
       float2* red = reinterpret_cast<float2*>(smem + EPI_TAB);
       red[tid] = make_float2(sy, sq);
       __syncthreads();
-      if (part == 0 && n0 + col < P.N) {
+      const int unit = tile_m * UNITS + part / SPU;
+      if (part % SPU == 0 && n0 + col < P.N && (int64_t)unit * 128 < P.M) {
 #pragma unroll
-        for (int k = 1; k < PARTS; ++k) { sy += red[k * BN + col].x; sq += red[k * BN + col].y; }
-        float* st = P.STATS + (int64_t)tile_m * 2 * P.N + n0 + col;
+        for (int k = 1; k < SPU; ++k) { sy += red[(part + k) * BN + col].x; sq += red[(part + k) * BN + col].y; }
+        float* st = P.STATS + (int64_t)unit * 2 * P.N + n0 + col;
         st[0] = sy; st[P.N] = sq;
       }
     }
@@ -570,6 +577,12 @@ template <int TM, int TN, int BK, int MODE, bool OUT_F32, bool CLS, int STAGES>
 __global__ __launch_bounds__(THREADS) void k_igemm(IgemmArgs P) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[igemm_smem_bytes<TM, TN, BK, MODE, OUT_F32, CLS, STAGES>()];
   igemm_body<TM, TN, BK, MODE, OUT_F32, CLS, STAGES>(P, smem, blockIdx.x, gridDim.x);
+}
+// 256x128 tile, 8 waves (4 x 2), 3-deep DMA ring: 72 KB of dynamic LDS, 2 workgroups per CU.
+template <int MODE, bool CLS>
+__global__ __launch_bounds__(512) void k_igemm_big(IgemmArgs P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_big[];
+  igemm_body<2, 2, 32, MODE, false, CLS, 3, 4>(P, smem_big, blockIdx.x, gridDim.x);
 }
 // Same body compiled for 4 waves per SIMD (<= 128 VGPRs): with the 2-deep ring's 35 KB of LDS that
 // is 4 workgroups per CU for the latency-bound short reductions.
@@ -1175,7 +1188,17 @@ static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, int bk, b
   }
 }
 
-struct IgemmPlan { bool wide_n, dma, w4, cls; int bk; unsigned grid; };
+struct IgemmPlan { bool wide_n, dma, w4, cls, big; int bk; unsigned grid; };
+
+static int num_cus();
+// The 512-thread kernel needs 72 KB of dynamic LDS: opt in once; if the runtime refuses, the plan never picks it.
+template <int MODE>
+static bool big_tile_ready() {
+  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm_big<MODE, false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                igemm_smem_bytes<2, 2, 32, MODE, false, false, 3, 4>()) == hipSuccess;
+  return ready;
+}
 
 // Fills the launch-time parts of `a` (fast divisors, tile counts, parity-class tables) and picks the variant.
 template <int MODE>
@@ -1204,6 +1227,7 @@ static IgemmPlan plan_igemm(IgemmArgs& a) {
   static const int w4_kt = [] { const char* e = getenv("RIGL_CONV_W4_KT"); return e ? atoi(e) : 0; }();
   pl.w4 = pl.dma && a.KH * a.KW * ((a.Cred + 31) / 32) <= w4_kt;   // K-tiles of 32
   pl.cls = false;
+  pl.big = false;
   if (MODE == 1 && (a.sh > 1 || a.sw > 1) && a.sh <= 2 && a.sw <= 2) {
     // class-major rows: class c = (h % sh) * sw + (w % sw)
     const int n_img = a.M / (a.RH * a.RW);
@@ -1229,7 +1253,16 @@ static IgemmPlan plan_igemm(IgemmArgs& a) {
     pl.grid = (unsigned)(tiles * a.tiles_n);
     return pl;
   }
-  const int tiles_m = (a.M + BM - 1) / BM;
+  // 256x128 tiles (8 waves) where they turn two rounds of workgroups into one: the 128x128 grid does not fit the
+  // 3 workgroups per CU of its 48 KB ring, the 256x128 grid fits the 2 per CU of its 72 KB -- at batch 128 the
+  // 784-tile layers (28x28x128 3x3 and 512->128, 14x14 1024->512, 7x7 ->2048): -11...-20 % each.  On other
+  // shapes the larger tile is neutral (14x14x256 3x3: 196 workgroups for 256 CUs) or loses (short reductions).
+  // RIGL_CONV_BIG=0 never, =2 wherever it is legal (testing).
+  static const int big_mode = [] { const char* e = getenv("RIGL_CONV_BIG"); return e ? atoi(e) : 1; }();
+  const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + 127) / 128);
+  pl.big = MODE == 0 && big_mode > 0 && big_tile_ready<MODE>() && pl.wide_n && pl.dma && !pl.w4 && a.M >= 256 &&
+           (big_mode == 2 || (tiles128 > 3 * (int64_t)num_cus() && tiles256 <= 2 * (int64_t)num_cus()));
+  const int tiles_m = (a.M + (pl.big ? 256 : BM) - 1) / (pl.big ? 256 : BM);
   pl.grid = (unsigned)(tiles_m * a.tiles_n);
   return pl;
 }
@@ -1238,6 +1271,10 @@ template <int MODE, bool F32>
 static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
   IgemmArgs a = a0;
   const IgemmPlan pl = plan_igemm<MODE>(a);
+  if (!F32 && pl.big) {
+    RIGL_K_LAUNCH((k_igemm_big<MODE, false>), dim3(pl.grid), dim3(512), (igemm_smem_bytes<2, 2, 32, MODE, false, false, 3, 4>()), st, a);
+    return;
+  }
   if (pl.cls) launch_igemm_t<MODE, F32, true>(a, dim3(pl.grid), pl.wide_n, pl.bk, pl.dma, pl.w4, st);
   else launch_igemm_t<MODE, F32, false>(a, dim3(pl.grid), pl.wide_n, pl.bk, pl.dma, pl.w4, st);
 }

@@ -1,6 +1,8 @@
 """Parity of K3 (masked SGD-momentum, bit-exact vs the oracle), the weight
 shadow packer, and K1 (MFMA masked conv fwd/dgrad/wgrad vs an fp32 / fp64
 convolution of the same bf16-rounded operands)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,6 +12,7 @@ import torch.nn.functional as F  # noqa: E402
 from oracle import rigl_oracle as O  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = 'cuda:0'
 
 
@@ -252,6 +255,38 @@ def test_conv_fwd_epilogue_bn_statistics(case):
   rows = yf[t * 128:(t + 1) * 128]
   np.testing.assert_allclose(part[t, 0].double().cpu().numpy(), rows.sum(0).cpu().numpy(), rtol=0,
                              atol=1e-5 * float(rows.abs().sum(0).max()) + 1e-6)
+
+
+@pytest.mark.parametrize('case', [(127, 28, 28, 64, 128, 1, 1, 0, 0, 28, 28),     # 779 tiles of 128x128, ragged last tile
+                                  (32, 56, 56, 32, 128, 3, 1, 1, 1, 56, 56)])     # 784 tiles, 3x3 with halo
+def test_conv_fwd_256x128_tile_is_bit_identical(case):
+  """Forward layers whose 128x128 grid needs a second round of workgroups but whose 256x128 grid does not
+  run the 8-wave 256x128 kernel (RIGL_CONV_BIG default rule).  Same K order per output and the same
+  128-row statistics partials, so outputs and partials must equal the 128x128 kernel's bit for bit --
+  checked in a subprocess with RIGL_CONV_BIG=0, the plan being cached per process."""
+  import json
+  import subprocess
+  import sys
+  N, H, W, Cin, Cout, k, stride, pt, pl, Ho, Wo = case
+  prog = ("import sys, json, hashlib, torch; sys.path.insert(0, %r); from rigl_amd import ops;"
+          "g = torch.Generator().manual_seed(5);"
+          "x = torch.randn(%d, %d, %d, %d, generator=g).to(torch.bfloat16).cuda();"
+          "w = (torch.randn(%d, generator=g) * %r).to(torch.bfloat16).cuda();"
+          "d = ops.conv_desc(%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d);"
+          "y, part = ops.conv_fwd(d, x, w, stats=True); torch.cuda.synchronize();"
+          "h = lambda t: hashlib.sha256(t.contiguous().cpu().numpy().tobytes()).hexdigest();"
+          "print(json.dumps({'y': h(y.view(torch.int16)), 'part': h(part.view(torch.int32)), 'shape': list(part.shape),"
+          " 'absmax': float(y.float().abs().max())}))"
+          % (ROOT, N, H, W, Cin, k * k * Cin * Cout, (2.0 / (k * k * Cin)) ** 0.5,
+             N, H, W, Cin, Cout, k, k, stride, pt, pl, Ho, Wo))
+  outs = {}
+  for big in ('0', '1', '2'):                    # never / the default rule / wherever legal
+    env = dict(os.environ, RIGL_CONV_BIG=big)
+    r = subprocess.run([sys.executable, '-c', prog], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    outs[big] = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+  assert outs['0'] == outs['1'] == outs['2']
+  assert outs['1']['shape'] == [(N * Ho * Wo + 127) // 128, 2, Cout] and outs['1']['absmax'] > 0
 
 
 @pytest.mark.parametrize('case', [CONV_CASES[1], CONV_CASES[4], CONV_CASES[5], CONV_CASES[8], CONV_CASES[15]])
