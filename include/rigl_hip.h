@@ -386,6 +386,23 @@ int rigl_maxpool_fwd(const RiglConvDesc* d, const rigl_bf16* x, rigl_bf16* y,
 int rigl_maxpool_bwd(const RiglConvDesc* d, const rigl_bf16* dy,
                      const uint8_t* argmax, rigl_bf16* dx, rigl_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Glue: classifier head.  Global average pool over `pixels` positions of an
+ * NHWC bf16 map (average_pooling2d + reshape, resnet_model.py:701-712; fp32
+ * accumulation, c even) and tf.losses.softmax_cross_entropy with label
+ * smoothing (imagenet_train_eval.py:578-584) on bf16 logits: row_loss[r] =
+ * -sum_k t_k log softmax(z)_k with t = onehot * (1 - eps) + eps / K, and --
+ * when dlogits is given -- dlogits = bf16((softmax(z) - t) * grad_scale), the
+ * gradient of grad_scale * sum_r row_loss[r] (grad_scale = 1 / rows for the mean).
+ * ---------------------------------------------------------------------- */
+int rigl_global_avgpool_fwd(int32_t n, int32_t pixels, int32_t c, const rigl_bf16* x,
+                            rigl_bf16* y, rigl_stream_t stream);
+int rigl_global_avgpool_bwd(int32_t n, int32_t pixels, int32_t c, const rigl_bf16* dy,
+                            rigl_bf16* dx, rigl_stream_t stream);
+int rigl_softmax_xent(int32_t rows, int32_t classes, const rigl_bf16* logits,
+                      const int64_t* labels, float label_smoothing, float grad_scale,
+                      float* row_loss, rigl_bf16* dlogits /* nullable */, rigl_stream_t stream);
+
 /* Optional per-kernel timing (HIP events recorded on the launch stream around
  * every K1/K2/K3 launch while enabled).  rigl_prof_collect synchronises the
  * recorded events and returns accumulated milliseconds / launch counts per

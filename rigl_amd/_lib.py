@@ -116,6 +116,9 @@ SIGNATURES = {
     'rigl_stateless_random': (C.c_int, [_P, _I64, _I32, _I32, _I32, _F, _F, _P]),
     'rigl_maxpool_fwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     'rigl_maxpool_bwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    'rigl_global_avgpool_fwd': (C.c_int, [_I32, _I32, _I32, _P, _P, _P]),
+    'rigl_global_avgpool_bwd': (C.c_int, [_I32, _I32, _I32, _P, _P, _P]),
+    'rigl_softmax_xent': (C.c_int, [_I32, _I32, _P, _P, _F, _F, _P, _P, _P]),
     'rigl_prof_enable': (C.c_int, [_I32]),
     'rigl_prof_collect': (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64)]),
 }

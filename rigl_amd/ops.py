@@ -559,6 +559,42 @@ def maxpool_bwd(d, dy, arg):
 
 
 # ----------------------------------------------------------------------------
+# classifier head glue
+# ----------------------------------------------------------------------------
+def global_avgpool_fwd(x):
+  """[N, H, W, C] bf16 -> [N, C] bf16, fp32 accumulation."""
+  _req(x, torch.bfloat16, 'x')
+  n, h, w, c = x.shape
+  y = torch.empty((n, c), dtype=torch.bfloat16, device=x.device)
+  check(_lib.load().rigl_global_avgpool_fwd(n, h * w, c, _ptr(x), _ptr(y), _stream()))
+  return y
+
+
+def global_avgpool_bwd(dy, h, w):
+  _req(dy, torch.bfloat16, 'dy')
+  n, c = dy.shape
+  dx = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=dy.device)
+  check(_lib.load().rigl_global_avgpool_bwd(n, h * w, c, _ptr(dy), _ptr(dx), _stream()))
+  return dx
+
+
+def softmax_xent(logits, labels, label_smoothing=0.0, grad_scale=None, want_grad=True):
+  """Per-row cross entropy (fp32 [rows]) of bf16 logits [rows, classes] against int64 labels with label
+  smoothing, and the gradient of ``grad_scale * sum(rows)`` w.r.t. the logits (bf16; default scale 1/rows)."""
+  _req(logits, torch.bfloat16, 'logits')
+  _req(labels, torch.int64, 'labels')
+  rows, k = logits.shape
+  if labels.numel() != rows:
+    raise ValueError('softmax_xent: %d labels for %d rows' % (labels.numel(), rows))
+  loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
+  dz = torch.empty_like(logits) if want_grad else None
+  check(_lib.load().rigl_softmax_xent(rows, k, _ptr(logits), _ptr(labels), float(label_smoothing),
+                                      1.0 / rows if grad_scale is None else float(grad_scale), _ptr(loss), _ptr(dz),
+                                      _stream()))
+  return loss, dz
+
+
+# ----------------------------------------------------------------------------
 # profiling
 # ----------------------------------------------------------------------------
 def prof_enable(on=True):

@@ -6,6 +6,8 @@ PyTorch-ROCm ops on NHWC bf16 tensors.  All tensors here are [N,H,W,C]
 contiguous; PyTorch's NCHW-shaped channels_last view of the same memory is
 used where an op wants NCHW.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -205,9 +207,45 @@ def max_pool_3x3_s2_same(x):
   return nhwc_view(F.max_pool2d(xn, 3, 2))
 
 
+# RIGL_HEAD_TORCH=1: the PyTorch formulation of the classifier head (comparison runs)
+_HEAD_KERNELS = os.environ.get('RIGL_HEAD_TORCH', '0') != '1'
+
+
+class _GlobalAvgPoolFn(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, x):
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    ctx.hw = (x.shape[1], x.shape[2])
+    return ops.global_avgpool_fwd(x.contiguous())
+
+  @staticmethod
+  def backward(ctx, dy):
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    return ops.global_avgpool_bwd(dy.contiguous(), *ctx.hw)
+
+
 def global_avg_pool(x):
   """average_pooling2d over the whole map + reshape (resnet_model.py:701-712)."""
+  if _HEAD_KERNELS and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 2 == 0:
+    return _GlobalAvgPoolFn.apply(x)          # one kernel each way instead of cast + reduce + cast (+ div + cast)
   return x.float().mean(dim=(1, 2)).to(x.dtype)
+
+
+class _SoftmaxXentFn(torch.autograd.Function):
+  """Mean cross entropy with label smoothing; the kernel leaves d(mean loss)/d(logits) next to the row losses."""
+
+  @staticmethod
+  def forward(ctx, logits, labels, label_smoothing):
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    rows, dz = ops.softmax_xent(logits.contiguous(), labels.reshape(-1).contiguous(), label_smoothing)
+    ctx.save_for_backward(dz)
+    return rows.mean()
+
+  @staticmethod
+  def backward(ctx, g):
+    dz, = ctx.saved_tensors
+    return (dz * g.to(dz.dtype)), None, None
 
 
 def softmax_cross_entropy(logits, labels, label_smoothing=0.0):
@@ -217,6 +255,9 @@ def softmax_cross_entropy(logits, labels, label_smoothing=0.0):
   synchronises the device on ROCm (measured, tools/sync_probe.py: the host blocks
   until every queued kernel has finished), which drained the launch queue once
   per step."""
+  if (_HEAD_KERNELS and logits.is_cuda and logits.dtype == torch.bfloat16 and logits.dim() == 2 and
+      labels.dtype == torch.int64):
+    return _SoftmaxXentFn.apply(logits, labels, float(label_smoothing))
   logp = F.log_softmax(logits.float(), dim=-1)
   nll = -logp.gather(1, labels.reshape(-1, 1)).squeeze(1)
   if not label_smoothing:
