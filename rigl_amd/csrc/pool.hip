@@ -121,47 +121,72 @@ __global__ __launch_bounds__(THREADS) void k_bwd(Geom G, const uint16_t* __restr
   }
 }
 
-// The ResNet case (3x3 window, stride 2) with compile-time window constants and 32-bit index math: the
-// generic kernel above spends its time in runtime divisions (151 us for the 205 MB stem gradient; this one 2x faster).
-// A pixel belongs to <= 2 x 2 windows: r = (h + pt) & 1, r + 2 while r < 3 (same for s).
-__global__ __launch_bounds__(THREADS) void k_bwd_3x3s2(Geom G, const uint16_t* __restrict__ dy,
+// The ResNet case (3x3 window, stride 2), one thread per 2x2 block of input pixels (in padded coordinates
+// hp = h + pad_top in {2k, 2k+1}, wp likewise) and 8 channels.  Those four pixels can only be the winners of
+// the four windows (k-1..k) x (l-1..l), so a thread loads 4 (argmax, dy) pairs for 4 outputs where the
+// per-pixel gather loads up to 4 per output (2.25 on average) -- and all window arithmetic is compile-time
+// (the generic kernel above spends its time in runtime divisions: 151 us for the 205 MB stem gradient).
+// Each pixel still adds its candidates in (r, s) ascending order: bit-identical to the generic kernel.
+__global__ __launch_bounds__(THREADS) void k_bwd_3x3s2(Geom G, int kb, int lb, const uint16_t* __restrict__ dy,
                                                         const uint8_t* __restrict__ idx, uint16_t* __restrict__ dx) {
-  const uint32_t total = (uint32_t)G.n * G.h * G.w * G.cg;     // < 2^31, checked by the caller
+  const uint32_t total = (uint32_t)G.n * kb * lb * G.cg;        // < 2^31, checked by the caller
   for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < total; i += gridDim.x * THREADS) {
     const uint32_t cgi = i % (uint32_t)G.cg;
     uint32_t p = i / (uint32_t)G.cg;
-    const int w = (int)(p % (uint32_t)G.w); p /= (uint32_t)G.w;
-    const int h = (int)(p % (uint32_t)G.h);
-    const int n = (int)(p / (uint32_t)G.h);
-    float acc[8];
+    const int l = (int)(p % (uint32_t)lb); p /= (uint32_t)lb;
+    const int k = (int)(p % (uint32_t)kb);
+    const int n = (int)(p / (uint32_t)kb);
+    uint2 av[2][2];
+    float f[2][2][8];
+    bool ok[2][2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    const int hp = h + G.pt, wp = w + G.pl;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int r = (hp & 1) + 2 * a, ho = (hp - r) >> 1;
-      if (r > 2 || hp < r || ho >= G.ho) continue;
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const int s = (wp & 1) + 2 * b, wo = (wp - s) >> 1;
-        if (s > 2 || wp < s || wo >= G.wo) continue;
-        const uint32_t o = ((uint32_t)(n * G.ho + ho) * (uint32_t)G.wo + (uint32_t)wo) * (uint32_t)G.cg + cgi;
-        const uint2 av = *reinterpret_cast<const uint2*>(idx + (size_t)o * 8);
-        const uint4 v = *reinterpret_cast<const uint4*>(dy + (size_t)o * 8);
-        float f[8];
-        unpack8(v, f);
-        const uint32_t code = (uint32_t)(r * 3 + s);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const uint32_t aj = ((j < 4 ? av.x : av.y) >> (8 * (j & 3))) & 0xFFu;
-          if (aj == code) acc[j] += f[j];
+        const int ho = k - 1 + a, wo = l - 1 + b;
+        ok[a][b] = ho >= 0 && ho < G.ho && wo >= 0 && wo < G.wo;
+        if (ok[a][b]) {
+          const uint32_t o = ((uint32_t)(n * G.ho + ho) * (uint32_t)G.wo + (uint32_t)wo) * (uint32_t)G.cg + cgi;
+          av[a][b] = *reinterpret_cast<const uint2*>(idx + (size_t)o * 8);
+          unpack8(*reinterpret_cast<const uint4*>(dy + (size_t)o * 8), f[a][b]);
         }
       }
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      const int h = 2 * k + ph - G.pt;
+      if (h < 0 || h >= G.h) continue;
+#pragma unroll
+      for (int pw = 0; pw < 2; ++pw) {
+        const int w = 2 * l + pw - G.pl;
+        if (w < 0 || w >= G.w) continue;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        // even padded row: taps r = 0 (window row k) then r = 2 (window row k-1); odd: r = 1 (window row k)
+#pragma unroll
+        for (int ra = 0; ra < 2; ++ra) {
+          if (ph == 1 && ra == 1) continue;
+          const int r = ph + 2 * ra, wa = (ph == 0 && ra == 1) ? 0 : 1;
+#pragma unroll
+          for (int sb = 0; sb < 2; ++sb) {
+            if (pw == 1 && sb == 1) continue;
+            const int s2 = pw + 2 * sb, wb = (pw == 0 && sb == 1) ? 0 : 1;
+            if (!ok[wa][wb]) continue;
+            const uint32_t code = (uint32_t)(r * 3 + s2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const uint32_t aj = ((j < 4 ? av[wa][wb].x : av[wa][wb].y) >> (8 * (j & 3))) & 0xFFu;
+              if (aj == code) acc[j] += f[wa][wb][j];
+            }
+          }
+        }
+        uint4 out;
+        out.x = f2bf(acc[0]) | (f2bf(acc[1]) << 16); out.y = f2bf(acc[2]) | (f2bf(acc[3]) << 16);
+        out.z = f2bf(acc[4]) | (f2bf(acc[5]) << 16); out.w = f2bf(acc[6]) | (f2bf(acc[7]) << 16);
+        const uint32_t xi = ((uint32_t)(n * G.h + h) * (uint32_t)G.w + (uint32_t)w) * (uint32_t)G.cg + cgi;
+        *reinterpret_cast<uint4*>(dx + (size_t)xi * 8) = out;
+      }
     }
-    uint4 out;
-    out.x = f2bf(acc[0]) | (f2bf(acc[1]) << 16); out.y = f2bf(acc[2]) | (f2bf(acc[3]) << 16);
-    out.z = f2bf(acc[4]) | (f2bf(acc[5]) << 16); out.w = f2bf(acc[6]) | (f2bf(acc[7]) << 16);
-    *reinterpret_cast<uint4*>(dx + (size_t)i * 8) = out;
   }
 }
 
@@ -216,8 +241,9 @@ int rigl_maxpool_bwd(const RiglConvDesc* d, const rigl_bf16* dy, const uint8_t* 
   if (!dy || !dx || !argmax) return fail(RIGL_EINVAL, "rigl_maxpool_bwd: NULL tensor");
   hipStream_t st = as_stream(stream);
   const int64_t items = (int64_t)g.n * g.h * g.w * g.cg;
+  const int kb = (g.h + g.pt + 1) / 2, lb = (g.w + g.pl + 1) / 2;       // 2x2 blocks of padded coordinates
   if (g.kh == 3 && g.kw == 3 && g.sh == 2 && g.sw == 2 && items < (int64_t(1) << 31))
-    hipLaunchKernelGGL(k_bwd_3x3s2, dim3(grid_for(items)), dim3(THREADS), 0, st, g, dy, argmax, dx);
+    hipLaunchKernelGGL(k_bwd_3x3s2, dim3(grid_for((int64_t)g.n * kb * lb * g.cg)), dim3(THREADS), 0, st, g, kb, lb, dy, argmax, dx);
   else
     hipLaunchKernelGGL(k_bwd, dim3(grid_for(items)), dim3(THREADS), 0, st, g, dy, argmax, dx);
   RIGL_CHECK_LAUNCH("rigl_maxpool_bwd");
