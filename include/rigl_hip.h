@@ -252,8 +252,10 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x,
 /* dW and (dx != NULL) dX = dgrad (+ addend) of one conv in a single call, and
  * for ordinary layers a single launch: the dgrad and the split-K wgrad
  * workgroups share one grid (they are independent and each alone leaves much
- * of the chip idle), followed by the split-K reduce.  Results are bit-identical
- * to rigl_masked_conv2d_wgrad + rigl_masked_conv2d_dgrad_acc.
+ * of the chip idle), followed by the split-K reduce.  dX is bit-identical to
+ * rigl_masked_conv2d_dgrad_acc; dW is the same sum split over fewer pixel ranges
+ * than rigl_masked_conv2d_wgrad's plan (the weight-gradient workgroups leave
+ * room for the dgrad tiles) -- deterministic, equal to it up to fp32 reassociation.
  * workspace: rigl_conv2d_workspace_bytes(d, 2).                              */
 int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x,
                            const rigl_bf16* dy, const rigl_bf16* w_hwio,
@@ -268,7 +270,7 @@ int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x,
  * workgroups inside this layer's launch (or by a kernel of its own on the
  * fallback paths).  The caller keeps the pending layer's workspace alive and
  * passes a DIFFERENT workspace here; the last pending reduce of a backward pass
- * is run by rigl_wgrad_reduce_pending.  Results are bit-identical.             */
+ * is run by rigl_wgrad_reduce_pending.  Same bits as rigl_masked_conv2d_bwd.     */
 typedef struct RiglPendingReduce {
   const float* slabs;   /* [splits][slab_elems] partial sums                   */
   float* dw;            /* destination, n_out elements                          */

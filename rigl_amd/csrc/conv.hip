@@ -1036,8 +1036,8 @@ __global__ __launch_bounds__(THREADS) void k_wgrad_reduce(const float* __restric
   }
 }
 
-// Whole backward of a conv in ONE launch: the first `nd` workgroups run the dgrad implicit GEMM, the
-// next `nw` the weight-gradient GEMM, any further ones the deferred split-K reduce of the layer before.  The two are independent (both read dY) and on their own each
+// Whole backward of a conv in ONE launch: the first `nw` workgroups run the weight-gradient GEMM, the
+// next `nd` the dgrad implicit GEMM, any further ones the deferred split-K reduce of the layer before.  The two are independent (both read dY) and on their own each
 // leaves much of the chip idle (196-784 tiles for 768 workgroup slots), so sharing a launch lets the
 // dispatcher fill the machine with whichever still has tiles -- the overlap a second stream gives,
 // without a second stream.  Same bodies, one LDS allocation (the larger of the two).
@@ -1045,8 +1045,10 @@ template <int TND, bool CLSD, int TMW, int TNW, int STW>
 __global__ __launch_bounds__(THREADS) void k_bwd_fused(IgemmArgs PD, WgradArgs PW, ReduceArgs PR, uint32_t nd, uint32_t nw) {
   constexpr int SD = igemm_smem_bytes<2, TND, 32, 1, false, CLSD, 3>(), SW = wgrad_tr_smem_bytes<TMW, TNW, STW>();
   __shared__ __attribute__((aligned(16))) unsigned char smem[SD > SW ? SD : SW];
-  if (blockIdx.x < nd) igemm_body<2, TND, 32, 1, false, CLSD, 3>(PD, smem, blockIdx.x, nd);
-  else if (blockIdx.x < nd + nw) wgrad_tr_body<TMW, TNW, STW>(PW, smem, blockIdx.x - nd, nw);
+  // longest jobs first: a weight-gradient workgroup walks 1/splits of all pixels and runs several times as long as
+  // a dgrad tile, so it must not be what is left for the tail (dgrad first: 13.85 ms per step, wgrad first: 13.74)
+  if (blockIdx.x < nw) wgrad_tr_body<TMW, TNW, STW>(PW, smem, blockIdx.x, nw);
+  else if (blockIdx.x < nd + nw) igemm_body<2, TND, 32, 1, false, CLSD, 3>(PD, smem, blockIdx.x - nw, nd);
   else wgrad_reduce_body(PR, smem, blockIdx.x - nd - nw, gridDim.x - nd - nw);   // the PREVIOUS layer's split-K reduce
 }
 
@@ -1318,7 +1320,7 @@ static int num_cus() {
 // (CUs x workgroups/CU at this tile's LDS footprint: 64/48/32 KB -> 2/3/4); one more
 // workgroup than that starts a second, nearly empty round (measured: 513 workgroups of
 // the 128x128 tile take 1.4x the time of 504).
-static WgradPlan plan_wgrad(int M, int cin, int cout, int taps) {
+static WgradPlan plan_wgrad(int M, int cin, int cout, int taps, bool fused = false) {
   WgradPlan p;
   p.tm = cin > 64 ? 2 : 1;
   p.tn = cout > 64 ? 2 : 1;
@@ -1331,7 +1333,13 @@ static WgradPlan plan_wgrad(int M, int cin, int cout, int taps) {
   static const int lds_cu = [] { const char* e = getenv("RIGL_WGRAD_LDS_KB"); return (e ? atoi(e) : 160) * 1024; }();
   int occ = lds_cu / lds;
   if (occ > 4) occ = 4;
-  const int64_t slots = target > 0 ? target : (int64_t)num_cus() * occ;
+  int64_t slots = target > 0 ? target : (int64_t)num_cus() * occ;
+  // Sharing the launch with the layer's dgrad tiles (k_bwd_fused, weight-gradient workgroups first): take 60 % of
+  // the workgroup slots and leave the rest to the dgrad tiles from the start instead of making them wait for a
+  // full round of long-running weight-gradient workgroups (ResNet-50 step: 100 % 13.87 ms, 83 % 13.99*, 67 % 13.70,
+  // 58 % 13.62, 50 % 13.80, 42 % 14.09; * on a slower box whose 100 % was 14.25).
+  static const int fused_pct = [] { const char* e = getenv("RIGL_WGRAD_FUSED_PCT"); return e ? atoi(e) : 60; }();
+  if (fused && target <= 0) slots = slots * fused_pct / 100;
   int64_t s = slots / base;
   if (s > kt / 4) s = kt / 4;                // at least 256 pixels per split
   if (s < 1) s = 1;
@@ -1614,7 +1622,7 @@ int rigl_masked_conv2d_bwd_deferred(const RiglConvDesc* d, const rigl_bf16* x, c
     aw.X = x; aw.Cin = d->cin; aw.x_pix_stride = d->cin; aw.KH = d->kh; aw.KW = d->kw; aw.H = d->h; aw.W = d->w;
     aw.Ho = d->ho; aw.Wo = d->wo; aw.sh = d->stride_h; aw.sw = d->stride_w; aw.ph = d->pad_top; aw.pw = d->pad_left;
     aw.x_bytes = (uint32_t)((size_t)d->n * d->h * d->w * d->cin * 2);
-    const WgradPlan p = plan_wgrad(aw.M, aw.Cin, aw.Cout, aw.KH * aw.KW);
+    const WgradPlan p = plan_wgrad(aw.M, aw.Cin, aw.Cout, aw.KH * aw.KW, true);
     const int st_default = (p.tm == 2 && p.tn == 2) ? 3 : 4;
     // Launched alone back to back, a large short-reduction (HBM-bound) dgrad -- the 56x56 / 28x28 1x1 "reduce"
     // convs -- is 9-28 % slower when it shares the launch, the other layers 3-10 % faster; inside the training
@@ -1676,8 +1684,8 @@ int rigl_masked_conv2d_bwd_deferred(const RiglConvDesc* d, const rigl_bf16* x, c
 }
 
 // Whole backward of one masked conv in one call: dW (dense) and, when dx is given, dX (+ addend).
-// Ordinary layers run both GEMMs in ONE launch (k_bwd_fused: dgrad workgroups first, then the split-K
-// weight-gradient ones) followed by the split-K reduce; the tiny-/small-Cin paths (extra repack
+// Ordinary layers run both GEMMs in ONE launch (k_bwd_fused: the split-K weight-gradient workgroups first, then the dgrad
+// tiles) followed by the split-K reduce; the tiny-/small-Cin paths (extra repack
 // kernels, no dX for the stem) and non-default tuning knobs fall back to the two separate launches.
 int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
                            const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,

@@ -79,12 +79,17 @@ def test_wgrad_homogeneity_additivity_and_single_launch_backward(shape):
       ops.conv_wgrad(dh, x[B // 2:].contiguous(), dy[B // 2:].contiguous())
   scale = (x.float().abs().mean() * dy.float().abs().mean() * x.shape[0] * dy.shape[1] * dy.shape[2]).item()
   assert float((half - dw).abs().max()) <= 1e-5 * scale                           # reassociated fp32 sums
-  # the training step's one-launch backward gives the same bits as the two separate kernels
-  dw1 = torch.empty_like(dw)
+  # the training step's one-launch backward: dX has the same bits as the separate dgrad kernel; dW is the same
+  # sum split over fewer pixel ranges (the weight-gradient workgroups share the launch with the dgrad tiles), so
+  # it agrees to fp32 reassociation and is itself deterministic
+  dw1, dw2 = torch.empty_like(dw), torch.empty_like(dw)
   need_dx = shape[2] % 8 == 0
   dx1 = ops.conv_bwd(d, x, dy, hwio, dw1, need_dx=need_dx)
   ops.flush_pending_wgrad()
-  assert torch.equal(dw1, dw)
+  assert float((dw1 - dw).abs().max()) <= 1e-5 * scale
+  ops.conv_bwd(d, x, dy, hwio, dw2, need_dx=need_dx)
+  ops.flush_pending_wgrad()
+  assert torch.equal(dw1, dw2)
   if need_dx:
     assert torch.equal(dx1, ops.conv_dgrad(d, dy, hwio))
 

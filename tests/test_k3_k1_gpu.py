@@ -291,7 +291,8 @@ def test_conv_fwd_256x128_tile_is_bit_identical(case):
 
 @pytest.mark.parametrize('case', [CONV_CASES[1], CONV_CASES[4], CONV_CASES[5], CONV_CASES[8], CONV_CASES[15]])
 def test_conv_bwd_single_call_equals_wgrad_then_dgrad(case, monkeypatch):
-  """rigl_masked_conv2d_bwd == rigl_masked_conv2d_wgrad + rigl_masked_conv2d_dgrad_acc, bit for bit."""
+  """rigl_masked_conv2d_bwd == rigl_masked_conv2d_wgrad + rigl_masked_conv2d_dgrad_acc: dX bit for bit, dW to fp32
+  reassociation (the fused launch may split the pixel sum over fewer ranges) and deterministic."""
   from rigl_amd import ops
   N, H, W, Cin, Cout, k, stride, pt, pl, Ho, Wo = case
   g = torch.Generator().manual_seed(23 + sum(case))
@@ -309,7 +310,9 @@ def test_conv_bwd_single_call_equals_wgrad_then_dgrad(case, monkeypatch):
   else:
     assert ops.conv_bwd(d, x, dy, hwio, dw1, need_dx=False) is None
   ops.flush_pending_wgrad()
-  assert torch.equal(dw0.view(torch.int32), dw1.view(torch.int32))
+  # same sum, possibly split over fewer pixel ranges than the standalone kernel's plan: fp32 reassociation only
+  tol = 1e-5 * float(x.float().abs().mean() * dy.float().abs().mean()) * N * Ho * Wo
+  assert float((dw0 - dw1).abs().max()) <= tol
   # a chain of backward launches: each one runs the split-K reduce of the one before as a third segment
   if Cin % 8 == 0:
     monkeypatch.setattr(ops, '_DEFER', True)
@@ -321,7 +324,7 @@ def test_conv_bwd_single_call_equals_wgrad_then_dgrad(case, monkeypatch):
     ops.flush_pending_wgrad()
     assert done == [0, 1, 2]
     for t in dws:
-      assert torch.equal(t.view(torch.int32), dw0.view(torch.int32))
+      assert torch.equal(t.view(torch.int32), dw1.view(torch.int32))      # deferred or not: the same bits
 
 
 def test_conv_asymmetric_b_detects_transposes():
