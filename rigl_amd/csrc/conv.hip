@@ -1339,7 +1339,9 @@ static WgradPlan plan_wgrad(int M, int cin, int cout, int taps, bool fused = fal
   // full round of long-running weight-gradient workgroups (ResNet-50 step: 100 % 13.87 ms, 83 % 13.99*, 67 % 13.70,
   // 58 % 13.62, 50 % 13.80, 42 % 14.09; * on a slower box whose 100 % was 14.25).
   static const int fused_pct = [] { const char* e = getenv("RIGL_WGRAD_FUSED_PCT"); return e ? atoi(e) : 60; }();
-  if (fused && target <= 0) slots = slots * fused_pct / 100;
+  // (the 64-wide weight-gradient tiles, planned on 4 workgroups per CU, do best at 75 %: 13.39 vs 13.44 ms; 45 % 13.57, 88 % 13.61)
+  static const int fused_pct_small = [] { const char* e = getenv("RIGL_WGRAD_FUSED_PCT_SMALL"); return e ? atoi(e) : 75; }();
+  if (fused && target <= 0) slots = slots * ((p.tm == 2 && p.tn == 2) ? fused_pct : fused_pct_small) / 100;
   int64_t s = slots / base;
   if (s > kt / 4) s = kt / 4;                // at least 256 pixels per split
   if (s < 1) s = 1;
