@@ -1036,6 +1036,55 @@ __global__ __launch_bounds__(THREADS) void k_wgrad_reduce(const float* __restric
   }
 }
 
+// Few splits (the large layers: 3-7 slabs of up to 2.4 M outputs): the 16 split-groups above would leave most of
+// the workgroup idle, so G = 4 or 8 groups x 256 / G float4 columns.  With G >= splits every group holds at most
+// one slab and the combine is the plain sum in split order -- the same bits as the 16-group kernel.
+template <int G>
+__global__ __launch_bounds__(THREADS) void k_wgrad_reduce_few(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                               int64_t n_out, int64_t slab_elems, int splits) {
+  constexpr int CW = THREADS / G;
+  __shared__ float4 part[G][CW];
+  const int col = threadIdx.x % CW, grp = threadIdx.x / CW;
+  const int64_t i0 = ((int64_t)blockIdx.x * CW + col) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (grp < splits) {
+    const float* p = slabs + (int64_t)grp * slab_elems;
+    if (i0 + 3 < slab_elems && (slab_elems & 3) == 0) {
+      const float4 v = *reinterpret_cast<const float4*>(p + i0);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    } else {
+      if (i0 + 0 < slab_elems) acc.x += p[i0 + 0];
+      if (i0 + 1 < slab_elems) acc.y += p[i0 + 1];
+      if (i0 + 2 < slab_elems) acc.z += p[i0 + 2];
+      if (i0 + 3 < slab_elems) acc.w += p[i0 + 3];
+    }
+  }
+  part[grp][col] = acc;
+  __syncthreads();
+  if (grp == 0) {
+    float4 r = part[0][col];
+#pragma unroll
+    for (int g2 = 1; g2 < G; ++g2) {
+      const float4 v = part[g2][col];
+      r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+    }
+    if (i0 + 0 < n_out) dw[i0 + 0] = r.x;
+    if (i0 + 1 < n_out) dw[i0 + 1] = r.y;
+    if (i0 + 2 < n_out) dw[i0 + 2] = r.z;
+    if (i0 + 3 < n_out) dw[i0 + 3] = r.w;
+  }
+}
+
+static void launch_wgrad_reduce(const ReduceArgs& ra, hipStream_t st) {
+  static const bool few = [] { const char* e = getenv("RIGL_WGRAD_REDUCE_FEW"); return e ? atoi(e) != 0 : true; }();
+  if (few && ra.splits <= 4)
+    RIGL_K_LAUNCH(k_wgrad_reduce_few<4>, dim3((unsigned)ceil_div64(ra.n_out, 256)), dim3(THREADS), 0, st, ra.slabs, ra.dw, ra.n_out, ra.slab_elems, ra.splits);
+  else if (few && ra.splits <= 8)
+    RIGL_K_LAUNCH(k_wgrad_reduce_few<8>, dim3((unsigned)ceil_div64(ra.n_out, 128)), dim3(THREADS), 0, st, ra.slabs, ra.dw, ra.n_out, ra.slab_elems, ra.splits);
+  else
+    RIGL_K_LAUNCH(k_wgrad_reduce, dim3((unsigned)ceil_div64(ra.n_out, 64)), dim3(THREADS), 0, st, ra.slabs, ra.dw, ra.n_out, ra.slab_elems, ra.splits);
+}
+
 // Whole backward of a conv in ONE launch: the first `nw` workgroups run the weight-gradient GEMM, the
 // next `nd` the dgrad implicit GEMM, any further ones the deferred split-K reduce of the layer before.  The two are independent (both read dY) and on their own each
 // leaves much of the chip idle (196-784 tiles for 768 workgroup slots), so sharing a launch lets the
@@ -1574,9 +1623,8 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
     else RIGL_K_LAUNCH((k_wgrad<1, 1>), grid, blk, 0, st, a);
   }
   if (two_pass) {
-    const int64_t blocks = ceil_div64(n_out, 64);
     ReduceArgs ra = {reinterpret_cast<const float*>(ws), tiny_tmp ? tiny_tmp : dw, n_out, p.slab, p.splits};
-    RIGL_K_LAUNCH(k_wgrad_reduce, dim3((unsigned)blocks), blk, 0, st, ra.slabs, ra.dw, ra.n_out, ra.slab_elems, ra.splits);
+    launch_wgrad_reduce(ra, st);
   }
   if (tiny_tmp)
     RIGL_K_LAUNCH(k_stem_unpack, dim3(64), blk, 0, st, tiny_tmp, dw, d->kh, d->kw, d->cin, tg.cred, d->cout);
@@ -1588,7 +1636,7 @@ static void launch_pending_reduce(const RiglPendingReduce* pr, hipStream_t st) {
   using namespace rigl;
   using namespace rigl::k1;
   ReduceArgs ra = {pr->slabs, pr->dw, pr->n_out, pr->slab_elems, pr->splits};
-  RIGL_K_LAUNCH(k_wgrad_reduce, dim3((unsigned)ceil_div64(pr->n_out, 64)), dim3(THREADS), 0, st, ra.slabs, ra.dw, ra.n_out, ra.slab_elems, ra.splits);
+  launch_wgrad_reduce(ra, st);
 }
 
 int rigl_wgrad_reduce_pending(const RiglPendingReduce* pending, rigl_stream_t stream) {
@@ -1669,7 +1717,7 @@ int rigl_masked_conv2d_bwd_deferred(const RiglConvDesc* d, const rigl_bf16* x, c
           defer->slab_elems = p.slab; defer->splits = p.splits;
         } else {
           ReduceArgs ra = {static_cast<const float*>(workspace), dw, n_out, p.slab, p.splits};
-          RIGL_K_LAUNCH(k_wgrad_reduce, dim3((unsigned)ceil_div64(n_out, 64)), blk, 0, st, ra.slabs, ra.dw, ra.n_out, ra.slab_elems, ra.splits);
+          launch_wgrad_reduce(ra, st);
         }
       }
       RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");

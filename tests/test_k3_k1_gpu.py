@@ -289,6 +289,34 @@ def test_conv_fwd_256x128_tile_is_bit_identical(case):
   assert outs['1']['shape'] == [(N * Ho * Wo + 127) // 128, 2, Cout] and outs['1']['absmax'] > 0
 
 
+def test_split_k_reduce_variants_give_the_same_bits():
+  """Layers with few split-K slabs (large dW, few pixels: the 7x7 3x3 convs) reduce with 4 or 8 split-groups
+  per workgroup instead of 16; with groups >= splits every variant is the plain sum in split order.  The
+  standalone plan of this shape has 5 slabs (8-group kernel), the shared-launch plan 3 (4-group kernel)."""
+  import json
+  import subprocess
+  import sys
+  prog = ("import sys, json, hashlib, torch; sys.path.insert(0, %r); from rigl_amd import ops;"
+          "g = torch.Generator().manual_seed(9);"
+          "x = torch.randn(32, 7, 7, 512, generator=g).to(torch.bfloat16).cuda();"
+          "dy = torch.randn(32, 7, 7, 512, generator=g).to(torch.bfloat16).cuda();"
+          "w = (torch.randn(9 * 512 * 512, generator=g) * 0.02).to(torch.bfloat16).cuda();"
+          "d = ops.conv_desc(32, 7, 7, 512, 512, 3, 3, 1, 1, 1, 7, 7);"
+          "dw0 = ops.conv_wgrad(d, x, dy); dw1 = torch.empty_like(dw0);"
+          "ops.conv_bwd(d, x, dy, w, dw1, need_dx=True); ops.flush_pending_wgrad(); torch.cuda.synchronize();"
+          "h = lambda t: hashlib.sha256(t.contiguous().cpu().numpy().tobytes()).hexdigest();"
+          "print(json.dumps({'alone': h(dw0.view(torch.int32)), 'shared': h(dw1.view(torch.int32)),"
+          " 'absmax': float(dw0.abs().max()), 'close': float((dw0 - dw1).abs().max())}))" % (ROOT,))
+  outs = {}
+  for few in ('0', '1'):
+    r = subprocess.run([sys.executable, '-c', prog], env=dict(os.environ, RIGL_WGRAD_REDUCE_FEW=few),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    outs[few] = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+  assert outs['0']['alone'] == outs['1']['alone'] and outs['0']['shared'] == outs['1']['shared']
+  assert outs['1']['absmax'] > 0 and outs['1']['close'] <= 1e-5 * 32 * 49
+
+
 @pytest.mark.parametrize('case', [CONV_CASES[1], CONV_CASES[4], CONV_CASES[5], CONV_CASES[8], CONV_CASES[15]])
 def test_conv_bwd_single_call_equals_wgrad_then_dgrad(case, monkeypatch):
   """rigl_masked_conv2d_bwd == rigl_masked_conv2d_wgrad + rigl_masked_conv2d_dgrad_acc: dX bit for bit, dW to fp32
