@@ -28,7 +28,9 @@ class GradSync:
     self.group = group
     self.world = dist.get_world_size(group) if dist.is_initialized() else 1
     self.enabled = (self.world > 1) if enabled is None else enabled
-    self.grad_scale = 1.0 / self.world
+    # the mean over replicas rides in K3's grad_scale -- only when the sum is actually taken
+    self.grad_scale = 1.0 / self.world if self.enabled else 1.0
+    self._state_synced = False
     self.bucket_elems = max(int(bucket_bytes) // 4, 1)
     self._handles = []
     self._hi = None       # arena index above which everything is already sent
@@ -37,6 +39,27 @@ class GradSync:
     self._ready = set()
     self.n_buckets_last = 0
     graph.grad_sync = self
+
+  def sync_initial_state(self, src=0):
+    """Replicas must start from the same weights, masks and BN buffers: the
+    reference gets that from a shared initial checkpoint / identical seeds;
+    here rank ``src`` broadcasts its arenas once (W, BITS and every BatchNorm's
+    moving statistics), so a caller that seeded NumPy differently per rank (or not
+    at all: ``get_mask_random`` draws from the global RNG) still trains ONE network."""
+    if not self.enabled or self._state_synced:
+      return
+    g = self.graph
+    g.finalize()
+    dist.broadcast(g.W, src=src, group=self.group)
+    if g.BITS is not None and g.BITS.numel():
+      dist.broadcast(g.BITS, src=src, group=self.group)
+    for mod in g.modules.values():
+      for name in ('moving_mean', 'moving_variance'):
+        t = getattr(mod, name, None)
+        if torch.is_tensor(t):
+          dist.broadcast(t, src=src, group=self.group)
+    g.shadows_dirty = True
+    self._state_synced = True
 
   def _kernel_end(self):
     from rigl_amd import variables as V  # pylint: disable=import-outside-toplevel

@@ -391,8 +391,6 @@ def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None):
   if _SIDE_WGRAD:
     # wgrad on the side stream (own workspace), dgrad on the main one: the two overlap
     flush_pending_wgrad(x.device)
-    if on_dw_ready is not None:
-      on_dw_ready()
     main, side = torch.cuda.current_stream(x.device), side_stream(x.device)
     side.wait_stream(main)
     ws = workspace(need, x.device, 'side') if need else None
@@ -400,6 +398,10 @@ def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None):
                                        ws.numel() if ws is not None else 0, C.c_void_p(side.cuda_stream)))
     x.record_stream(side)
     dy.record_stream(side)
+    # only now is dW's producer enqueued: a bucket launched from this callback joins the side stream first
+    # (GradSync._launch), so the collective is ordered after the weight-gradient kernel, never before it
+    if on_dw_ready is not None:
+      on_dw_ready()
     return conv_dgrad(d, dy, w_hwio, addend=addend) if need_dx else None
   key = x.device.index or 0
   prev = _pending.pop(key, None)

@@ -86,16 +86,37 @@ class GradientDescentOptimizer(Optimizer):
         self._grad_sync.all_reduce(g)
     if var_list is not None:
       return [(v.grad, v) for v in var_list]
-    return [(v.grad, v) for v in g.trainable_variables()]
+    # (the list handed out is remembered: getting it back untouched needs no per-variable check in apply_gradients)
+    self._last_gv = [(v.grad, v) for v in g.trainable_variables()]
+    return self._last_gv
 
   # ---- update ----------------------------------------------------------------
   def _ensure_slots(self):
     pass
 
   def apply_gradients(self, grads_and_vars, global_step=None, name=None):
-    del grads_and_vars, name  # gradients live in the arena the kernels read
+    del name
     g = self.graph
     g.finalize()
+    # The kernels read the gradient arena.  Gradients handed back unchanged ARE arena slices; transformed ones
+    # (clipping, scaling) are copied into their variable's slice; what the arena-wide update cannot express --
+    # a None gradient or a subset of the trainable variables -- raises instead of being silently ignored.
+    if grads_and_vars is not None and grads_and_vars is not getattr(self, '_last_gv', None):
+      gv = list(grads_and_vars)
+      seen = set()
+      for grad, var in gv:
+        if grad is None:
+          raise NotImplementedError('apply_gradients: None gradient for %s (the fused update walks whole arena '
+                                    'segments; freeze a variable by zeroing its gradient instead)' % var.name)
+        if not hasattr(var, 'grad') or var.grad is None:
+          raise ValueError('apply_gradients: %r is not a variable of this graph' % (var,))
+        if grad.data_ptr() != var.grad.data_ptr():
+          var.grad.copy_(grad.reshape(var.grad.shape))
+        seen.add(var.name)
+      missing = [v.name for v in g.trainable_variables() if v.name not in seen]
+      if gv and missing:
+        raise NotImplementedError('apply_gradients: the fused update covers every trainable variable; missing %s%s'
+                                  % (missing[:3], ' ...' if len(missing) > 3 else ''))
     self._ensure_slots()
     lr = _lr_value(self._lr, global_step)
     scale = self._grad_sync.grad_scale if self._grad_sync is not None else 1.0

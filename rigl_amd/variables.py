@@ -311,6 +311,9 @@ class Graph:
     from rigl_amd import ops  # pylint: disable=import-outside-toplevel
     if not (self.shadows_dirty or force):
       return
+    sync = getattr(self, 'grad_sync', None)
+    if sync is not None and not sync._state_synced:   # pylint: disable=protected-access
+      sync.sync_initial_state()          # first forward of a data-parallel run: rank 0's weights / masks everywhere
     items = []
     for l in self.layers:
       items.append((l.weights.data.view(-1),
