@@ -92,8 +92,9 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t b
 // template parameter made the host pass drop the kernel's launch stub).
 template <int N> __device__ __forceinline__ void wait_vmcnt();
 #define RIGL_WAIT_VMCNT(N) template <> __device__ __forceinline__ void wait_vmcnt<N>() { asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); }
-RIGL_WAIT_VMCNT(0) RIGL_WAIT_VMCNT(2) RIGL_WAIT_VMCNT(3) RIGL_WAIT_VMCNT(4) RIGL_WAIT_VMCNT(6) RIGL_WAIT_VMCNT(8)
-RIGL_WAIT_VMCNT(9) RIGL_WAIT_VMCNT(12) RIGL_WAIT_VMCNT(16)
+RIGL_WAIT_VMCNT(0) RIGL_WAIT_VMCNT(1) RIGL_WAIT_VMCNT(2) RIGL_WAIT_VMCNT(3) RIGL_WAIT_VMCNT(4) RIGL_WAIT_VMCNT(5)
+RIGL_WAIT_VMCNT(6) RIGL_WAIT_VMCNT(7) RIGL_WAIT_VMCNT(8) RIGL_WAIT_VMCNT(9) RIGL_WAIT_VMCNT(10) RIGL_WAIT_VMCNT(12)
+RIGL_WAIT_VMCNT(16)
 #undef RIGL_WAIT_VMCNT
 
 __device__ __forceinline__ uint32_t dword_of(const uint4& v, int d) {
@@ -1242,6 +1243,7 @@ static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, int bk, b
 struct IgemmPlan { bool wide_n, dma, w4, cls, big; int bk; unsigned grid; };
 
 static int num_cus();
+#include "conv196.hpp"
 // The 512-thread kernel needs 72 KB of dynamic LDS: opt in once; if the runtime refuses, the plan never picks it.
 template <int MODE>
 static bool big_tile_ready() {
@@ -1451,6 +1453,10 @@ size_t rigl_conv2d_workspace_bytes(const RiglConvDesc* d, int32_t which) {
 int32_t rigl_conv2d_stats_parts(const RiglConvDesc* d) {
   if (!d || d->cout <= 0 || (d->cout % 8)) return 0;
   const int64_t M = (int64_t)d->n * d->ho * d->wo;
+  using namespace rigl::k1;
+  if (!tiny_cin(d) && !small_cin(d) &&
+      plan_t196(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo, M, d->cout, d->cin).use)
+    return (int32_t)(M / T196_BMV);      // tile196 forward: one partial per 196-row tile
   return (int32_t)((M + 127) / 128);     // one partial per 128-row output tile
 }
 
@@ -1497,6 +1503,18 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, cons
     a.sh = a.sw = 1; a.ph = a.pw = 0; a.b_row_stride = Kp; a.b_tap_stride = 0;
     a.a_bytes = (uint32_t)((size_t)a.M * Kp * 2); a.b_bytes = (uint32_t)((size_t)d->cout * Kp * 2);
   } else {
+    const T196Plan tp = plan_t196(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo,
+                                  a.M, d->cout, d->cin);
+    if (tp.use) {
+      T196Args t = {};
+      t.A = x; t.B = w_ohwi; t.C = y; t.STATS = stats; t.M = a.M; t.N = d->cout; t.Cred = d->cin; t.H = d->h; t.W = d->w;
+      t.b_row_stride = d->kh * d->kw * d->cin; t.b_tap_stride = d->cin; t.ldc = d->cout;
+      t.a_bytes = (uint32_t)((size_t)a.M * d->cin * 2);
+      t.b_bytes = (uint32_t)((size_t)d->kh * d->kw * d->cin * d->cout * 2);
+      if (!launch_t196<0>(tp, t, st)) return fail(RIGL_ELAUNCH, "rigl_masked_conv2d_fwd: tile196 kernel could not get its LDS");
+      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
+      return RIGL_OK;
+    }
     a.A = x; a.B = w_ohwi; a.Cred = d->cin; a.a_pix_stride = d->cin; a.KH = d->kh; a.KW = d->kw; a.RH = d->ho; a.RW = d->wo;
     a.GH = d->h; a.GW = d->w; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
     a.b_row_stride = d->kh * d->kw * d->cin; a.b_tap_stride = d->cin;
@@ -1538,6 +1556,18 @@ int rigl_masked_conv2d_dgrad_acc(const RiglConvDesc* d, const rigl_bf16* dy, con
   if ((d->cin % 8) || (d->cout % 8)) return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_dgrad: cin/cout %% 8 != 0 (use the reference kernel)");
   hipStream_t st = as_stream(stream);
   ProfFamily prof(PROF_CONV_DGRAD);
+  const T196Plan tp = plan_t196(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo,
+                                (int64_t)d->n * d->h * d->w, d->cin, d->cout);
+  if (tp.use) {
+    T196Args t = {};
+    t.A = dy; t.B = w_hwio; t.C = dx; t.ADD = addend; t.M = d->n * d->h * d->w; t.N = d->cin; t.Cred = d->cout;
+    t.H = d->h; t.W = d->w; t.b_row_stride = d->cout; t.b_tap_stride = d->cin * d->cout; t.ldc = d->cin;
+    t.a_bytes = (uint32_t)((size_t)t.M * d->cout * 2);
+    t.b_bytes = (uint32_t)((size_t)d->kh * d->kw * d->cin * d->cout * 2);
+    if (!launch_t196<1>(tp, t, st)) return fail(RIGL_ELAUNCH, "rigl_masked_conv2d_dgrad: tile196 kernel could not get its LDS");
+    RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
+    return RIGL_OK;
+  }
   IgemmArgs a = dgrad_args(d, dy, w_hwio, addend, dx);
   launch_igemm<1, false>(a, st);
   RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
@@ -1662,7 +1692,12 @@ int rigl_masked_conv2d_bwd_deferred(const RiglConvDesc* d, const rigl_bf16* x, c
   const bool have_flush = flush && flush->splits > 0;
   if (have_flush && (!flush->slabs || !flush->dw)) return fail(RIGL_EINVAL, "rigl_masked_conv2d_bwd: NULL buffer in the pending reduce");
   hipStream_t st = as_stream(stream);
-  if (fuse && dx && x && dy && w_hwio && dw && !tiny_cin(d) && !small_cin(d) && (d->cin % 8) == 0 && (d->cout % 8) == 0 &&
+  // RIGL_T196_BWD=1: layers whose dgrad has a tile196 plan run wgrad and that dgrad as two launches instead of sharing one
+  static const bool t196_bwd = [] { const char* e = getenv("RIGL_T196_BWD"); return e ? atoi(e) != 0 : false; }();
+  const bool dgrad_196 = t196_bwd && dx && (d->cin % 8) == 0 && (d->cout % 8) == 0 &&
+      plan_t196(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo,
+                (int64_t)d->n * d->h * d->w, d->cin, d->cout).use;
+  if (fuse && !dgrad_196 && dx && x && dy && w_hwio && dw && !tiny_cin(d) && !small_cin(d) && (d->cin % 8) == 0 && (d->cout % 8) == 0 &&
       wgrad_use_tr() && conv_dma_stages() == 3) {
     IgemmArgs ad = dgrad_args(d, dy, w_hwio, addend, dx);
     const IgemmPlan pd = plan_igemm<1>(ad);

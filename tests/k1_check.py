@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""K1 parity runner (GPU): every conv entry point of the C ABI against tests/convref.py's fp64 reference on the same
+bf16 operands, with the per-element bound  2^-8 |ref| + 1e-5 sum|a||b|  (fwd / dgrad)  and  1e-5 sum|a||b|  (wgrad).
+
+Run as a script so that the kernel-selection environment (RIGL_T196, RIGL_W9, RIGL_CONV_BIG, ...), which the library
+reads once per process, can be chosen per invocation:
+
+  python tests/k1_check.py --set t196          # tile196 shapes (1x1 / 3x3, both column widths, K splits, ragged N)
+  python tests/k1_check.py --set resnet50 --batch 128     # the 23 distinct ResNet-50 layer shapes at the benchmarked batch
+
+Prints one line per case and a final JSON line {"ok": true, "cases": n, "worst": ratio}; exit code 1 on a mismatch.
+Test infrastructure: the pytest files call it in a subprocess.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from tests import convref  # noqa: E402
+
+DEV = 'cuda:0'
+
+# N, H, W, Cin, Cout, k, stride, pad_top, pad_left, Ho, Wo
+T196_CASES = [
+    (4, 7, 7, 32, 128, 1, 1, 0, 0, 7, 7),         # 1x1, one K-tile (the peeled tail alone)
+    (4, 7, 7, 64, 64, 1, 1, 0, 0, 7, 7),          # 1x1, two K-tiles, 64 columns (K split)
+    (8, 7, 7, 96, 96, 1, 1, 0, 0, 7, 7),          # three K-tiles, ragged N (96 = 64 + 32)
+    (4, 14, 14, 256, 128, 1, 1, 0, 0, 14, 14),    # 1x1, 8 K-tiles, four row tiles
+    (2, 14, 14, 160, 64, 1, 1, 0, 0, 14, 14),     # odd number of K-tiles with the K split (zero batch in the tail)
+    (4, 7, 7, 32, 128, 3, 1, 1, 1, 7, 7),         # 3x3, one channel block, one tile spanning four images
+    (4, 7, 7, 64, 64, 3, 1, 1, 1, 7, 7),          # 3x3, two channel blocks (slab double buffer), K split
+    (2, 14, 14, 96, 72, 3, 1, 1, 1, 14, 14),      # 3x3, three channel blocks, ragged N
+    (1, 28, 28, 128, 128, 3, 1, 1, 1, 28, 28),    # four row bands of one image: real halo rows between tiles
+    (2, 14, 28, 64, 256, 3, 1, 1, 1, 14, 28),     # H != W, two column tiles
+    (16, 7, 7, 512, 512, 3, 1, 1, 1, 7, 7),       # the late 3x3 of ResNet-50 (16 channel blocks)
+    (4, 14, 14, 256, 256, 3, 1, 1, 1, 14, 14),    # the group-3 3x3
+]
+
+
+def resnet50_shapes(batch):
+  seen, out = set(), []
+  out.append((batch, 224, 224, 3, 64, 7, 2, 3, 3, 112, 112))
+  in_ch, hw = 64, 56
+  for g, nb in enumerate([3, 4, 6, 3], start=1):
+    f = 64 * 2 ** (g - 1)
+    stride = 1 if g == 1 else 2
+    ohw = hw // stride
+    p3 = 1
+    cand = [(batch, hw, hw, in_ch, 4 * f, 1, stride, 0, 0, ohw, ohw),
+            (batch, hw, hw, in_ch, f, 1, 1, 0, 0, hw, hw),
+            (batch, hw, hw, f, f, 3, stride, p3, p3, ohw, ohw),
+            (batch, ohw, ohw, f, 4 * f, 1, 1, 0, 0, ohw, ohw),
+            (batch, ohw, ohw, 4 * f, f, 1, 1, 0, 0, ohw, ohw),
+            (batch, ohw, ohw, f, f, 3, 1, 1, 1, ohw, ohw)]
+    for c in cand:
+      if c not in seen:
+        seen.add(c)
+        out.append(c)
+    in_ch, hw = 4 * f, ohw
+  return out
+
+
+def run_case(case, seed, check_bwd_call=True, check_stats=True):
+  from rigl_amd import ops
+  N, H, W, Cin, Cout, k, stride, pt, pl, Ho, Wo = case
+  g = torch.Generator(device=DEV).manual_seed(seed)
+  x = torch.randn(N, H, W, Cin, generator=g, device=DEV).to(torch.bfloat16)
+  dy = torch.randn(N, Ho, Wo, Cout, generator=g, device=DEV).to(torch.bfloat16)
+  w = torch.randn(k, k, Cin, Cout, generator=g, device=DEV) * (2.0 / (k * k * Cin)) ** 0.5
+  add = torch.randn(N, H, W, Cin, generator=g, device=DEV).to(torch.bfloat16)
+  n = w.numel()
+  hwio = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+  ohwi = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+  ops.pack_weights(w.reshape(-1).contiguous(), None, k * k * Cin, Cout, hwio, ohwi)
+  wm = hwio.float().reshape(k, k, Cin, Cout)
+  d = ops.conv_desc(N, H, W, Cin, Cout, k, k, stride, pt, pl, Ho, Wo)
+  has_dx = Cin % 8 == 0
+  want = ('y', 'dx', 'dw') if has_dx else ('y', 'dw')
+  ref = convref.conv_fp64(x, wm, dy, stride, pt, pl, Ho, Wo, want)
+  ab = convref.conv_fp64(x.abs(), wm.abs(), dy.abs(), stride, pt, pl, Ho, Wo, want)
+  worst = 0.0
+  # forward (with the batch-norm statistics epilogue: y must not change, the partials must add up)
+  y = ops.conv_fwd(d, x, ohwi)
+  worst = max(worst, convref.check_close('fwd', y, ref['y'], ab['y'], 1e-5, 2.0 ** -8))
+  if check_stats and Cout % 8 == 0:
+    y2, part = ops.conv_fwd(d, x, ohwi, stats=True)
+    assert torch.equal(y2.view(torch.int16), y.view(torch.int16)), 'fwd_stats changed y'
+    if part is not None:
+      yf = y.double().reshape(-1, Cout)
+      s = part.double().sum(0)
+      assert part.shape[0] == d._stats_parts
+      tol0 = 2e-6 * float(yf.abs().sum(0).max()) + 1e-6
+      assert float((s[0] - yf.sum(0)).abs().max()) <= tol0, 'statistics: sum y'
+      q = (yf * yf).sum(0)
+      assert float(((s[1] - q).abs() / (q.abs() + 1e-6)).max()) <= 2e-6, 'statistics: sum y^2'
+      rows = yf.shape[0] // part.shape[0] if yf.shape[0] % part.shape[0] == 0 else 128
+      t = min(part.shape[0] - 1, 1)
+      blk = yf[t * rows:(t + 1) * rows]
+      assert float((part[t, 0].double() - blk.sum(0)).abs().max()) <= 1e-5 * float(blk.abs().sum(0).max()) + 1e-6, \
+          'statistics: a tile partial is not the sum of its own rows'
+  del y
+  dw = ops.conv_wgrad(d, x, dy).reshape(k, k, Cin, Cout)
+  worst = max(worst, convref.check_close('wgrad', dw, ref['dw'], ab['dw'], 1e-5))
+  if has_dx:
+    dx = ops.conv_dgrad(d, dy, hwio)
+    worst = max(worst, convref.check_close('dgrad', dx, ref['dx'], ab['dx'], 1e-5, 2.0 ** -8))
+    dxa = ops.conv_dgrad(d, dy, hwio, addend=add)
+    assert torch.equal(dxa.view(torch.int16), (dx + add).view(torch.int16)), 'dgrad_acc != dgrad + addend'
+    del dxa
+  if check_bwd_call:
+    dw1 = torch.empty(n, dtype=torch.float32, device=DEV)
+    dx1 = ops.conv_bwd(d, x, dy, hwio, dw1, need_dx=has_dx, addend=add if has_dx else None)
+    ops.flush_pending_wgrad()
+    worst = max(worst, convref.check_close('bwd.dw', dw1.reshape(k, k, Cin, Cout), ref['dw'], ab['dw'], 1e-5))
+    if has_dx:
+      # the one-call backward adds the addend in bf16 after rounding dgrad to bf16, like dgrad_acc
+      assert torch.equal(dx1.view(torch.int16), (dx + add).view(torch.int16)), 'bwd.dx != dgrad + addend'
+    # run-to-run determinism of the dense gradient (masks are a function of it)
+    dw2 = torch.empty_like(dw1)
+    ops.conv_bwd(d, x, dy, hwio, dw2, need_dx=has_dx, addend=add if has_dx else None)
+    ops.flush_pending_wgrad()
+    assert torch.equal(dw1.view(torch.int32), dw2.view(torch.int32)), 'bwd.dw not deterministic'
+  torch.cuda.synchronize()
+  return worst
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--set', default='t196', choices=['t196', 'resnet50'])
+  ap.add_argument('--batch', type=int, default=128)
+  ap.add_argument('--only', type=int, default=-1)
+  a = ap.parse_args()
+  cases = T196_CASES if a.set == 't196' else resnet50_shapes(a.batch)
+  worst, n = 0.0, 0
+  for i, c in enumerate(cases):
+    if a.only >= 0 and i != a.only:
+      continue
+    try:
+      r = run_case(c, 100 + i)
+    except AssertionError as e:
+      print('FAIL case %d %s: %s' % (i, c, e), flush=True)
+      print(json.dumps({'ok': False, 'case': i, 'shape': list(c), 'error': str(e)[:500]}))
+      return 1
+    print('ok case %d %s worst ratio %.3f' % (i, c, r), flush=True)
+    worst, n = max(worst, r), n + 1
+    torch.cuda.empty_cache()
+  print(json.dumps({'ok': True, 'cases': n, 'worst': worst, 'set': a.set,
+                    'env': {k: v for k, v in os.environ.items() if k.startswith('RIGL_')}}))
+  return 0
+
+
+if __name__ == '__main__':
+  sys.exit(main())
