@@ -1244,6 +1244,8 @@ struct IgemmPlan { bool wide_n, dma, w4, cls, big; int bk; unsigned grid; };
 
 static int num_cus();
 #include "conv196.hpp"
+#include "conv3x3.hpp"
+#include "wgrad9.hpp"
 // The 512-thread kernel needs 72 KB of dynamic LDS: opt in once; if the runtime refuses, the plan never picks it.
 template <int MODE>
 static bool big_tile_ready() {
@@ -1445,7 +1447,13 @@ size_t rigl_conv2d_workspace_bytes(const RiglConvDesc* d, int32_t which) {
   }
   if (which == 2) {
     WgradPlan p = plan_wgrad((int)M, d->cin, d->cout, d->kh * d->kw);
-    return p.splits > 1 ? align_up((size_t)p.splits * p.slab * 4, 256) : 0;
+    size_t need = p.splits > 1 ? align_up((size_t)p.splits * p.slab * 4, 256) : 0;
+    const W9Plan p9 = plan_w9(d);          // the all-taps 3x3 kernel has its own split plan; the buffer serves either
+    if (p9.use && p9.splits > 1) {
+      const size_t n9 = align_up((size_t)p9.splits * p9.slab * 4, 256);
+      if (n9 > need) need = n9;
+    }
+    return need;
   }
   return 0;
 }
@@ -1454,6 +1462,10 @@ int32_t rigl_conv2d_stats_parts(const RiglConvDesc* d) {
   if (!d || d->cout <= 0 || (d->cout % 8)) return 0;
   const int64_t M = (int64_t)d->n * d->ho * d->wo;
   using namespace rigl::k1;
+  if (!tiny_cin(d) && !small_cin(d)) {
+    const C3Plan p3 = plan_c3(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo, d->n, d->cout, d->cin);
+    if (p3.use) return (int32_t)p3.tiles_m;   // 3x3 slab forward: one partial per tile of whole image rows
+  }
   if (!tiny_cin(d) && !small_cin(d) &&
       plan_t196(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo, M, d->cout, d->cin).use)
     return (int32_t)(M / T196_BMV);      // tile196 forward: one partial per 196-row tile
@@ -1503,6 +1515,16 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, cons
     a.sh = a.sw = 1; a.ph = a.pw = 0; a.b_row_stride = Kp; a.b_tap_stride = 0;
     a.a_bytes = (uint32_t)((size_t)a.M * Kp * 2); a.b_bytes = (uint32_t)((size_t)d->cout * Kp * 2);
   } else {
+    const C3Plan p3 = plan_c3(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo, d->n, d->cout, d->cin);
+    if (p3.use) {
+      C3Args t = {};
+      t.A = x; t.B = w_ohwi; t.C = y; t.STATS = stats; t.M = a.M; t.N = d->cout; t.Cred = d->cin; t.H = d->h; t.W = d->w; t.nimg = d->n;
+      t.b_row_stride = 9 * d->cin; t.b_tap_stride = d->cin; t.ldc = d->cout;
+      t.a_bytes = (uint32_t)((size_t)a.M * d->cin * 2); t.b_bytes = (uint32_t)((size_t)9 * d->cin * d->cout * 2);
+      if (!launch_c3<0>(p3, t, st)) return fail(RIGL_ELAUNCH, "rigl_masked_conv2d_fwd: 3x3 slab kernel could not get its LDS");
+      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
+      return RIGL_OK;
+    }
     const T196Plan tp = plan_t196(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo,
                                   a.M, d->cout, d->cin);
     if (tp.use) {
@@ -1556,8 +1578,18 @@ int rigl_masked_conv2d_dgrad_acc(const RiglConvDesc* d, const rigl_bf16* dy, con
   if ((d->cin % 8) || (d->cout % 8)) return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_dgrad: cin/cout %% 8 != 0 (use the reference kernel)");
   hipStream_t st = as_stream(stream);
   ProfFamily prof(PROF_CONV_DGRAD);
+  const C3Plan p3 = plan_c3(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo, d->n, d->cin, d->cout, true);
+  if (p3.use) {
+    C3Args t = {};
+    t.A = dy; t.B = w_hwio; t.C = dx; t.ADD = addend; t.M = d->n * d->h * d->w; t.N = d->cin; t.Cred = d->cout;
+    t.H = d->h; t.W = d->w; t.nimg = d->n; t.b_row_stride = d->cout; t.b_tap_stride = d->cin * d->cout; t.ldc = d->cin;
+    t.a_bytes = (uint32_t)((size_t)t.M * d->cout * 2); t.b_bytes = (uint32_t)((size_t)9 * d->cin * d->cout * 2);
+    if (!launch_c3<1>(p3, t, st)) return fail(RIGL_ELAUNCH, "rigl_masked_conv2d_dgrad: 3x3 slab kernel could not get its LDS");
+    RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
+    return RIGL_OK;
+  }
   const T196Plan tp = plan_t196(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo,
-                                (int64_t)d->n * d->h * d->w, d->cin, d->cout);
+                                (int64_t)d->n * d->h * d->w, d->cin, d->cout, true);
   if (tp.use) {
     T196Args t = {};
     t.A = dy; t.B = w_hwio; t.C = dx; t.ADD = addend; t.M = d->n * d->h * d->w; t.N = d->cin; t.Cred = d->cout;
@@ -1591,6 +1623,26 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   const size_t need = rigl_conv2d_workspace_bytes(d, 2);
   if (need && (!workspace || workspace_bytes < need)) return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
   ProfFamily prof(PROF_CONV_WGRAD);
+  {
+    const W9Plan p9 = plan_w9(d);
+    if (p9.use && !tiny_cin(d) && !small_cin(d)) {
+      W9Args w = {};
+      w.X = x; w.DY = dy; w.M = d->n * d->h * d->w; w.Cin = d->cin; w.Cout = d->cout; w.H = d->h; w.W = d->w;
+      w.tiles_ci = p9.tiles_ci; w.tiles_co = p9.tiles_co; w.splits = p9.splits; w.kt_per_split = p9.kt_per_split;
+      w.hb = p9.hb; w.slab_elems = p9.slab;
+      w.x_bytes = (uint32_t)((size_t)w.M * d->cin * 2); w.dy_bytes = (uint32_t)((size_t)w.M * d->cout * 2);
+      w.fd_w = make_fastdiv(d->w); w.fd_h = make_fastdiv(d->h);
+      w.OUT = p9.splits > 1 ? static_cast<float*>(workspace) : dw;
+      const dim3 grid9((unsigned)((int64_t)p9.tiles_ci * p9.tiles_co * p9.splits));
+      RIGL_K_LAUNCH(k_wgrad9, grid9, dim3(THREADS), 0, st, w);
+      if (p9.splits > 1) {
+        ReduceArgs ra = {static_cast<const float*>(workspace), dw, p9.slab, p9.slab, p9.splits};
+        launch_wgrad_reduce(ra, st);
+      }
+      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_wgrad");
+      return RIGL_OK;
+    }
+  }
   WgradArgs a = {};
   a.DY = dy; a.M = d->n * d->ho * d->wo; a.Cout = d->cout;
   a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
@@ -1693,11 +1745,15 @@ int rigl_masked_conv2d_bwd_deferred(const RiglConvDesc* d, const rigl_bf16* x, c
   if (have_flush && (!flush->slabs || !flush->dw)) return fail(RIGL_EINVAL, "rigl_masked_conv2d_bwd: NULL buffer in the pending reduce");
   hipStream_t st = as_stream(stream);
   // RIGL_T196_BWD=1: layers whose dgrad has a tile196 plan run wgrad and that dgrad as two launches instead of sharing one
-  static const bool t196_bwd = [] { const char* e = getenv("RIGL_T196_BWD"); return e ? atoi(e) != 0 : false; }();
-  const bool dgrad_196 = t196_bwd && dx && (d->cin % 8) == 0 && (d->cout % 8) == 0 &&
-      plan_t196(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo,
-                (int64_t)d->n * d->h * d->w, d->cin, d->cout).use;
-  if (fuse && !dgrad_196 && dx && x && dy && w_hwio && dw && !tiny_cin(d) && !small_cin(d) && (d->cin % 8) == 0 && (d->cout % 8) == 0 &&
+  // A layer's dX must come from the same kernel whichever entry point computes it (rigl_masked_conv2d_dgrad or this
+  // one): the 3x3 slab / tile196 kernels accumulate in another order than the igemm body of the shared launch, so layers
+  // that have such a dgrad plan run wgrad and dgrad as two launches.
+  const bool dgrad_196 = dx && (d->cin % 8) == 0 && (d->cout % 8) == 0 &&
+      (plan_c3(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo, d->n, d->cin, d->cout, true).use ||
+       plan_t196(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo,
+                 (int64_t)d->n * d->h * d->w, d->cin, d->cout, true).use);
+  const bool wgrad_9 = !tiny_cin(d) && !small_cin(d) && plan_w9(d).use;      // the all-taps 3x3 weight gradient is its own launch
+  if (fuse && !dgrad_196 && !wgrad_9 && dx && x && dy && w_hwio && dw && !tiny_cin(d) && !small_cin(d) && (d->cin % 8) == 0 && (d->cout % 8) == 0 &&
       wgrad_use_tr() && conv_dma_stages() == 3) {
     IgemmArgs ad = dgrad_args(d, dy, w_hwio, addend, dx);
     const IgemmPlan pd = plan_igemm<1>(ad);

@@ -15,19 +15,31 @@
 // tap, K-step) in the same order in both variants and whatever tile it falls into, so the result does
 // not depend on the plan (batch size, column width) -- only on the operands.
 //
-// 3x3 mode keeps the INPUT SLAB of the tile resident in LDS: for a block of 32 channels the 196 pixels of
-// the tile plus a halo of W + 1 pixels on either side (flat NHW index space) are fetched ONCE and the nine
-// taps read it as shifted views -- the activation operand crosses L2 -> LDS once per channel block instead
-// of nine times, and only the 8 KB weight tiles stream through the 3-deep DMA ring.  Pixels a tap must not
-// see (image border, the neighbouring image inside a multi-image tile, the 28 padding rows) are redirected
-// to a 64-byte zero row by a per-lane 9-bit validity mask computed once.  The slab is double buffered over
-// channel blocks: block cb + 1 is fetched while the nine K-tiles of block cb are multiplied.
+// 3x3 mode keeps the INPUT SLAB of the tile resident in LDS: for a block of 32 channels the image rows the tile
+// touches (plus one row above and below) are fetched ONCE and the nine taps read them as shifted views -- the
+// activation operand crosses L2 -> LDS once per channel block instead of nine times, and only the 8 KB weight
+// tiles stream through the 3-deep DMA ring.  The slab is stored ZERO-PADDED: an image row of W pixels takes W + 2
+// entries (a zero pixel at either end) and an all-zero row separates consecutive images, so a tap is nothing but a
+// constant offset (dh (W + 2) + dw entries) from the lane's centre entry -- no per-tap bounds test, no select.
+// Entries are 80 bytes apart (64 of data + 16 unused): consecutive entries then fall into distinct 16-byte bank
+// slots (5 r mod 16), i.e. ds_read_b128 is conflict-free without an XOR swizzle, whose recomputation per tap was
+// what made the first version of this kernel issue-bound (measured: 58 us with, 29 us without the fragment-read
+// path on the 14x14x256 layer; ~14 instructions per MFMA at one wave per SIMD).  `buffer_load ... lds` writes
+// lane-linearly, so every fifth lane lands on an unused tail and the pad entries are out-of-range lanes (zeros).
+// The slab is double buffered over channel blocks: block cb + 1 is fetched while the nine K-tiles of block cb are
+// multiplied.  Rows 196..223 of the tile repeat row 195 (computed, never stored, excluded from the statistics).
 //
 // Everything else follows conv.hip's igemm: `buffer_load ... lds` with the XOR swizzle on the source
 // side, counted vmcnt + one raw barrier per K-tile, transposed accumulators, bf16 output staged through
 // LDS, optional batch-norm partial statistics (one partial row per 196-row tile) and optional addend.
 // The index arithmetic is restated lane by lane in tools/emu/t196_emu.py and checked there against a
 // plain convolution (there is no GPU where this is written).
+
+// Development ablations (never defined in the product build; tools/build_alt.sh + RIGL_HIP_LIB): bit 0 drops the MFMAs
+// (fragments stay live), bit 1 the fragment reads, bit 2 the DMA loads, bit 3 the per-tile barrier.
+#ifndef RIGL_T196_ABLATE
+#define RIGL_T196_ABLATE 0
+#endif
 
 struct T196Args {
   const uint16_t* A;   // activations: x (fwd) or dy (dgrad), NHWC, row space == gathered space
@@ -36,18 +48,19 @@ struct T196Args {
   const uint16_t* ADD;
   float* STATS;        // [M / 196][2][N] or NULL
   int M, N, Cred;      // rows (pixels), columns, reduction channels per tap (multiple of 32)
-  int H, W;
+  int H, W, nimg;
   int b_row_stride, b_tap_stride, ldc, tiles_n;
   uint32_t a_bytes, b_bytes;
-  FastDiv fd_w, fd_h;
+  FastDiv fd_w, fd_h, fd_w2, fd_h1;   // / W, / H, / (W + 2), / (H + 1)
 };
 
-constexpr int T196_BMV = 196, T196_BMC = 224, T196_RB = 7, T196_SLAB_ROWS = 320;
+constexpr int T196_BMV = 196, T196_BMC = 224, T196_RB = 7;
+constexpr int T196_SLAB_BYTES = 24576, T196_PITCH = 80;      // 3x3 slab buffer: up to 307 padded entries of 80 bytes
 
 template <bool K3, int BN>
 constexpr int t196_smem_bytes() {
   constexpr int EPI = T196_BMC * (BN + 8) * 2 + THREADS * 8;          // bf16 staging + statistics scratch
-  constexpr int RING = K3 ? (2 * T196_SLAB_ROWS * 64 + 3 * BN * 64 + 64) : 3 * (256 * 64 + BN * 64);
+  constexpr int RING = K3 ? (2 * T196_SLAB_BYTES + 3 * BN * 64) : 3 * (256 * 64 + BN * 64);
   return EPI > RING ? EPI : RING;
 }
 
@@ -56,9 +69,9 @@ __device__ __forceinline__ void t196_body(const T196Args& P, unsigned char* smem
   constexpr int BMV = T196_BMV, BMC = T196_BMC;
   constexpr int WN = BN / 32, WM = 4 / WN, LB = BN / 64;
   constexpr int RB = WM == 1 ? T196_RB : 4;   // row blocks per wave (BN = 64: blocks 4 wm .. 4 wm + 3; block 7 is all zeros)
-  constexpr int SLAB_B = T196_SLAB_ROWS * 64, B_STAGE = BN * 64, OFF_B = 2 * SLAB_B, OFF_ZERO = OFF_B + 3 * B_STAGE;
+  constexpr int SLAB_B = T196_SLAB_BYTES, PITCH = T196_PITCH, B_STAGE = BN * 64, OFF_B = 2 * SLAB_B;
   constexpr int A_ST = 256 * 64, STAGE = A_ST + BN * 64;
-  constexpr int LA = K3 ? 5 : 4;             // slab (per channel block) / A-tile (per K-tile) DMA instructions per wave
+  constexpr int LA = K3 ? SLAB_B / 4096 : 4;   // slab (per channel block) / A-tile (per K-tile) DMA instructions per wave
   constexpr int CS_LD = BN + 8, EPI = BMC * CS_LD * 2;
   static_assert(BN == 64 || BN == 128, "tile196: 64 or 128 columns");
 
@@ -70,7 +83,9 @@ __device__ __forceinline__ void t196_body(const T196Args& P, unsigned char* smem
   const int n0 = (int)(tile % (uint32_t)P.tiles_n) * BN;
   const int m0 = tile_m * BMV;
   const int l4 = lane >> 2, dchunk = (lane & 3) ^ ((lane >> 4) & 3), hi = lane >> 5;
-  const int halo = P.W + 1;
+  const int W2 = P.W + 2;
+  // 3x3: padded row (image rows + one gap row per image, counted over the whole batch) stored first in the slab
+  const int gr0 = fdiv(m0, P.fd_w), pr_base = gr0 + fdiv(gr0, P.fd_h) - 1;
   const int CB = P.Cred >> 5;
   const int KT = K3 ? CB * 9 : CB;
   const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.A, P.a_bytes), rsrcB = make_rsrc(P.B, P.b_bytes);
@@ -86,8 +101,15 @@ __device__ __forceinline__ void t196_body(const T196Args& P, unsigned char* smem
   for (int j = 0; j < LA; ++j) {
     const int row = (j * 4 + wave) * 16 + l4;
     if (K3) {
-      const int gp = m0 - halo + row;                                   // flat pixel of slab row `row`
-      va[j] = (row < BMV + 2 * halo && gp >= 0 && gp < P.M) ? (uint32_t)(gp * P.Cred + dchunk * 8) * 2u : OOB;
+      // lane -> (padded entry, 16-byte column) of the 80-byte-pitch slab; pads, gap rows, rows outside the batch and the
+      // unused fifth column are out-of-range lanes (the hardware writes zeros)
+      const int o = (j * 4 + wave) * 1024 + lane * 16;
+      const int e = o / PITCH, col = (o - e * PITCH) >> 4;
+      const int prr = fdiv(e, P.fd_w2), w_ = e - prr * W2 - 1;
+      const int pr = pr_base + prr;                                      // >= -1
+      const int n_ = fdiv(pr + P.H + 1, P.fd_h1) - 1, h_ = pr - n_ * (P.H + 1);
+      const bool ok = col < 4 && (unsigned)w_ < (unsigned)P.W && h_ < P.H && pr >= 0 && n_ < P.nimg;
+      va[j] = ok ? (uint32_t)(((n_ * P.H + h_) * P.W + w_) * P.Cred + col * 8) * 2u : OOB;
     } else {
       const int m = m0 + row;
       va[j] = (row < BMV && m < P.M) ? (uint32_t)(m * P.Cred + dchunk * 8) * 2u : OOB;
@@ -98,6 +120,7 @@ __device__ __forceinline__ void t196_body(const T196Args& P, unsigned char* smem
   {                                                                                                   \
     unsigned char* base_ = smem + (K3 ? OFF_B + (st_) * B_STAGE : (st_) * STAGE + A_ST);              \
     const uint32_t add_ = (uint32_t)((tap_) * P.b_tap_stride + (cb_) * 32) * 2u;                      \
+    if (!(RIGL_T196_ABLATE & 4))                                                                      \
     _Pragma("unroll") for (int j = 0; j < LB; ++j)                                                    \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                       \
           rsrcB, (__attribute__((address_space(3))) void*)(base_ + (j * 4 + wave) * 1024), 16,        \
@@ -107,6 +130,7 @@ __device__ __forceinline__ void t196_body(const T196Args& P, unsigned char* smem
   {                                                                                                   \
     unsigned char* base_ = smem + (base_off_);                                                        \
     const uint32_t add_ = (uint32_t)((cb_) * 64);                                                     \
+    if (!(RIGL_T196_ABLATE & 4))                                                                      \
     _Pragma("unroll") for (int j = 0; j < LA; ++j)                                                    \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                       \
           rsrcA, (__attribute__((address_space(3))) void*)(base_ + (j * 4 + wave) * 1024), 16,        \
@@ -117,28 +141,18 @@ __device__ __forceinline__ void t196_body(const T196Args& P, unsigned char* smem
   const int lr0 = lane & 31;
   const int row_b = wn * 32 + lr0;
   const int b_rd = row_b * 64 + (((hi ^ (row_b >> 2)) & 3) << 4);
-  uint32_t mask9[RB];
-  int a_fix[RB];                            // 1x1: fragment offset inside a stage (constant)
+  int a_fix[RB];                            // fragment offset of row block i: inside a stage (1x1) / a slab buffer, centre tap (3x3)
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
     const int lr = (blk0 + i) * 32 + lr0;   // (rows 224..255 of the 1x1 A stage are zero-filled by the DMA: block 7 multiplies zeros)
-    a_fix[i] = lr * 64 + (((hi ^ (lr >> 2)) & 3) << 4);
-    mask9[i] = 0u;
     if (K3) {
-      const int m = m0 + lr;
-      const int t = fdiv(m, P.fd_w), w_ = m - t * P.W, n_ = fdiv(t, P.fd_h), h_ = t - n_ * P.H;
-#pragma unroll
-      for (int t9 = 0; t9 < 9; ++t9) {
-        const int r = t9 / 3, s = t9 % 3;
-        const int dh = MODE == 0 ? r - 1 : 1 - r, dw = MODE == 0 ? s - 1 : 1 - s;
-        const bool ok = lr < BMV && (unsigned)(h_ + dh) < (unsigned)P.H && (unsigned)(w_ + dw) < (unsigned)P.W;
-        mask9[i] |= (ok ? 1u : 0u) << t9;
-      }
+      const int m = m0 + (lr < BMV ? lr : BMV - 1);                      // rows beyond 196 repeat row 195
+      const int gr = fdiv(m, P.fd_w), w_ = m - gr * P.W;
+      const int pe = (gr + fdiv(gr, P.fd_h) - pr_base) * W2 + w_ + 1;     // padded entry of the output pixel itself
+      a_fix[i] = pe * PITCH + hi * 16;
+    } else {
+      a_fix[i] = lr * 64 + (((hi ^ (lr >> 2)) & 3) << 4);
     }
-  }
-  if (K3) {   // the zero row, visible to every wave before the first DMA is in flight (a plain barrier then has nothing to drain)
-    if (tid < 4) *reinterpret_cast<uint4*>(smem + OFF_ZERO + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
   }
 
   f32x16 acc[RB];
@@ -149,18 +163,20 @@ __device__ __forceinline__ void t196_body(const T196Args& P, unsigned char* smem
 
   // Fragments of one K-step: the wave's 32 weight rows and all 7 row blocks of the activation operand.
   struct Frag { bf16x8 b; bf16x8 a[RB]; };
-  // a_off[i]: byte offset of row block i's K-step-0 fragment (K-step 1 = the same offset with bit 5 flipped:
-  // chunk (2 + hi) ^ sw == (hi ^ sw) ^ 2).
+  // a_off[i]: byte offset of row block i's K-step-0 fragment.  K-step 1: 1x1 (XOR-swizzled stage) = the same offset with
+  // bit 5 flipped (chunk (2 + hi) ^ sw == (hi ^ sw) ^ 2); 3x3 (linear 80-byte entries) = 32 bytes further.
 #define T196_READ(F_, bbase_, kx_)                                                                    \
-  {                                                                                                   \
+  if (!(RIGL_T196_ABLATE & 2)) {                                                                      \
     F_.b = *reinterpret_cast<const bf16x8*>(smem + (bbase_) + (b_rd ^ (kx_)));                        \
     _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                    \
-      F_.a[i] = *reinterpret_cast<const bf16x8*>(smem + (a_off[i] ^ (kx_)));                          \
+      F_.a[i] = *reinterpret_cast<const bf16x8*>(smem + (K3 ? a_off[i] + (kx_) : (a_off[i] ^ (kx_)))); \
   }
 #define T196_MFMA(F_)                                                                                 \
   {                                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                    \
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F_.b, F_.a[i], acc[i], 0, 0, 0);               \
+    _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                  \
+      if (RIGL_T196_ABLATE & 1) asm volatile("" :: "v"(F_.a[i]), "v"(F_.b));                          \
+      else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F_.b, F_.a[i], acc[i], 0, 0, 0);          \
+    }                                                                                                 \
   }
   // fragment offsets of K-tile (stage st_ | slab of block cb_, tap tap_)
 #define T196_AOFF(st_, cb_, tap_)                                                                     \
@@ -170,12 +186,8 @@ __device__ __forceinline__ void t196_body(const T196Args& P, unsigned char* smem
     } else {                                                                                          \
       const int r_ = (tap_) >= 6 ? 2 : ((tap_) >= 3 ? 1 : 0), s_ = (tap_) - 3 * r_;                   \
       const int dh_ = MODE == 0 ? r_ - 1 : 1 - r_, dw_ = MODE == 0 ? s_ - 1 : 1 - s_;                 \
-      const int sbase_ = ((cb_) & 1) * SLAB_B, shift_ = halo + dh_ * P.W + dw_;                       \
-      _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                \
-        const int srb_ = (blk0 + i) * 32 + lr0 + shift_;                                              \
-        const int addr_ = sbase_ + srb_ * 64 + (((hi ^ (srb_ >> 2)) & 3) << 4);                       \
-        a_off[i] = ((mask9[i] >> (tap_)) & 1u) ? addr_ : OFF_ZERO + (hi << 4);                        \
-      }                                                                                               \
+      const int tapoff_ = ((cb_) & 1) * SLAB_B + (dh_ * W2 + dw_) * PITCH;     /* wave-uniform */      \
+      _Pragma("unroll") for (int i = 0; i < RB; ++i) a_off[i] = a_fix[i] + tapoff_;                   \
     }                                                                                                 \
   }
 #define T196_BBASE(st_) (K3 ? OFF_B + (st_) * B_STAGE : (st_) * STAGE + A_ST)
@@ -212,7 +224,7 @@ __device__ __forceinline__ void t196_body(const T196Args& P, unsigned char* smem
   int cb3 = 0, tap3 = K3 ? 3 : 0;            // ... of tile kt + 3
   int cbc = 0, tapc = 0;                     // ... of tile kt
   if constexpr (!K3) { cb1 = 1; cb3 = 3; }
-  Frag F0, F1;
+  Frag F0 = {}, F1 = {};
   T196_AOFF(0, 0, 0);
   // The part of an iteration between the two MFMA batches (tile kt is in registers; kt + 1 < KT):
 #define T196_MID()                                                                                    \
@@ -222,7 +234,7 @@ __device__ __forceinline__ void t196_body(const T196Args& P, unsigned char* smem
     if (slab_pending) wait_vmcnt<L + LA>();                                                           \
     else if (kt + 2 < KT) wait_vmcnt<L>();                                                            \
     else wait_vmcnt<0>();                                                                             \
-    __builtin_amdgcn_s_barrier();                                                                     \
+    if (!(RIGL_T196_ABLATE & 8)) __builtin_amdgcn_s_barrier();                                        \
     if (kt + 3 < KT) {                                                                                \
       if constexpr (!K3) T196_ISSUE_A(st * STAGE, cb3);                                               \
       T196_ISSUE_B(st, cb3, tap3);                                                                    \
@@ -279,13 +291,13 @@ __device__ __forceinline__ void t196_body(const T196Args& P, unsigned char* smem
   }
   __syncthreads();
   if (MODE == 0 && P.STATS) {
-    // one partial row per tile: rows 196..223 are exact zeros (zero-filled operands), so all 224 are summed;
-    // PARTS row slices per column, combined in ascending order (deterministic)
+    // one partial row per tile over its 196 valid rows; PARTS row slices per column, combined in ascending order (deterministic)
     constexpr int PARTS = THREADS / BN, RPS = BMC / PARTS;
     const int col = tid % BN, part = tid / BN;
     float sy = 0.f, sq = 0.f;
 #pragma unroll 8
     for (int r2 = 0; r2 < RPS; ++r2) {
+      if (part * RPS + r2 >= BMV) break;
       const float v = __uint_as_float((uint32_t)Cs[(part * RPS + r2) * CS_LD + col] << 16);
       sy += v; sq = fmaf(v, v, sq);
     }
@@ -343,9 +355,10 @@ static bool t196_ready_one() {
   return ok;
 }
 
-// RIGL_T196: 0 = never, 1 = the default rule (below), 2 = wherever the shape is legal (testing / measurements).
+// RIGL_T196: 0 = never (default: inside the ResNet-50 step the kernel loses 0.2 ms of forward time although it wins 0-20 %
+// per layer in isolation, profiles/r2/README.md), 1 = forward passes of the maps <= 28x28 with K >= 128, 2 = wherever legal, dgrad too.
 static int t196_mode() {
-  static const int v = [] { const char* e = getenv("RIGL_T196"); return e ? atoi(e) : 1; }();
+  static const int v = [] { const char* e = getenv("RIGL_T196"); return e ? atoi(e) : 0; }();
   return v;
 }
 
@@ -353,17 +366,27 @@ struct T196Plan { bool use, k3; int bn; unsigned grid; };
 
 // `rows` x `cols` GEMM with `cred` reduction channels per tap of a kxk stride-1 convolution over HxW maps.
 static T196Plan plan_t196(int kh, int kw, int sh, int sw, int pt, int pl, int H, int W, int Ho, int Wo,
-                          int64_t M, int N, int cred) {
+                          int64_t M, int N, int cred, bool dgrad = false) {
   T196Plan p = {false, false, 128, 0u};
   const int mode = t196_mode();
   if (mode <= 0) return p;
   if (sh != 1 || sw != 1 || Ho != H || Wo != W) return p;
   const bool k1 = kh == 1 && kw == 1 && pt == 0 && pl == 0;
-  const bool k3 = kh == 3 && kw == 3 && pt == 1 && pl == 1;
-  if (!k1 && !k3) return p;
+  const bool k3 = false;                  // (3x3 layers are conv3x3.hpp's; this file's 3x3 mode is kept for reference only)
+  if (!k1) return p;
   if (M % T196_BMV || (cred & 31) || (N & 7) || N < 64) return p;
-  if (k3 && T196_BMV + 2 * (W + 1) > T196_SLAB_ROWS) return p;
   const int64_t tiles_m = M / T196_BMV;
+  if (k3) {
+    // the padded slab of a tile (image rows it touches + one above and below, W + 2 entries each, a gap row per image
+    // boundary inside) must fit its LDS buffer; tile starts repeat with period lcm(196, H W) / 196 <= 16 for the shapes of interest
+    const int cap = T196_SLAB_BYTES / T196_PITCH;
+    for (int64_t t = 0; t < tiles_m && t < 64; ++t) {
+      const int64_t m0 = t * T196_BMV, m1 = m0 + T196_BMV - 1;
+      const int64_t g0 = m0 / W, g1 = m1 / W;
+      const int64_t rows = (g1 + g1 / H) - (g0 + g0 / H) + 3;
+      if (rows * (W + 2) > cap) return p;
+    }
+  }
   const int cus = num_cus();
   // 128 columns when that still gives every CU a tile, else 64 (the 7x7 maps: 32 row tiles at batch 128)
   p.bn = (tiles_m * ((N + 127) / 128) >= cus) ? 128 : 64;
@@ -372,6 +395,10 @@ static T196Plan plan_t196(int kh, int kw, int sh, int sw, int pt, int pl, int H,
   if (tiles > 0x7fffffff) return p;
   p.grid = (unsigned)tiles;
   if (mode >= 2) { p.use = true; return p; }
+  // Default: FORWARD only.  A dgrad through this kernel would have to leave the launch it shares with the layer's weight
+  // gradient (its accumulation order differs from the igemm body's, and a layer's dX must not depend on the entry point);
+  // measured in the ResNet-50 step that costs more than the kernel gains (profiles/r2/README.md).
+  if (dgrad) return p;
   // default rule: the maps where the 128-row grid leaves CUs idle (<= 28x28 at batch 128: fewer than ~6 tiles
   // per CU) and the reduction is long enough to matter; the 56x56 layers are HBM-bound and stay on the old tiles.
   static const int max_hw = [] { const char* e = getenv("RIGL_T196_MAX_HW"); return e ? atoi(e) : 28; }();
@@ -384,6 +411,8 @@ template <int MODE>
 static bool launch_t196(const T196Plan& pl, T196Args& a, hipStream_t st) {
   a.tiles_n = (a.N + pl.bn - 1) / pl.bn;
   a.fd_w = make_fastdiv(a.W); a.fd_h = make_fastdiv(a.H);
+  a.fd_w2 = make_fastdiv(a.W + 2); a.fd_h1 = make_fastdiv(a.H + 1);
+  a.nimg = a.M / (a.H * a.W);
   const dim3 grid(pl.grid), blk(THREADS);
 #define RIGL_T196_GO(K3_, BN_)                                                                        \
   {                                                                                                   \
@@ -391,8 +420,7 @@ static bool launch_t196(const T196Plan& pl, T196Args& a, hipStream_t st) {
     RIGL_K_LAUNCH((k_t196<MODE, K3_, BN_>), grid, blk, (t196_smem_bytes<K3_, BN_>()), st, a);         \
     return true;                                                                                      \
   }
-  if (pl.k3) { if (pl.bn == 128) RIGL_T196_GO(true, 128) else RIGL_T196_GO(true, 64) }
-  else { if (pl.bn == 128) RIGL_T196_GO(false, 128) else RIGL_T196_GO(false, 64) }
+  if (pl.bn == 128) RIGL_T196_GO(false, 128) else RIGL_T196_GO(false, 64)
 #undef RIGL_T196_GO
   return false;
 }

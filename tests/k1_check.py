@@ -98,7 +98,8 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
       assert float((s[0] - yf.sum(0)).abs().max()) <= tol0, 'statistics: sum y'
       q = (yf * yf).sum(0)
       assert float(((s[1] - q).abs() / (q.abs() + 1e-6)).max()) <= 2e-6, 'statistics: sum y^2'
-      rows = yf.shape[0] // part.shape[0] if yf.shape[0] % part.shape[0] == 0 else 128
+      rows = 128 if part.shape[0] == (yf.shape[0] + 127) // 128 else 196      # igemm: 128-row tiles; tile196: 196
+      assert part.shape[0] == (yf.shape[0] + rows - 1) // rows
       t = min(part.shape[0] - 1, 1)
       blk = yf[t * rows:(t + 1) * rows]
       assert float((part[t, 0].double() - blk.sum(0)).abs().max()) <= 1e-5 * float(blk.abs().sum(0).max()) + 1e-6, \

@@ -28,10 +28,9 @@ def _run(args, env=None, timeout=1500):
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
 @pytest.mark.parametrize('env', [
-    {'RIGL_T196': '2', 'RIGL_T196_BWD': '1', 'RIGL_W9': '2'},     # new kernels wherever their shapes are legal
-    {'RIGL_T196': '2', 'RIGL_T196_BWD': '0', 'RIGL_W9': '0'},     # tile196 forward / dgrad next to the shared backward launch
-    {},                                                           # the default selection rules
-    {'RIGL_T196': '0', 'RIGL_W9': '0'},                           # round-1 kernels on the same shapes
+    {'RIGL_T196': '2', 'RIGL_C3': '2', 'RIGL_W9': '1'},     # every new kernel wherever its shape is legal (fwd, dgrad, wgrad)
+    {'RIGL_T196': '1', 'RIGL_C3': '1'},                     # the forward-only selection rules
+    {},                                                     # the defaults
 ])
 def test_tile196_shapes(env):
   out = _run(['--set', 't196'], env)
@@ -39,10 +38,11 @@ def test_tile196_shapes(env):
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
-def test_resnet50_layer_shapes_at_batch_128():
+@pytest.mark.parametrize('env', [{}, {'RIGL_T196': '2', 'RIGL_C3': '2'}])
+def test_resnet50_layer_shapes_at_batch_128(env):
   """All distinct ResNet-50 conv shapes at the benchmarked per-GPU batch: fwd, fwd + statistics,
-  dgrad, dgrad + addend, wgrad and the one-call backward, under the default kernel selection -- so the 256x128 forward
-  tile, the parity-class strided dgrad, tile196, the all-taps 3x3 weight gradient and the shared-launch split plans
-  are each pinned directly against the fp64 reference at the sizes they are selected for."""
-  out = _run(['--set', 'resnet50', '--batch', '128'], timeout=3000)
+  dgrad, dgrad + addend, wgrad and the one-call backward, under the default kernel selection and with the tile196 / 3x3
+  slab kernels forced wherever legal -- so the 256x128 forward tile, the parity-class strided dgrad, tile196, the slab
+  kernel and the shared-launch split plans are each pinned directly against the fp64 reference at the benchmarked sizes."""
+  out = _run(['--set', 'resnet50', '--batch', '128'], env, timeout=3000)
   assert out['cases'] == 23

@@ -15,7 +15,8 @@ The formulas are kept textually close to the HIP source; change them together.
 import numpy as np
 
 BMV, BMC, RB = 196, 224, 7
-SLAB_ROWS = 320
+SLAB_BYTES = 24576          # 3x3 slab buffer: up to 307 padded pixel entries of 80 bytes
+PITCH = 80
 OOB = 1 << 31
 
 
@@ -78,13 +79,15 @@ def run_tile(mode, k3, BN, A, B, M, N, Cred, H, W, b_row_stride, b_tap_stride, t
   KT_taps = 9 if k3 else 1
   CB = Cred // 32
   if k3:
-    SLAB_B = SLAB_ROWS * 64
+    SLAB_B = SLAB_BYTES
     B_STAGE = BN * 64
     OFF_B = 2 * SLAB_B
-    OFF_ZERO = OFF_B + 3 * B_STAGE
-    lds = Lds(OFF_ZERO + 64)
-    lds.v[OFF_ZERO // 2:OFF_ZERO // 2 + 32] = 0.0
-    halo = W + 1
+    lds = Lds(OFF_B + 3 * B_STAGE)
+    # zero-padded slab geometry: image rows are stored as W + 2 entries (a zero pixel at either end), one all-zero
+    # row separates consecutive images; the slab starts one padded row above the tile's first image row
+    Nimg = M // (H * W)
+    gr0 = m0 // W
+    pr_base = gr0 + gr0 // H - 1
   else:
     A_ST = 256 * 64
     STAGE = A_ST + BN * 64
@@ -103,11 +106,15 @@ def run_tile(mode, k3, BN, A, B, M, N, Cred, H, W, b_row_stride, b_tap_stride, t
     ok = (row < BMV) & (m < M)
     return np.where(ok, (m * Cred + dchunk * 8) * 2, OOB), (j * 4 + wave) * 1024
 
-  def voff_s(wave, j):                      # 3x3: slab rows
-    sr = (j * 4 + wave) * 16 + l4
-    gp = m0 - halo + sr
-    ok = (sr < BMV + 2 * halo) & (gp >= 0) & (gp < M)
-    return np.where(ok, (gp * Cred + dchunk * 8) * 2, OOB), (j * 4 + wave) * 1024
+  def voff_s(wave, j):                      # 3x3: padded slab, 80-byte entries (lane 4 of every 5 writes the unused tail)
+    o = (j * 4 + wave) * 1024 + lane * 16
+    e, col = o // PITCH, (o % PITCH) // 16
+    pr = pr_base + e // (W + 2)
+    w_ = e % (W + 2) - 1
+    n_, h_ = pr // (H + 1), pr % (H + 1)
+    ok = (col < 4) & (w_ >= 0) & (w_ < W) & (h_ < H) & (pr >= 0) & (n_ < Nimg)
+    pix = (n_ * H + h_) * W + w_
+    return np.where(ok, (pix * Cred + col * 8) * 2, OOB), (j * 4 + wave) * 1024
 
   def issue_b(kt):
     cb, tap = (kt // 9, kt % 9) if k3 else (kt, 0)
@@ -128,7 +135,7 @@ def run_tile(mode, k3, BN, A, B, M, N, Cred, H, W, b_row_stride, b_tap_stride, t
 
   def issue_slab(cb):
     for wave in range(4):
-      for j in range(5):
+      for j in range(6):
         vo, dst = voff_s(wave, j)
         lds.dma(A, (cb & 1) * SLAB_B + dst, np.where(vo >= OOB, OOB, vo + cb * 64))
 
@@ -136,21 +143,15 @@ def run_tile(mode, k3, BN, A, B, M, N, Cred, H, W, b_row_stride, b_tap_stride, t
   blk0 = [(wave // WN) * 4 for wave in range(4)]
   lr = [[(blk0[wave] + i) * 32 + (lane & 31) for i in range(RBW)] for wave in range(4)]
   if k3:
-    mask9 = []
+    a_base = []
     for wave in range(4):
-      mw = []
+      aw = []
       for i in range(RBW):
-        m = m0 + lr[wave][i]
-        w_ = m % W
-        h_ = (m // W) % H
-        bits = np.zeros(64, np.int64)
-        for t in range(9):
-          r, s = t // 3, t % 3
-          dh, dw = (r - 1, s - 1) if mode == 0 else (1 - r, 1 - s)
-          ok = (lr[wave][i] < BMV) & (h_ + dh >= 0) & (h_ + dh < H) & (w_ + dw >= 0) & (w_ + dw < W)
-          bits |= ok.astype(np.int64) << t
-        mw.append(bits)
-      mask9.append(mw)
+        m = m0 + np.minimum(lr[wave][i], BMV - 1)      # rows beyond 196 repeat row 195 (computed, never stored)
+        gr = m // W
+        P = (gr + gr // H - pr_base) * (W + 2) + m % W + 1
+        aw.append(P * PITCH + hi * 16)
+      a_base.append(aw)
   b_rd = [None] * 4
   for wave in range(4):
     wn = wave % WN
@@ -172,14 +173,8 @@ def run_tile(mode, k3, BN, A, B, M, N, Cred, H, W, b_row_stride, b_tap_stride, t
     if k3:
       r, s = tap // 3, tap % 3
       dh, dw = (r - 1, s - 1) if mode == 0 else (1 - r, 1 - s)
-      shift = halo + dh * W + dw
-      out = []
-      for i in range(RBW):
-        srb = lr[wave][i] + shift
-        ok = (mask9[wave][i] >> tap) & 1
-        addr = (cb & 1) * SLAB_B + srb * 64 + (((hi ^ (srb >> 2)) & 3) << 4)
-        out.append(np.where(ok == 1, addr, OFF_ZERO + (hi << 4)))
-      return out, OFF_B + st * B_STAGE
+      tapoff = (cb & 1) * SLAB_B + (dh * (W + 2) + dw) * PITCH
+      return [a_base[wave][i] + tapoff for i in range(RBW)], OFF_B + st * B_STAGE
     return [st * STAGE + lr[wave][i] * 64 + (((hi ^ (lr[wave][i] >> 2)) & 3) << 4) for i in range(RBW)], st * STAGE + A_ST
 
   def read_frags(kt, kx):
@@ -187,7 +182,7 @@ def run_tile(mode, k3, BN, A, B, M, N, Cred, H, W, b_row_stride, b_tap_stride, t
     for wave in range(4):
       a_addr, bbase = a_offsets(kt, wave)
       bfr = lds.read16(bbase + (b_rd[wave] ^ kx))
-      afs = [lds.read16(a_addr[i] ^ kx) for i in range(RBW)]
+      afs = [lds.read16((a_addr[i] + kx) if k3 else (a_addr[i] ^ kx)) for i in range(RBW)]
       assert not np.isnan(bfr).any() and not any(np.isnan(a).any() for a in afs), 'read of never-written LDS'
       out.append((bfr, afs))
     return out
@@ -226,7 +221,7 @@ def run_tile(mode, k3, BN, A, B, M, N, Cred, H, W, b_row_stride, b_tap_stride, t
     wn = wave % WN
     for i in range(RBW):
       if blk0[wave] + i >= RB:
-        assert np.all(acc[wave, i] == 0), 'the eighth row block must multiply zeros'
+        assert k3 or np.all(acc[wave, i] == 0), '1x1: the eighth row block multiplies zeros'
         continue
       for q in range(4):
         for t in range(4):
@@ -285,7 +280,7 @@ def check(mode, k, BN, Nimg, H, W, Cin, Cout, seed=0):
     m0, n0, Cs = run_tile(mode, k3, BN, A, B, M, N, Cred, H, W, brs, bts, tile, tiles_n)
     nn = min(BN, N - n0)
     out[m0:m0 + BMV, n0:n0 + nn] = Cs[:BMV, :nn]
-    assert np.all(Cs[BMV:] == 0), 'rows beyond the valid 196 must be exact zeros (statistics rely on it)'
+    assert k3 or np.all(Cs[BMV:] == 0), '1x1: rows beyond the valid 196 are exact zeros'
   assert np.array_equal(out, ref), 'mismatch mode=%d k=%d BN=%d: max err %g' % (mode, k, BN, np.nanmax(np.abs(out - ref)))
   print('ok mode=%d k=%d BN=%d  N=%d %dx%d cin=%d cout=%d' % (mode, k, BN, Nimg, H, W, Cin, Cout))
 
