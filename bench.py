@@ -2,14 +2,23 @@
 """Headline benchmark: images/sec of the ResNet-50 80 %-ERK RigL training step
 (BASELINE.json metric) on N MI355X of one node, synthetic ImageNet-shaped data.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus 1 --steps K --warmup W [--workload resnet50]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one call of ``SparseRigLOptimizer.minimize`` on a per-GPU batch of
 128 images: masked-conv forward + backward (HIP MFMA kernels), DP all-reduce of
 the dense gradient arena (RCCL), then either the fused masked Nesterov update
 (K3) or -- every 100th step -- the fused prune/regrow mask update (K2).
-Nothing is skipped inside the timed region; inputs are resident in HBM.
+Nothing is skipped inside the timed region; inputs are resident in HBM.  After the
+warm-up the global step is positioned one step before a multiple of the update
+period, so the SECOND timed step of every run is a mask-update iteration (K2 is
+inside the timed window and on the JSON line for any --steps >= 2); later updates
+fall every 100 steps as in training.
+
+``--workload`` selects the configuration (BASELINE.json `configs`): resnet50 (the
+metric's own config, default), resnet50_erk99, mobilenet_v1, wrn22 -- the other
+three are side measurements with the same JSON contract; `config.workload` names
+what ran.
 
 Rank 0 prints ONE JSON line (contract in the task statement) that also carries
   "roofline":     achieved dense-equivalent conv TFLOP/s vs the 2.5 PF bf16 MFMA
@@ -20,6 +29,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) that also carries
                   timed on a bounded sample on this host's cores (N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,6 +41,71 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+UPDATE_PERIOD = 100          # maskupdate_frequency (imagenet_train_eval.py:244, resnet_train_eval.py:101)
+
+
+def build_workload(name, g, dev, batch, rank, sparsity):
+  """Returns dict(model, images, labels, loss(), label, metric, opt_kwargs, lr(global_batch))."""
+  import numpy as np
+  from rigl_amd import sparse_utils
+  if name in ('resnet50', 'resnet50_erk99'):
+    from rigl_amd.workloads import resnet50
+    dense_stem = name == 'resnet50_erk99'
+    if sparsity is None:
+      sparsity = 0.99 if dense_stem else 0.8
+    model = resnet50.ResNet50(g, prune_first_layer=not dense_stem, seed=0)
+    np.random.seed(0)                       # identical masks on every rank
+    sparse_utils.get_mask_init_fn(g.get_masks(), 'erdos_renyi_kernel', sparsity, {})()
+    images, labels = resnet50.synthetic_batch(batch, dev, seed=1234 + rank)
+    return dict(
+        model=model, images=images, labels=labels, loss=lambda: model.loss(images, labels, label_smoothing=0.1),
+        label='ResNet-50 v1.5, ERK(kernel) %.2f sparse, %d masked tensors%s, RigL dT=100 drop 0.3 cosine, Nesterov 0.9, '
+              'wd 1e-4, label smoothing 0.1, 224x224x3 NHWC' % (sparsity, len(g.get_masks()), ' (dense stem)' if dense_stem else ''),
+        metric='images/sec/node, ResNet-50 %d%% ERK RigL step' % round(sparsity * 100),
+        lr=lambda gb: 0.1 * gb / 256.0,      # imagenet_train_eval.py:317-330 (peak LR)
+        opt=dict(begin_step=0, end_step=25000, frequency=UPDATE_PERIOD, drop_fraction=0.3, drop_fraction_anneal='cosine'))
+  if name == 'mobilenet_v1':
+    from rigl_amd.workloads import mobilenet_v1
+    if sparsity is None:
+      sparsity = 0.9
+    model = mobilenet_v1.MobileNetV1(g, seed=0)
+    np.random.seed(0)
+    sparse_utils.get_mask_init_fn(g.get_masks(), 'random', sparsity, {})()
+    images, labels = mobilenet_v1.synthetic_batch(batch, dev, seed=1234 + rank)
+    return dict(
+        model=model, images=images, labels=labels, loss=lambda: model.loss(images, labels, label_smoothing=0.1),
+        label='MobileNet-v1, uniform %.2f on the 13 pointwise convs + final_dense (%d masked tensors; depthwise convs and '
+              'stem dense), RigL dT=100 drop 0.3 cosine, Nesterov 0.9, wd 4e-5, label smoothing 0.1, 224x224x3 NHWC'
+              % (sparsity, len(g.get_masks())),
+        metric='images/sec/node, MobileNet-v1 %d%% uniform RigL step' % round(sparsity * 100),
+        lr=lambda gb: 0.1 * gb / 256.0,
+        opt=dict(begin_step=0, end_step=25000, frequency=UPDATE_PERIOD, drop_fraction=0.3, drop_fraction_anneal='cosine'))
+  if name == 'wrn22':
+    from rigl_amd.workloads import wide_resnet
+    if sparsity is None:
+      sparsity = 0.8
+    model = wide_resnet.WideResNet(g, depth=22, width=1)
+    np.random.seed(0)
+    sparse_utils.get_mask_init_fn(g.get_masks(), 'erdos_renyi_kernel', sparsity, {})()
+    images, labels = wide_resnet.synthetic_batch(batch, dev, seed=1234 + rank)
+    return dict(
+        model=model, images=images, labels=labels, loss=lambda: model.loss(images, labels),
+        label='CIFAR WideResNet-22-1 ("ResNet-20"), ERK(kernel) %.2f sparse, %d masked tensors (dense stem), RigL dT=100 '
+              'drop 0.3 constant, Nesterov 0.9, wd 5e-4, 32x32x3 NHWC' % (sparsity, len(g.get_masks())),
+        metric='images/sec/node, CIFAR WRN-22-1 %d%% ERK RigL step' % round(sparsity * 100),
+        lr=lambda gb: 0.1,                    # resnet_train_eval.py:189-203
+        opt=dict(begin_step=0, end_step=75000, frequency=UPDATE_PERIOD, drop_fraction=0.3, drop_fraction_anneal='constant'))
+  raise ValueError('unknown workload %r' % (name,))
+
+
+def lib_sha16():
+  from rigl_amd import _lib
+  try:
+    with open(_lib.LIB_PATH, 'rb') as fh:
+      return hashlib.sha256(fh.read()).hexdigest()[:16]
+  except OSError:
+    return None
+
 
 def main():
   ap = argparse.ArgumentParser()
@@ -38,9 +113,13 @@ def main():
   ap.add_argument('--steps', type=int, default=100)
   ap.add_argument('--warmup', type=int, default=20)
   ap.add_argument('--batch', type=int, default=128, help='per-GPU batch')
-  ap.add_argument('--sparsity', type=float, default=0.8)
+  ap.add_argument('--workload', default='resnet50', choices=('resnet50', 'resnet50_erk99', 'mobilenet_v1', 'wrn22'))
+  ap.add_argument('--sparsity', type=float, default=None, help="override the workload's sparsity")
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-prof', action='store_true')
+  ap.add_argument('--no-sync', action='store_true',
+                  help='N > 1 only: run the step WITHOUT the gradient exchange (replicas diverge; gives the compute-only step '
+                       'time that comm_exposed_ms is measured against -- never a headline number)')
   ap.add_argument('--prof-every', type=int, default=10,
                   help='HIP-event timing of the K1 launches on every Nth timed step (1 = every step); the stamped '
                        'dispatches cost ~4 us each in the queue, 0.7 ms per fully profiled step')
@@ -58,35 +137,30 @@ def main():
   dev = torch.device('cuda', dev_index)
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC only on this pool (RCCL needs it)
     if backend == 'nccl':
       dist.init_process_group('nccl', device_id=dev)
     else:
       dist.init_process_group(backend)
   assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
-  import numpy as np
-  from rigl_amd import ops, sparse_optimizers, sparse_utils, train, variables
+  from rigl_amd import ops, sparse_optimizers, train, variables
   from rigl_amd.dist import GradSync
-  from rigl_amd.workloads import resnet50, shapes
+  from rigl_amd.workloads import shapes
 
-  # ---- build: ResNet-50, all 54 kernels masked, ERK(-kernel) 0.8 (README.md:84-90)
   g = variables.reset_default_graph(dev)
-  model = resnet50.ResNet50(g, seed=0)
-  np.random.seed(0)                       # identical masks on every rank
-  sparse_utils.get_mask_init_fn(g.get_masks(), 'erdos_renyi_kernel', args.sparsity, {})()
-  sync = GradSync(g) if world > 1 else None
+  wl = build_workload(args.workload, g, dev, args.batch, rank, args.sparsity)
+  sync = GradSync(g, enabled=not args.no_sync) if world > 1 else None
   global_batch = args.batch * world
-  lr = 0.1 * global_batch / 256.0          # imagenet_train_eval.py:317-330 (peak LR)
+  lr = wl['lr'](global_batch)
   inner = train.MomentumOptimizer(lr, 0.9, use_nesterov=True, graph=g, grad_sync=sync)
   opt = sparse_optimizers.SparseRigLOptimizer(
-      inner, begin_step=0, end_step=25000, frequency=100, drop_fraction=0.3,
-      drop_fraction_anneal='cosine', grow_init='zeros', initial_acc_scale=0.0,
-      use_tpu=world > 1)
+      inner, grow_init='zeros', initial_acc_scale=0.0, use_tpu=world > 1 and not args.no_sync, **wl['opt'])
   gs = g.get_or_create_global_step()
-  images, labels = resnet50.synthetic_batch(args.batch, dev, seed=1234 + rank)
+  loss_fn = wl['loss']
 
   def step():
-    loss = model.loss(images, labels, label_smoothing=0.1)
+    loss = loss_fn()
     opt.minimize(loss, gs)
     return loss
 
@@ -96,30 +170,49 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
-  for _ in range(args.warmup):
+  for i in range(args.warmup):
+    if i == args.warmup - 1:
+      ops.work_count(True)                  # dense-equivalent MACs / depthwise bytes of one fwd + bwd
     step()
+  if args.warmup == 0:
+    ops.work_count(True)
+    step()
+  ops.work_count(False)
+  work = dict(ops.WORK)
   fence()
+  # Position the schedule: the first warm-up step was the step-0 mask update (last_update = 0); with the global step at
+  # period - 1 the first timed step is an ordinary one and the second is the next mask update.
+  if int(gs.value) < UPDATE_PERIOD - 1:
+    gs.value = UPDATE_PERIOD - 1
   prof_every = max(int(args.prof_every), 1)
   if not args.no_prof:
     ops.prof_collect()
+  if sync is not None:
+    sync.reset_timeline()
   t0 = time.perf_counter()
   n_updates = 0
   n_profiled = 0
+  n_profiled_updates = 0
   for i in range(args.steps):
     if not args.no_prof:
-      on = i % prof_every == 0 or int(gs.value) % 100 == 0     # ... and the mask-update step (K2)
+      upd = opt.is_mask_update_iter(int(gs.value), opt._last_update_step)   # (pure host arithmetic; the step recomputes it)
+      on = i % prof_every == 0 or upd       # ... and every mask-update step (K2)
       ops.prof_enable(on)                  # a flag flip; the events are read after the timed region
       n_profiled += int(on)
     before = gs.value
     step()
-    n_updates += int(gs.value == before)
+    is_upd = int(gs.value == before)
+    n_updates += is_upd
+    if not args.no_prof and on:
+      n_profiled_updates += is_upd
   fence()
   dt = time.perf_counter() - t0
   prof = None
   if not args.no_prof:
     ops.prof_enable(False)
     prof = ops.prof_collect()
-  masks_same = sync.check_masks_identical() if sync is not None else None   # after the timed region: replicas must agree
+  masks_same = sync.check_masks_identical() if (sync is not None and not args.no_sync) else None   # after the timed region
+  timeline = sync.timeline_summary() if sync is not None else None
   # C1 on its own, after the timed region: the gradient arena all-reduced in GradSync's buckets, nothing
   # to overlap with -- what the step would pay if none of it hid behind the backward pass.
   ar = None
@@ -141,6 +234,22 @@ def main():
           'note': 'fp32 gradient arena, bucketed all-reduce alone (outside the timed region); bus = 2(N-1)/N x bytes / time, '
                   'peak = 7 xGMI links x 153 GB/s per GPU'}
     del buf, chunks
+  # exposed communication: the same steps once more WITHOUT the exchange (after everything that is reported above;
+  # the replicas diverge from here on, nothing below reads the model)
+  comm_exposed = None
+  if sync is not None and not args.no_sync and os.environ.get('RIGL_BENCH_COMM_EXPOSED', '1') == '1':
+    sync.enabled = False
+    n_probe = min(args.steps, 20)
+    for _ in range(2):
+      step()
+    fence()
+    tb = time.perf_counter()
+    for _ in range(n_probe):
+      step()
+    fence()
+    t_nosync = torch.tensor([(time.perf_counter() - tb) / n_probe], dtype=torch.float64, device=dev)
+    dist.all_reduce(t_nosync, op=dist.ReduceOp.MAX)
+    comm_exposed = {'ms_per_step_without_exchange': float(t_nosync.item()) * 1e3, 'steps': n_probe}
   t = torch.tensor([dt], dtype=torch.float64, device=dev)
   if world > 1:
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -149,42 +258,61 @@ def main():
   value = global_batch * args.steps / dt
 
   if rank == 0:
-    fwd_macs, dgrad_macs = shapes.resnet50_macs_per_image()
-    flops_per_step = 2.0 * (2 * fwd_macs + dgrad_macs) * args.batch   # per GPU, dense-equivalent
+    macs = work['fwd_macs'] + work['dgrad_macs'] + work['wgrad_macs']
+    flops_per_step = 2.0 * macs              # per GPU, dense-equivalent (the mask saves no MFMA work by design)
+    if args.workload.startswith('resnet50'):
+      fwd_macs, dgrad_macs = shapes.resnet50_macs_per_image()
+      analytic = 2.0 * (2 * fwd_macs + dgrad_macs) * args.batch
+      assert abs(analytic - flops_per_step) <= 1e-9 * analytic, (analytic, flops_per_step)   # counter == rigl/str_sparsities.py:29
     out = {
-        'metric': 'images/sec/node, ResNet-50 80% ERK RigL step',
+        'metric': wl['metric'],
         'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': 'ResNet-50 v1.5, ERK(kernel) %.2f sparse, 54 masked tensors, RigL dT=100 '
-                               'drop 0.3 cosine, Nesterov 0.9, wd 1e-4, label smoothing 0.1, 224x224x3 NHWC'
-                               % args.sparsity,
+        'config': {'workload': wl['label'],
                    'global_batch': global_batch, 'per_gpu_batch': args.batch,
                    'parallelism': 'dp%d' % world, 'mask_updates_in_timed_region': n_updates,
-                   'masks_identical_across_ranks': masks_same},
+                   'masks_identical_across_ranks': masks_same,
+                   'gradient_exchange': (None if world == 1 else ('off (--no-sync)' if args.no_sync else 'on')),
+                   'lib_sha16': lib_sha16()},
     }
     if ar is not None:
       out['allreduce'] = ar
+      if timeline is not None:
+        out['allreduce']['in_step'] = timeline
+      if comm_exposed is not None:
+        comm_exposed['comm_exposed_ms'] = ms_per_step - comm_exposed['ms_per_step_without_exchange']
+        comm_exposed['note'] = ('step time with the gradient exchange minus the same step without it (max over ranks, '
+                                'measured right after the timed region)')
+        out['allreduce']['exposed'] = comm_exposed
     if prof is not None:
       conv_ms = sum(prof[k][0] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'conv_bwd'))
       launches = sum(prof[k][1] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'conv_bwd'))
       n_fwd_bwd = max(n_profiled, 1)       # every profiled step (update or not) runs fwd + bwd
       achieved = flops_per_step * n_fwd_bwd / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
       # HBM bytes per K1 launch from the PMC passes (rocprofv3 cannot run inside this process: the two
-      # counters need separate passes) -- tools/pmc_summary.py writes the figure next to the profiles.
-      traffic = None
-      try:
-        with open(os.path.join(ROOT, 'profiles', 'r1', 'k1_traffic.json')) as fh:
-          traffic = float(json.load(fh)['bytes_per_launch'])
-      except (OSError, ValueError, KeyError):
-        pass
+      # counters need separate passes) -- tools/pmc_summary.py writes the figure next to the profiles,
+      # stamped with the library build it was collected on.
+      traffic = traffic_build = None
+      if args.workload == 'resnet50':
+        for rnd in ('r2', 'r1'):
+          try:
+            with open(os.path.join(ROOT, 'profiles', rnd, 'k1_traffic.json')) as fh:
+              tj = json.load(fh)
+            traffic = float(tj['bytes_per_launch'])
+            traffic_build = tj.get('lib_sha16')
+            break
+          except (OSError, ValueError, KeyError):
+            continue
       out['roofline'] = {
           'bound': 'mfma', 'achieved': achieved, 'peak': 2500.0, 'unit': 'TFLOP/s',
           'frac': achieved / 2500.0, 'traffic': traffic,
-          'traffic_unit': 'HBM bytes per K1 launch (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes, profiles/r1/pmc_hbm_traffic.csv)',
+          'traffic_unit': 'HBM bytes per K1 launch (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes, profiles/r*/pmc_hbm_traffic.csv)',
+          'traffic_lib_sha16': traffic_build,
+          'traffic_from_this_build': (traffic_build == lib_sha16()) if traffic_build else None,
           'kernel': 'K1 masked conv implicit-GEMM (fwd, dgrad, wgrad; conv_bwd = dgrad + wgrad sharing one launch): all %d '
-                    'kernel dispatches of %d of the %d timed steps (every %d-th), each stamped by its own dispatch '
-                    '(hipExtLaunchKernelGGL start/stop events)' % (launches, n_profiled, args.steps, prof_every),
+                    'kernel dispatches of %d of the %d timed steps (every %d-th + the mask-update steps), each stamped by its '
+                    'own dispatch (hipExtLaunchKernelGGL start/stop events)' % (launches, n_profiled, args.steps, prof_every),
           'profiled_steps': n_profiled,
           'algorithmic_gflop_per_image': flops_per_step / args.batch / 1e9,
           'avg_launch_ms': conv_ms / max(launches, 1),
@@ -192,33 +320,42 @@ def main():
           'by_kind_ms_per_step': {k: prof[k][0] / n_fwd_bwd for k in prof},
           'conv_share_of_step': (conv_ms / n_fwd_bwd) / ms_per_step,
       }
-      # what the same three GEMMs per layer could reach: each layer at the better of its MFMA and HBM bounds
-      lb, lb_mfma, lb_hbm = shapes.resnet50_layerwise_bound(args.batch)
-      out['roofline']['layerwise_bound'] = {
-          'ms_per_step': lb * 1e3, 'mfma_only_ms': lb_mfma * 1e3, 'hbm_only_ms': lb_hbm * 1e3,
-          'frac_of_bound': lb * 1e3 / (conv_ms / n_fwd_bwd) if conv_ms > 0 else 0.0,
-          'note': 'sum over layers and fwd/dgrad/wgrad of max(flops / 2.5 PF, algorithmic bytes / 8 TB/s); '
-                  'mfma_only_ms / ms_per_step is the highest `frac` any implementation of these layers can reach'}
-      # the two HBM-bound kernels of the path, against the 8 TB/s HBM3E peak (algorithmic bytes: SURVEY 8d)
+      if args.workload.startswith('resnet50'):
+        # what the same three GEMMs per layer could reach: each layer at the better of its MFMA and HBM bounds
+        lb, lb_mfma, lb_hbm = shapes.resnet50_layerwise_bound(args.batch)
+        out['roofline']['layerwise_bound'] = {
+            'ms_per_step': lb * 1e3, 'mfma_only_ms': lb_mfma * 1e3, 'hbm_only_ms': lb_hbm * 1e3,
+            'frac_of_bound': lb * 1e3 / (conv_ms / n_fwd_bwd) if conv_ms > 0 else 0.0,
+            'note': 'sum over layers and fwd/dgrad/wgrad of max(flops / 2.5 PF, algorithmic bytes / 8 TB/s); '
+                    'mfma_only_ms / ms_per_step is the highest `frac` any implementation of these layers can reach'}
+      # the HBM-bound kernels of the path, against the 8 TB/s HBM3E peak (algorithmic bytes: SURVEY 8d)
       n_params = sum(v.numel for v in g.trainable_variables())
       n_masked = sum(m.numel for m in g.get_masks())
       k3_ms, k3_n = prof['sgd_momentum']
       k2_ms, k2_n = prof['prune_regrow']
       hbm = {}
       if k3_ms > 0:
-        steps_k3 = max(n_profiled - (1 if k2_n else 0), 1)      # update iterations skip the weight update (F9)
+        steps_k3 = max(n_profiled - n_profiled_updates, 1)      # update iterations skip the weight update (F9)
         gbs = 20.1 * n_params / (k3_ms / steps_k3 * 1e-3) / 1e9
         hbm['masked_sgd_momentum'] = {'bound': 'hbm', 'achieved': gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0,
                                       'algorithmic_bytes_per_param': 20.1, 'ms_per_step': k3_ms / steps_k3}
       if k2_ms > 0 and k2_n > 0:
         gbs = 8.25 * n_masked / (k2_ms / k2_n * 1e-3) / 1e9
         hbm['prune_regrow'] = {'bound': 'hbm', 'achieved': gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0,
-                               'algorithmic_bytes_per_weight': 8.25, 'ms_per_update': k2_ms / k2_n}
+                               'algorithmic_bytes_per_weight': 8.25, 'ms_per_update': k2_ms / k2_n, 'updates_timed': k2_n,
+                               'masked_weights': n_masked}
+      dw_ms, dw_n = prof['depthwise']
+      if dw_ms > 0 and work['depthwise_bytes'] > 0:
+        gbs = work['depthwise_bytes'] * n_fwd_bwd / (dw_ms * 1e-3) / 1e9
+        hbm['depthwise_conv'] = {'bound': 'hbm', 'achieved': gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0,
+                                 'algorithmic_bytes_per_step': work['depthwise_bytes'], 'ms_per_step': dw_ms / n_fwd_bwd,
+                                 'launches_per_step': dw_n / n_fwd_bwd,
+                                 'note': 'K1d fwd + dgrad + wgrad of the 13 dense depthwise 3x3 convs: one bf16 tensor in, one out per pass'}
       out['roofline']['hbm_kernels'] = hbm
     if world == 1 and not args.no_cpu_baseline:
       try:
         from oracle import resnet_cpu
-        out['cpu_baseline'] = resnet_cpu.time_cpu_baseline(batch=8, steps=2)
+        out['cpu_baseline'] = resnet_cpu.time_cpu_baseline()
       except Exception as e:  # pylint: disable=broad-except
         out['cpu_baseline'] = {'value': None, 'unit': 'images/sec', 'cores': os.cpu_count(), 'kind': 'port',
                                'sample': 'failed: %r' % (e,)}

@@ -410,10 +410,11 @@ int rigl_softmax_xent(int32_t rows, int32_t classes, const rigl_bf16* logits,
  * recorded events and returns accumulated milliseconds / launch counts per
  * kernel family: 0 conv_fwd, 1 conv_dgrad, 2 conv_wgrad, 3 prune_regrow,
  * 4 sgd_momentum, 5 pack_weights, 6 conv_bwd (the fused dgrad + wgrad launch
- * of rigl_masked_conv2d_bwd, with its split-K reduce).                      */
-#define RIGL_PROF_KINDS 7
+ * of rigl_masked_conv2d_bwd, with its split-K reduce), 7 depthwise (K1d, the
+ * three rigl_depthwise_conv2d_* entry points).                              */
+#define RIGL_PROF_KINDS 8
 int rigl_prof_enable(int32_t on);
-int rigl_prof_collect(double* ms_per_kind /*[7]*/, int64_t* launches /*[7]*/);
+int rigl_prof_collect(double* ms_per_kind /*[8]*/, int64_t* launches /*[8]*/);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ RIGL_EWORKSPACE = -3
 RIGL_EUNSUPPORTED = -4
 COUNTS_PER_LAYER = 8
 PROF_KINDS = ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'prune_regrow',
-              'sgd_momentum', 'pack_weights', 'conv_bwd')
+              'sgd_momentum', 'pack_weights', 'conv_bwd', 'depthwise')
 
 GROW_ZEROS, GROW_GRAD_SCALE, GROW_GRAD_SIGN, GROW_EXPLICIT = 0, 1, 2, 3
 MOMRESET_ZEROS, MOMRESET_GRAD = 0, 1

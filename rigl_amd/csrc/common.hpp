@@ -32,7 +32,7 @@ inline hipStream_t as_stream(rigl_stream_t s) { return reinterpret_cast<hipStrea
 
 // ---- optional per-launch timing (rigl_prof_*) -------------------------------
 enum ProfKind { PROF_CONV_FWD = 0, PROF_CONV_DGRAD = 1, PROF_CONV_WGRAD = 2,
-                PROF_PRUNE_REGROW = 3, PROF_SGD = 4, PROF_PACK = 5, PROF_CONV_BWD = 6 };
+                PROF_PRUNE_REGROW = 3, PROF_SGD = 4, PROF_PACK = 5, PROF_CONV_BWD = 6, PROF_DEPTHWISE = 7 };
 bool prof_enabled();
 void prof_begin(int kind, hipStream_t s);
 void prof_end(int kind, hipStream_t s);

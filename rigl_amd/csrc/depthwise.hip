@@ -216,6 +216,7 @@ int rigl_depthwise_conv2d_fwd(const RiglConvDesc* d, const rigl_bf16* x, const f
   int rc = kdw::check(d, "rigl_depthwise_conv2d_fwd");
   if (rc) return rc;
   if (!x || !w || !y) return fail(RIGL_EINVAL, "rigl_depthwise_conv2d_fwd: NULL tensor");
+  ProfScope prof(PROF_DEPTHWISE, as_stream(stream));
   hipLaunchKernelGGL(kdw::k_fwd, dim3(kdw::stream_grid((int64_t)d->n * d->ho * d->wo * d->cin / 8)), dim3(kdw::THREADS), 0,
                      as_stream(stream), *d, x, w, y);
   RIGL_CHECK_LAUNCH("rigl_depthwise_conv2d_fwd");
@@ -228,6 +229,7 @@ int rigl_depthwise_conv2d_dgrad(const RiglConvDesc* d, const rigl_bf16* dy, cons
   int rc = kdw::check(d, "rigl_depthwise_conv2d_dgrad");
   if (rc) return rc;
   if (!dy || !w || !dx) return fail(RIGL_EINVAL, "rigl_depthwise_conv2d_dgrad: NULL tensor");
+  ProfScope prof(PROF_DEPTHWISE, as_stream(stream));
   hipLaunchKernelGGL(kdw::k_dgrad, dim3(kdw::stream_grid((int64_t)d->n * d->h * d->w * d->cin / 8)), dim3(kdw::THREADS), 0,
                      as_stream(stream), *d, dy, w, dx);
   RIGL_CHECK_LAUNCH("rigl_depthwise_conv2d_dgrad");
@@ -244,6 +246,7 @@ int rigl_depthwise_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const
   if (!workspace || workspace_bytes < need) return fail(RIGL_EWORKSPACE, "rigl_depthwise_conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
   kdw::WGeom g = kdw::make_wgeom(d);
   hipStream_t st = as_stream(stream);
+  ProfScope prof(PROF_DEPTHWISE, st);
   float* partial = static_cast<float*>(workspace);
   dim3 grid((unsigned)g.parts, (unsigned)((g.cg + g.tpr - 1) / g.tpr));
   hipLaunchKernelGGL(kdw::k_wgrad_partial, grid, dim3(kdw::THREADS), 0, st, *d, g, x, dy, partial);

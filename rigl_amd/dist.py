@@ -17,8 +17,13 @@ from its end to its start), so communication overlaps the remaining backward
 kernels.  The mean (1/world) is folded into the update kernel's ``grad_scale``;
 the mask update consumes the raw sum, like the reference.
 """
+import os
+import time
+
 import torch
 import torch.distributed as dist
+
+DEBUG = os.environ.get('RIGL_DEBUG', '0') == '1'     # check_masks_identical after EVERY mask update (sparse_optimizers._run_update)
 
 
 class GradSync:
@@ -38,7 +43,43 @@ class GradSync:
     self._ptr = -1        # highest-offset variable not yet produced
     self._ready = set()
     self.n_buckets_last = 0
+    # per-bucket record of the most recent step: (arena offset, elements, host ms since the step's first
+    # notification, [device events]) -- bench.py prints it next to the stand-alone all-reduce figure
+    self._timeline = []
+    self._t_first = None
+    self._timeline_events = False
+    self._wait_events = None
     graph.grad_sync = self
+
+  # ---- instrumentation ---------------------------------------------------------
+  def reset_timeline(self, device_events=True):
+    """Start recording: every bucket launch of the following steps is stamped (host clock; with
+    ``device_events`` also a CUDA event on the compute stream at the launch point and one after the
+    final wait, so that launch -> done spans are known on the device timeline)."""
+    self._timeline = []
+    self._timeline_events = bool(device_events) and self.graph.G.is_cuda
+
+  def timeline_summary(self):
+    """Buckets of the LAST step: where in the step each collective was launched and how long the
+    compute stream then still had to wait for the exchange at the end of backward."""
+    if not self._timeline:
+      return None
+    rows = []
+    wait_ms = None
+    if self._timeline_events and self._wait_events is not None:
+      torch.cuda.synchronize()
+      a, b = self._wait_events
+      wait_ms = a.elapsed_time(b)
+    first_ev = next((r[3] for r in self._timeline if r[3] is not None), None)
+    for lo, n, t_ms, ev in self._timeline:
+      row = {'arena_offset': lo, 'bytes': 4 * n, 'host_ms_after_first_ready': round(t_ms, 4)}
+      if ev is not None and first_ev is not None:
+        row['device_ms_after_first_bucket'] = round(first_ev.elapsed_time(ev), 4)
+      rows.append(row)
+    return {'buckets': rows, 'tail_wait_ms': wait_ms,
+            'note': 'last timed step: one row per all-reduce launch in launch order (backward walks the arena end -> start; '
+                    'the final row carries the head of the kernel segment together with the BN / bias segment); '
+                    'tail_wait_ms = compute-stream time between the end of backward and the last bucket being done'}
 
   def sync_initial_state(self, src=0):
     """Replicas must start from the same weights, masks and BN buffers: the
@@ -74,6 +115,8 @@ class GradSync:
     self._ready = set()
     self._hi = self._kernel_end()
     self._handles = []
+    self._timeline = []
+    self._t_first = time.perf_counter()
 
   def _reset(self):
     self._hi = None
@@ -97,12 +140,48 @@ class GradSync:
       self._launch(lo, self._hi)
       self._hi = lo
 
+  def _stamp(self, lo, n):
+    ev = None
+    if self._timeline_events:
+      ev = torch.cuda.Event(enable_timing=True)
+      ev.record()
+    t0 = self._t_first if self._t_first is not None else time.perf_counter()
+    self._timeline.append((lo, n, (time.perf_counter() - t0) * 1e3, ev))
+
   def _launch(self, lo, hi):
     if hi > lo:
       if self.graph.G.is_cuda:
         from rigl_amd import ops  # pylint: disable=import-outside-toplevel
         ops.join_side_stream(self.graph.G.device)   # weight gradients may come from the side stream
+      self._stamp(lo, hi - lo)
       self._handles.append(dist.all_reduce(self.graph.G[lo:hi], group=self.group, async_op=True))
+
+  def _launch_last(self, hi, kend):
+    """The final flush: the head of the kernel segment [0, hi) and the BN / bias segment [kend, end) as ONE
+    collective launch.  The BN / bias gradients are complete only when backward ends (the stem's batch norm
+    is its last node), so they cannot ride in an earlier bucket; sent on their own they were a second,
+    latency-bound all-reduce of ~0.2 MB behind the last bucket.  With RCCL both tensors go into one
+    group call (torch's coalescing manager = ncclGroupStart / End: one kernel, one ring traversal);
+    backends without coalescing (gloo in the CPU tests) get the two calls back to back."""
+    g = self.graph
+    end = g.G.numel()
+    parts = [(lo, h) for lo, h in ((0, hi), (kend, end)) if h > lo]
+    if not parts:
+      return
+    if len(parts) == 2 and g.G.is_cuda and dist.get_backend(self.group) == 'nccl':
+      from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+      ops.join_side_stream(g.G.device)
+      self._stamp(parts[0][0], sum(h - lo for lo, h in parts))
+      try:
+        with dist._coalescing_manager(group=self.group, device=g.G.device, async_ops=True) as cm:   # pylint: disable=protected-access
+          for lo, h in parts:
+            dist.all_reduce(g.G[lo:h], group=self.group)
+        self._handles.append(cm)
+        return
+      except (AttributeError, TypeError, RuntimeError):
+        self._timeline.pop()               # this torch has no usable coalescing manager: plain launches below
+    for lo, h in parts:
+      self._launch(lo, h)
 
   def all_reduce(self, graph=None):
     """Called once after backward: flushes what is left (the head of the kernel
@@ -113,12 +192,21 @@ class GradSync:
       return
     g = self.graph
     kend = self._kernel_end()
+    if self._hi is None:                                   # no layer notified (e.g. a model without masked convs)
+      self._timeline = []
+      self._t_first = time.perf_counter()
     hi = self._hi if self._hi is not None else kend
-    self._launch(0, hi)                                   # remaining kernels
-    self._launch(kend, g.G.numel())                       # BN / bias segment
+    self._launch_last(hi, kend)                           # remaining kernels + BN / bias segment, one launch
     self.n_buckets_last = len(self._handles)
+    if self._timeline_events:
+      a = torch.cuda.Event(enable_timing=True)
+      a.record()
     for h in self._handles:
       h.wait()                                            # stream-level wait on GPU
+    if self._timeline_events:
+      b = torch.cuda.Event(enable_timing=True)
+      b.record()
+      self._wait_events = (a, b)
     self._reset()
 
   def check_masks_identical(self):

@@ -251,6 +251,30 @@ def pack_weights(w, mask_bits, k, cout, hwio=None, ohwi=None):
 # ----------------------------------------------------------------------------
 # K1
 # ----------------------------------------------------------------------------
+# Dense-equivalent work of the K1 / K1d calls, counted on the host while ``work_count(True)`` is set: the
+# algorithmic FLOPs / bytes that bench.py's roofline divides by the kernels' measured time.
+WORK = {'fwd_macs': 0, 'dgrad_macs': 0, 'wgrad_macs': 0, 'depthwise_bytes': 0}
+_work_on = False
+
+
+def work_count(on=True):
+  global _work_on
+  _work_on = bool(on)
+  if on:
+    for k in WORK:
+      WORK[k] = 0
+
+
+def _count_macs(kind, d):
+  if _work_on:
+    WORK[kind] += d.n * d.ho * d.wo * d.kh * d.kw * d.cin * d.cout
+
+
+def _count_depthwise(d):
+  if _work_on:      # one bf16 tensor read + one written (fwd, dgrad) or two read (wgrad); weights are negligible
+    WORK['depthwise_bytes'] += 2 * d.n * (d.h * d.w + d.ho * d.wo) * d.cin
+
+
 def conv_desc(n, h, w, cin, cout, kh, kw, stride, pad_top, pad_left, ho, wo):
   sh, sw = (stride, stride) if isinstance(stride, int) else stride
   return ConvDesc(n, h, w, cin, ho, wo, cout, kh, kw, sh, sw, pad_top,
@@ -272,6 +296,7 @@ def conv_fwd(d, x, w_ohwi, y=None, force_ref=False, stats=False):
   conv epilogue (None where the MFMA path does not apply)."""
   _req(x, torch.bfloat16, 'x')
   _req(w_ohwi, torch.bfloat16, 'w_ohwi')
+  _count_macs('fwd_macs', d)
   if y is None:
     y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16,
                     device=x.device)
@@ -300,6 +325,7 @@ def conv_fwd(d, x, w_ohwi, y=None, force_ref=False, stats=False):
 def conv_dgrad(d, dy, w_hwio, dx=None, force_ref=False, addend=None):
   """dx = conv2d_backprop_input(dy, w) (+ addend, fused into the epilogue: the
   gradient accumulation of a tensor that feeds this conv and a shortcut)."""
+  _count_macs('dgrad_macs', d)
   _req(dy, torch.bfloat16, 'dy')
   _req(w_hwio, torch.bfloat16, 'w_hwio')
   if dx is None:
@@ -325,6 +351,7 @@ def conv_dgrad(d, dy, w_hwio, dx=None, force_ref=False, addend=None):
 
 def conv_wgrad(d, x, dy, dw=None, force_ref=False):
   """Dense fp32 dW in HWIO order (flat [kh*kw*cin*cout])."""
+  _count_macs('wgrad_macs', d)
   _req(x, torch.bfloat16, 'x')
   _req(dy, torch.bfloat16, 'dy')
   if dw is None:
@@ -385,6 +412,9 @@ def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None):
   _req(dw, torch.float32, 'dw')
   _req(addend, torch.bfloat16, 'addend', allow_none=True)
   lib = _lib.load()
+  _count_macs('wgrad_macs', d)
+  if need_dx and not _SIDE_WGRAD:        # (the side-stream path goes through conv_dgrad, which counts)
+    _count_macs('dgrad_macs', d)
   need = getattr(d, '_ws_wgrad', None)
   if need is None:
     need = d._ws_wgrad = lib.rigl_conv2d_workspace_bytes(C.byref(d), 2)
@@ -432,6 +462,7 @@ def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None):
 # K1d depthwise
 # ----------------------------------------------------------------------------
 def depthwise_fwd(d, x, w):
+  _count_depthwise(d)
   _req(x, torch.bfloat16, 'x')
   _req(w, torch.float32, 'w')
   y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16, device=x.device)
@@ -440,6 +471,7 @@ def depthwise_fwd(d, x, w):
 
 
 def depthwise_dgrad(d, dy, w):
+  _count_depthwise(d)
   _req(dy, torch.bfloat16, 'dy')
   _req(w, torch.float32, 'w')
   dx = torch.empty((d.n, d.h, d.w, d.cin), dtype=torch.bfloat16, device=dy.device)
@@ -448,6 +480,7 @@ def depthwise_dgrad(d, dy, w):
 
 
 def depthwise_wgrad(d, x, dy, dw):
+  _count_depthwise(d)
   _req(x, torch.bfloat16, 'x')
   _req(dy, torch.bfloat16, 'dy')
   _req(dw, torch.float32, 'dw')

@@ -309,6 +309,11 @@ class SparseSETOptimizerBase(train.Optimizer):
         initial_acc_scale=getattr(self, '_initial_acc_scale', 0.0),
         reinit_when_same=reinit_when_same)
     self.graph.shadows_dirty = True
+    if sync is not None and getattr(sync, 'enabled', False):
+      from rigl_amd import dist as rdist  # pylint: disable=import-outside-toplevel
+      if rdist.DEBUG and not sync.check_masks_identical():     # RIGL_DEBUG=1: replicas must hold ONE bitmap after every update
+        raise RuntimeError('mask update left different masks on the replicas (RIGL_DEBUG check, '
+                           'sparse_optimizers_base.py:471-476 expects identical summed gradients)')
 
 
 def _flat_f32(t, device):
