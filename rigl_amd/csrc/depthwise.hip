@@ -9,6 +9,8 @@
 // fp32 HWIO tensor [kh][kw][C][1] = flat [kh*kw][C], read directly (no shadow).
 // wgrad reduces over pixels with per-block partial sums combined in a fixed
 // order (deterministic), like the BN statistics.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace rigl {
@@ -165,6 +167,313 @@ __global__ __launch_bounds__(THREADS) void k_wgrad_final(const float* __restrict
   dw[i] = (float)a;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// 3x3 specialisations (stride 1 / 2): what MobileNet-v1 runs.  The generic kernels above spend their time in
+// 64-bit index divisions, runtime tap loops and (wgrad) nine passes over the data with <= 128 workgroups:
+// 408 GB/s of algorithmic traffic, 9.4 ms of a 13.5 ms MobileNet step (profiles/r2).  Here a thread owns 8
+// channels (16 B) of a strip of TW = 4 consecutive produced pixels: the 3 x ((TW - 1) S + 3) gathered pixels it
+// needs are fetched with buffer loads (out-of-image taps = out-of-range offsets, the hardware returns zeros:
+// no branches), unpacked once, and every gathered pixel feeds up to three outputs from registers.  Index math is
+// 32-bit with launch-time magic-number division.  Accumulation order per output is tap-major (r, s) as in the
+// generic kernels, so forward / dgrad results are bit-identical to them.
+constexpr int TW = 4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+constexpr uint32_t OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+struct FastDiv { uint32_t magic, shift; };     // q = umulhi(n, magic) >> shift, exact for 0 <= n < 2^31 (magic == 0: d == 1)
+static inline FastDiv make_fastdiv(int d) {
+  FastDiv f = {0u, 0u};
+  if (d <= 1) return f;
+  int l = 0;
+  while ((1ll << l) < (long long)d) ++l;
+  const unsigned long long p = 1ull << (31 + l);
+  f.magic = (uint32_t)((p + (unsigned long long)d - 1) / (unsigned long long)d);
+  f.shift = (uint32_t)(l - 1);
+  return f;
+}
+__device__ __forceinline__ int fdiv(int n, FastDiv f) {
+  return f.magic ? (int)(__umulhi((uint32_t)n, f.magic) >> f.shift) : n;
+}
+
+// XCD-aware block remap (hardware hands block b to XCD b % 8): consecutive logical blocks -- neighbouring image rows,
+// which share their halo rows -- land on one XCD's L2 instead of eight.  Bijective; speed only.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
+  const uint32_t q = nblk >> 3, r = nblk & 7u, x = bid & 7u, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+struct G3 {
+  int N, GH, GW;        // gathered tensor (x for fwd / wgrad, dy for dgrad)
+  int PH, PW;           // produced tensor rows / columns (y | dx); for wgrad: the dy tensor
+  int C, cg, SW;        // channels, 8-channel groups, strips per produced row
+  int pt, pl;           // gathered row / column of tap (0, 0) for produced pixel (0, 0) is (-pt, -pl)
+  int total;            // work items: N * PH * SW * cg (fwd, dgrad) | N * PH * SW (wgrad)
+  uint32_t g_bytes, p_bytes;
+  FastDiv fd_cg, fd_sw, fd_ph;
+};
+
+// produced[n, p, q, c] = sum_{r, s} gathered[n, p S - pt + r, q S - pl + s, c] * w[tap(r, s), c]
+// FLIP (the stride-1 dgrad): tap(r, s) = (2 - r, 2 - s).
+template <int S, bool FLIP>
+__global__ __launch_bounds__(THREADS) void k_fwd3(G3 g, const uint16_t* __restrict__ in, const float* __restrict__ w,
+                                                  uint16_t* __restrict__ out) {
+  constexpr int NC = (TW - 1) * S + 3;
+  const int i = (int)xcd_remap(blockIdx.x, gridDim.x) * THREADS + threadIdx.x;
+  if (i >= g.total) return;
+  const int t = fdiv(i, g.fd_cg), cgi = i - t * g.cg;
+  const int t2 = fdiv(t, g.fd_sw), strip = t - t2 * g.SW;
+  const int n = fdiv(t2, g.fd_ph), po = t2 - n * g.PH;
+  const int c0 = cgi * 8, q0 = strip * TW;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(in, g.g_bytes);
+  const int gw0 = q0 * S - g.pl;
+  float acc[TW][8];
+#pragma unroll
+  for (int j = 0; j < TW; ++j)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[j][c] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int gh = po * S - g.pt + r;
+    const bool rok = (unsigned)gh < (unsigned)g.GH;
+    const int rowbase = ((n * g.GH + gh) * g.GW) * g.C + c0;     // element index of pixel (gh, 0), channel c0
+    uint4 px[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int gw = gw0 + j;
+      const bool ok = rok && (unsigned)gw < (unsigned)g.GW;
+      px[j] = buf_load16(rs, ok ? (uint32_t)(rowbase + gw * g.C) * 2u : OOB);
+    }
+    float wv[3][8];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int tap = FLIP ? (2 - r) * 3 + (2 - s) : r * 3 + s;
+      const float* wp = w + tap * g.C + c0;
+      const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+      wv[s][0] = w0.x; wv[s][1] = w0.y; wv[s][2] = w0.z; wv[s][3] = w0.w;
+      wv[s][4] = w1.x; wv[s][5] = w1.y; wv[s][6] = w1.z; wv[s][7] = w1.w;
+    }
+    // pixel-major: a gathered pixel is unpacked once and feeds every (output j, tap s) with j S + s == k; for a fixed
+    // output the taps still arrive in the order s = 0, 1, 2 (k ascending), i.e. tap-major like the generic kernel
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      float xv[8];
+      unpack8(px[k], xv);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        if (k - s < 0 || (k - s) % S != 0 || (k - s) / S >= TW) continue;
+        const int j = (k - s) / S;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[j][c] = fmaf(xv[c], wv[s][c], acc[j][c]);
+      }
+    }
+  }
+  const int obase = ((n * g.PH + po) * g.PW) * g.C + c0;
+#pragma unroll
+  for (int j = 0; j < TW; ++j)
+    if (q0 + j < g.PW) *reinterpret_cast<uint4*>(out + obase + (q0 + j) * g.C) = pack8(acc[j]);
+}
+
+// Stride-2 dgrad: dx[n, h, w, c] = sum over the taps whose parity matches, dy[n, (h + pt - r) / 2, (w + pl - s) / 2, c] * w[r, s, c].
+// A strip of 4 dx pixels (w0 % 4 == 0) touches 3 dy columns; which (pixel, tap) pairs meet which column depends only
+// on the parity of pl (template), rows r = {0, 2} or {1} on the parity of h + pt.
+template <int PLODD>
+__global__ __launch_bounds__(THREADS) void k_dgrad3s2(G3 g, const uint16_t* __restrict__ dy, const float* __restrict__ w,
+                                                      uint16_t* __restrict__ dx) {
+  const int i = (int)xcd_remap(blockIdx.x, gridDim.x) * THREADS + threadIdx.x;
+  if (i >= g.total) return;
+  const int t = fdiv(i, g.fd_cg), cgi = i - t * g.cg;
+  const int t2 = fdiv(t, g.fd_sw), strip = t - t2 * g.SW;
+  const int n = fdiv(t2, g.fd_ph), h = t2 - n * g.PH;
+  const int c0 = cgi * 8, w0 = strip * TW;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(dy, g.g_bytes);
+  const int e0 = w0 + g.pl - 2 + PLODD;             // first even tw the strip can use (may be negative)
+  const int wo_b = e0 >> 1;                          // arithmetic shift: e0 is even
+  float acc[TW][8];
+#pragma unroll
+  for (int j = 0; j < TW; ++j)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[j][c] = 0.f;
+  const int par = (h + g.pt) & 1;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    if ((r & 1) != par) continue;                    // th = h + pt - r must be even
+    const int th = h + g.pt - r;
+    const int ho = th >> 1;
+    const bool rok = th >= 0 && ho < g.GH;
+    const int rowbase = ((n * g.GH + ho) * g.GW) * g.C + c0;
+    float gv[3][8];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int wo = wo_b + k;
+      const bool ok = rok && (unsigned)wo < (unsigned)g.GW;
+      unpack8(buf_load16(rs, ok ? (uint32_t)(rowbase + wo * g.C) * 2u : OOB), gv[k]);
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const float* wp = w + (r * 3 + s) * g.C + c0;
+      const float4 wa = *reinterpret_cast<const float4*>(wp), wb = *reinterpret_cast<const float4*>(wp + 4);
+      const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+      for (int j = 0; j < TW; ++j) {
+        if (((j - s - PLODD) & 1) != 0) continue;    // tw = w0 + j + pl - s must be even (compile-time)
+        const int k = (j - s + 2 - PLODD) / 2;       // dy column slot: 0..2
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[j][c] = fmaf(gv[k][c], wv[c], acc[j][c]);
+      }
+    }
+  }
+  const int obase = ((n * g.PH + h) * g.PW) * g.C + c0;
+#pragma unroll
+  for (int j = 0; j < TW; ++j)
+    if (w0 + j < g.PW) *reinterpret_cast<uint4*>(dx + obase + (w0 + j) * g.C) = pack8(acc[j]);
+}
+
+// Weight gradient, all nine taps at once: 72 fp32 accumulators per thread; x and dy are each read ONCE
+// (the generic kernel walks the data once per tap).  partial[part][tap][c], combined by k_wgrad_final2.
+struct WG3 { int tpr, rpb, parts, items_per_part; };
+template <int S>
+__global__ __launch_bounds__(THREADS, 2) void k_wgrad3(G3 g, WG3 G, const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                    float* __restrict__ partial) {
+  constexpr int NC = (TW - 1) * S + 3;
+  __shared__ float red[THREADS][9];
+  const int tx = threadIdx.x % G.tpr, ty = threadIdx.x / G.tpr;
+  const int cgi = blockIdx.y * G.tpr + tx;
+  const bool c_ok = cgi < g.cg;
+  const int c0 = cgi * 8;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, g.g_bytes), rd = make_rsrc(dy, g.p_bytes);
+  float acc[9][8];
+#pragma unroll
+  for (int tpi = 0; tpi < 9; ++tpi)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[tpi][c] = 0.f;
+  const int part = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = part * G.items_per_part;
+  int m1 = m0 + G.items_per_part;
+  if (m1 > g.total) m1 = g.total;
+  if (c_ok) {
+    for (int m = m0 + ty; m < m1; m += G.rpb) {
+      const int t2 = fdiv(m, g.fd_sw), strip = m - t2 * g.SW;
+      const int n = fdiv(t2, g.fd_ph), po = t2 - n * g.PH;
+      const int q0 = strip * TW;
+      float dv[TW][8];
+      const int dbase = ((n * g.PH + po) * g.PW) * g.C + c0;
+#pragma unroll
+      for (int j = 0; j < TW; ++j)
+        unpack8(buf_load16(rd, (q0 + j < g.PW) ? (uint32_t)(dbase + (q0 + j) * g.C) * 2u : OOB), dv[j]);
+      const int gw0 = q0 * S - g.pl;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int gh = po * S - g.pt + r;
+        const bool rok = (unsigned)gh < (unsigned)g.GH;
+        const int rowbase = ((n * g.GH + gh) * g.GW) * g.C + c0;
+        uint4 px[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          const int gw = gw0 + k;
+          const bool ok = rok && (unsigned)gw < (unsigned)g.GW;
+          px[k] = buf_load16(rx, ok ? (uint32_t)(rowbase + gw * g.C) * 2u : OOB);
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          float xv[8];
+          unpack8(px[k], xv);
+#pragma unroll
+          for (int s = 0; s < 3; ++s) {
+            if (k - s < 0 || (k - s) % S != 0 || (k - s) / S >= TW) continue;
+            const int j = (k - s) / S;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[r * 3 + s][c] = fmaf(xv[c], dv[j][c], acc[r * 3 + s][c]);
+          }
+        }
+      }
+    }
+  }
+  // combine the item-lanes of each channel group, 8 channels of all 9 taps at a time... one channel per round
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int tpi = 0; tpi < 9; ++tpi) red[threadIdx.x][tpi] = acc[tpi][c];
+    __syncthreads();
+    for (int st = G.rpb >> 1; st > 0; st >>= 1) {
+      if (ty < st) {
+#pragma unroll
+        for (int tpi = 0; tpi < 9; ++tpi) red[threadIdx.x][tpi] += red[threadIdx.x + st * G.tpr][tpi];
+      }
+      __syncthreads();
+    }
+    if (ty == 0 && c_ok) {
+#pragma unroll
+      for (int tpi = 0; tpi < 9; ++tpi) partial[((int64_t)part * 9 + tpi) * g.C + c0 + c] = red[threadIdx.x][tpi];
+    }
+  }
+}
+
+// dw[i] = sum over parts of partial[p][i], fixed order: 16 part-lanes per output (lane-strided, then lanes ascending), in double.
+__global__ __launch_bounds__(THREADS) void k_wgrad_final2(const float* __restrict__ partial, float* __restrict__ dw, int n_out,
+                                                          int parts) {
+  __shared__ double acc[16][17];
+  const int ol = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + ol;
+  double a = 0.0;
+  if (i < n_out)
+    for (int p = pl; p < parts; p += 16) a += (double)partial[(int64_t)p * n_out + i];
+  acc[pl][ol] = a;
+  __syncthreads();
+  if (pl == 0 && i < n_out) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += acc[k][ol];
+    dw[i] = (float)s;
+  }
+}
+
+static bool use3(const RiglConvDesc* d) {
+  static const bool on = [] { const char* e = getenv("RIGL_DW3"); return e ? atoi(e) != 0 : true; }();
+  if (!on || d->kh != 3 || d->kw != 3 || d->stride_h != d->stride_w || (d->stride_h != 1 && d->stride_h != 2)) return false;
+  const int64_t xb = (int64_t)d->n * d->h * d->w * d->cin * 2, yb = (int64_t)d->n * d->ho * d->wo * d->cin * 2;
+  const int64_t items = (int64_t)d->n * (d->h > d->ho ? d->h : d->ho) * (((d->w > d->wo ? d->w : d->wo) + TW - 1) / TW) * (d->cin / 8);
+  return xb < (int64_t(1) << 31) && yb < (int64_t(1) << 31) && items < (int64_t(1) << 31);
+}
+
+// gathered = [N][gh][gw][C], produced = [N][ph][pw][C]
+static G3 make_g3(const RiglConvDesc* d, int gh, int gw, int ph, int pw, int pt, int pl, bool with_cg) {
+  G3 g;
+  g.N = d->n; g.GH = gh; g.GW = gw; g.PH = ph; g.PW = pw; g.C = d->cin; g.cg = d->cin / 8;
+  g.SW = (pw + TW - 1) / TW;
+  g.pt = pt; g.pl = pl;
+  g.total = d->n * ph * g.SW * (with_cg ? g.cg : 1);
+  g.g_bytes = (uint32_t)((int64_t)d->n * gh * gw * d->cin * 2);
+  g.p_bytes = (uint32_t)((int64_t)d->n * ph * pw * d->cin * 2);
+  g.fd_cg = make_fastdiv(g.cg); g.fd_sw = make_fastdiv(g.SW); g.fd_ph = make_fastdiv(ph);
+  return g;
+}
+
+static WG3 make_wg3(const G3& g) {
+  static const int max_parts = [] { const char* e = getenv("RIGL_DW_PARTS"); return e ? atoi(e) : 512; }();
+  WG3 G;
+  int tpr = 1;
+  while (tpr < g.cg && tpr < THREADS) tpr <<= 1;
+  G.tpr = tpr; G.rpb = THREADS / tpr;
+  int64_t parts = ((int64_t)g.total + (int64_t)G.rpb * 4 - 1) / ((int64_t)G.rpb * 4);     // >= 4 strips per item-lane
+  const int64_t cap_bytes = (int64_t(8) << 20) / ((int64_t)9 * g.C * 4);                   // <= 8 MB of partial sums
+  if (parts > cap_bytes) parts = cap_bytes;
+  if (parts > max_parts) parts = max_parts;
+  if (parts < 1) parts = 1;
+  int64_t ipp = ((int64_t)g.total + parts - 1) / parts;
+  ipp = (ipp + G.rpb - 1) / G.rpb * G.rpb;
+  G.items_per_part = (int)ipp;
+  G.parts = (int)(((int64_t)g.total + ipp - 1) / ipp);
+  return G;
+}
+
 static unsigned stream_grid(int64_t total) {
   int64_t b = (total + THREADS * 2 - 1) / (THREADS * 2);
   if (b > 8192) b = 8192;
@@ -206,6 +515,10 @@ extern "C" {
 
 size_t rigl_depthwise_conv2d_workspace_bytes(const RiglConvDesc* d) {
   if (!d || d->cin % 8) return 0;
+  if (rigl::kdw::use3(d)) {
+    const rigl::kdw::G3 g3 = rigl::kdw::make_g3(d, d->h, d->w, d->ho, d->wo, d->pad_top, d->pad_left, false);
+    return rigl::align_up((size_t)rigl::kdw::make_wg3(g3).parts * 9 * d->cin * 4, 256);
+  }
   rigl::kdw::WGeom g = rigl::kdw::make_wgeom(d);
   return rigl::align_up((size_t)g.parts * d->kh * d->kw * d->cin * 4, 256);
 }
@@ -217,6 +530,14 @@ int rigl_depthwise_conv2d_fwd(const RiglConvDesc* d, const rigl_bf16* x, const f
   if (rc) return rc;
   if (!x || !w || !y) return fail(RIGL_EINVAL, "rigl_depthwise_conv2d_fwd: NULL tensor");
   ProfScope prof(PROF_DEPTHWISE, as_stream(stream));
+  if (kdw::use3(d)) {
+    const kdw::G3 g = kdw::make_g3(d, d->h, d->w, d->ho, d->wo, d->pad_top, d->pad_left, true);
+    const dim3 grid((unsigned)((g.total + kdw::THREADS - 1) / kdw::THREADS));
+    if (d->stride_h == 1) hipLaunchKernelGGL((kdw::k_fwd3<1, false>), grid, dim3(kdw::THREADS), 0, as_stream(stream), g, x, w, y);
+    else hipLaunchKernelGGL((kdw::k_fwd3<2, false>), grid, dim3(kdw::THREADS), 0, as_stream(stream), g, x, w, y);
+    RIGL_CHECK_LAUNCH("rigl_depthwise_conv2d_fwd");
+    return RIGL_OK;
+  }
   hipLaunchKernelGGL(kdw::k_fwd, dim3(kdw::stream_grid((int64_t)d->n * d->ho * d->wo * d->cin / 8)), dim3(kdw::THREADS), 0,
                      as_stream(stream), *d, x, w, y);
   RIGL_CHECK_LAUNCH("rigl_depthwise_conv2d_fwd");
@@ -230,6 +551,20 @@ int rigl_depthwise_conv2d_dgrad(const RiglConvDesc* d, const rigl_bf16* dy, cons
   if (rc) return rc;
   if (!dy || !w || !dx) return fail(RIGL_EINVAL, "rigl_depthwise_conv2d_dgrad: NULL tensor");
   ProfScope prof(PROF_DEPTHWISE, as_stream(stream));
+  if (kdw::use3(d)) {
+    if (d->stride_h == 1) {       // a correlation with the flipped filter: the forward body, gathering dy
+      const kdw::G3 g = kdw::make_g3(d, d->ho, d->wo, d->h, d->w, 2 - d->pad_top, 2 - d->pad_left, true);
+      const dim3 grid((unsigned)((g.total + kdw::THREADS - 1) / kdw::THREADS));
+      hipLaunchKernelGGL((kdw::k_fwd3<1, true>), grid, dim3(kdw::THREADS), 0, as_stream(stream), g, dy, w, dx);
+    } else {
+      const kdw::G3 g = kdw::make_g3(d, d->ho, d->wo, d->h, d->w, d->pad_top, d->pad_left, true);
+      const dim3 grid((unsigned)((g.total + kdw::THREADS - 1) / kdw::THREADS));
+      if (d->pad_left & 1) hipLaunchKernelGGL(kdw::k_dgrad3s2<1>, grid, dim3(kdw::THREADS), 0, as_stream(stream), g, dy, w, dx);
+      else hipLaunchKernelGGL(kdw::k_dgrad3s2<0>, grid, dim3(kdw::THREADS), 0, as_stream(stream), g, dy, w, dx);
+    }
+    RIGL_CHECK_LAUNCH("rigl_depthwise_conv2d_dgrad");
+    return RIGL_OK;
+  }
   hipLaunchKernelGGL(kdw::k_dgrad, dim3(kdw::stream_grid((int64_t)d->n * d->h * d->w * d->cin / 8)), dim3(kdw::THREADS), 0,
                      as_stream(stream), *d, dy, w, dx);
   RIGL_CHECK_LAUNCH("rigl_depthwise_conv2d_dgrad");
@@ -244,10 +579,21 @@ int rigl_depthwise_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const
   if (!x || !dy || !dw) return fail(RIGL_EINVAL, "rigl_depthwise_conv2d_wgrad: NULL tensor");
   const size_t need = rigl_depthwise_conv2d_workspace_bytes(d);
   if (!workspace || workspace_bytes < need) return fail(RIGL_EWORKSPACE, "rigl_depthwise_conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
-  kdw::WGeom g = kdw::make_wgeom(d);
   hipStream_t st = as_stream(stream);
   ProfScope prof(PROF_DEPTHWISE, st);
   float* partial = static_cast<float*>(workspace);
+  if (kdw::use3(d)) {
+    const kdw::G3 g3 = kdw::make_g3(d, d->h, d->w, d->ho, d->wo, d->pad_top, d->pad_left, false);
+    const kdw::WG3 wg = kdw::make_wg3(g3);
+    const dim3 grid3((unsigned)wg.parts, (unsigned)((g3.cg + wg.tpr - 1) / wg.tpr));
+    if (d->stride_h == 1) hipLaunchKernelGGL(kdw::k_wgrad3<1>, grid3, dim3(kdw::THREADS), 0, st, g3, wg, x, dy, partial);
+    else hipLaunchKernelGGL(kdw::k_wgrad3<2>, grid3, dim3(kdw::THREADS), 0, st, g3, wg, x, dy, partial);
+    const int n_out3 = 9 * d->cin;
+    hipLaunchKernelGGL(kdw::k_wgrad_final2, dim3((unsigned)((n_out3 + 15) / 16)), dim3(kdw::THREADS), 0, st, partial, dw, n_out3, wg.parts);
+    RIGL_CHECK_LAUNCH("rigl_depthwise_conv2d_wgrad");
+    return RIGL_OK;
+  }
+  kdw::WGeom g = kdw::make_wgeom(d);
   dim3 grid((unsigned)g.parts, (unsigned)((g.cg + g.tpr - 1) / g.tpr));
   hipLaunchKernelGGL(kdw::k_wgrad_partial, grid, dim3(kdw::THREADS), 0, st, *d, g, x, dy, partial);
   const int n_out = d->kh * d->kw * d->cin;

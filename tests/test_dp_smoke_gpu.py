@@ -51,7 +51,30 @@ def test_bench_contract_single_gpu():
     assert k in r, k
   assert r['bound'] == 'mfma' and r['peak'] == 2500.0 and r['unit'] == 'TFLOP/s'
   assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0.0 < r['frac'] < r['layerwise_bound']['mfma_only_ms'] / r['layerwise_bound']['ms_per_step']
+  # the second timed step of every run is a mask update: K2 is inside the window and on the line (missing #2)
+  assert d['config']['mask_updates_in_timed_region'] == 1
+  k2 = r['hbm_kernels']['prune_regrow']
+  assert k2['updates_timed'] == 1 and k2['ms_per_update'] > 0 and k2['masked_weights'] == 25502912
+  assert r['hbm_kernels']['masked_sgd_momentum']['ms_per_step'] > 0
+  assert abs(r['algorithmic_gflop_per_image'] - 24.299077632) < 1e-6      # host-side MAC counter == the analytic figure
   c = d['cpu_baseline']
-  for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+  for k in ('value', 'unit', 'cores', 'kind', 'sample', 'host_cores'):
     assert k in c, k
-  assert c['kind'] == 'port' and c['value'] > 0 and c['cores'] >= 1
+  assert c['kind'] == 'port' and c['value'] > 0 and 1 <= c['cores'] <= c['host_cores']
+  assert c['batch'] == 32 and c['timed_steps'] >= 1 and c['s_per_mask_update'] > 0   # SURVEY 8(d) protocol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workload,extra', [('mobilenet_v1', 'depthwise_conv'), ('resnet50_erk99', None), ('wrn22', None)])
+def test_bench_other_workloads(workload, extra):
+  """BASELINE configs 2, 4, 5 through the same bench line (small batch: this checks the plumbing, not the numbers)."""
+  cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', workload, '--steps', '3', '--warmup', '1',
+         '--batch', '16', '--prof-every', '1', '--no-cpu-baseline']
+  out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stderr[-2000:]
+  d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+  assert d['value'] > 0 and d['config']['mask_updates_in_timed_region'] == 1
+  r = d['roofline']
+  assert r['frac'] > 0 and r['hbm_kernels']['prune_regrow']['ms_per_update'] > 0
+  if extra:
+    assert r['hbm_kernels'][extra]['achieved'] > 0 and r['hbm_kernels'][extra]['launches_per_step'] > 0
