@@ -117,6 +117,10 @@ def main():
   ap.add_argument('--sparsity', type=float, default=None, help="override the workload's sparsity")
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-prof', action='store_true')
+  ap.add_argument('--graph', action='store_true',
+                  help='replay ordinary steps from a captured HIP graph (rigl_amd.train.GraphedStep; N = 1 only): for '
+                       'launch-bound models such as wrn22.  The K1 timings of `roofline` then come from a few eager '
+                       'steps run AFTER the timed region')
   ap.add_argument('--no-sync', action='store_true',
                   help='N > 1 only: run the step WITHOUT the gradient exchange (replicas diverge; gives the compute-only step '
                        'time that comm_exposed_ms is measured against -- never a headline number)')
@@ -170,6 +174,8 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
+  graphed = train.GraphedStep(loss_fn, opt, gs) if (args.graph and world == 1) else None
+  run_step = graphed if graphed is not None else step
   for i in range(args.warmup):
     if i == args.warmup - 1:
       ops.work_count(True)                  # dense-equivalent MACs / depthwise bytes of one fwd + bwd
@@ -184,7 +190,16 @@ def main():
   # period - 1 the first timed step is an ordinary one and the second is the next mask update.
   if int(gs.value) < UPDATE_PERIOD - 1:
     gs.value = UPDATE_PERIOD - 1
+  if graphed is not None:                   # capture now (its own warm-up + capture step), then re-position the schedule
+    for _ in range(6):
+      graphed()
+      if graphed.replays:
+        break
+    fence()
+    gs.value = UPDATE_PERIOD - 1
+    opt._last_update_step = 0               # pylint: disable=protected-access
   prof_every = max(int(args.prof_every), 1)
+  in_loop_prof = not args.no_prof and graphed is None
   if not args.no_prof:
     ops.prof_collect()
   if sync is not None:
@@ -194,20 +209,31 @@ def main():
   n_profiled = 0
   n_profiled_updates = 0
   for i in range(args.steps):
-    if not args.no_prof:
+    if in_loop_prof:
       upd = opt.is_mask_update_iter(int(gs.value), opt._last_update_step)   # (pure host arithmetic; the step recomputes it)
       on = i % prof_every == 0 or upd       # ... and every mask-update step (K2)
       ops.prof_enable(on)                  # a flag flip; the events are read after the timed region
       n_profiled += int(on)
     before = gs.value
-    step()
+    run_step()
     is_upd = int(gs.value == before)
     n_updates += is_upd
-    if not args.no_prof and on:
+    if in_loop_prof and on:
       n_profiled_updates += is_upd
   fence()
   dt = time.perf_counter() - t0
   prof = None
+  if not args.no_prof and graphed is not None:
+    # graph replays carry no per-kernel events: time the kernels on a few EAGER steps after the timed region
+    gs.value = UPDATE_PERIOD - 1
+    opt._last_update_step = 0               # pylint: disable=protected-access
+    ops.prof_enable(True)
+    for _ in range(4):
+      before = gs.value
+      step()
+      n_profiled += 1
+      n_profiled_updates += int(gs.value == before)
+    fence()
   if not args.no_prof:
     ops.prof_enable(False)
     prof = ops.prof_collect()
@@ -274,6 +300,8 @@ def main():
                    'parallelism': 'dp%d' % world, 'mask_updates_in_timed_region': n_updates,
                    'masks_identical_across_ranks': masks_same,
                    'gradient_exchange': (None if world == 1 else ('off (--no-sync)' if args.no_sync else 'on')),
+                   'execution': ('HIP graph replay of ordinary steps (%d replays, %d eager steps incl. mask updates)'
+                                 % (graphed.replays, graphed.eager_steps)) if graphed is not None else 'eager',
                    'lib_sha16': lib_sha16()},
     }
     if ar is not None:

@@ -193,3 +193,79 @@ class MomentumOptimizer(GradientDescentOptimizer):
     self.graph.finalize()
     self._ensure_slots()
     return self._slot[var.offset:var.offset + var.numel].view(var.shape)
+
+
+class GraphedStep:
+  """One training step replayed from a captured HIP graph (torch.cuda.CUDAGraph over the kernels the
+  C ABI enqueues on the current stream) -- for launch-bound models, where the ~250 launches of a step cost
+  more on the host than on the device (CIFAR WRN-22 at batch 128: 2.4 ms eager, the device work is a
+  fraction of that).  ResNet-50 at batch 128 is device-bound and gains < 1 % (tools/graph_probe.py), so the
+  headline benchmark stays eager.
+
+  Only ORDINARY iterations are replayed: the schedule (``is_mask_update_iter``) is host arithmetic on the
+  global step, so it is evaluated before every call and mask-update iterations (one in ``frequency``) run
+  eagerly -- they change the masks the captured kernels read through the same buffers, which is fine: the
+  graph holds pointers, not values.  Scalars that are kernel ARGUMENTS are frozen at capture: the learning
+  rate (a new graph is captured whenever ``lr(global_step)`` changes: piecewise-constant schedules recapture
+  a handful of times) and the gradient scale.  The loss tensor returned is the captured step's output buffer.
+
+  ``loss_fn`` must read its inputs from fixed device buffers (copy each new batch into them).  Data-parallel
+  steps (a GradSync with world > 1) are not captured -- the collectives stay eager -- and run as usual.
+  """
+
+  def __init__(self, loss_fn, optimizer, global_step, warmup=3):
+    self._loss_fn = loss_fn
+    self._opt = optimizer
+    self._gs = global_step
+    self._warmup = warmup
+    self._graphs = {}          # lr value -> (CUDAGraph, loss tensor)
+    inner = getattr(optimizer, '_optimizer', optimizer)
+    self._inner = inner
+    sync = getattr(inner, '_grad_sync', None)
+    self._eager_only = (sync is not None and getattr(sync, 'enabled', False)) or not torch.cuda.is_available()
+    self.replays = 0
+    self.eager_steps = 0
+
+  def _is_update(self):
+    o = self._opt
+    if not hasattr(o, 'is_mask_update_iter'):
+      return False
+    return bool(o.is_mask_update_iter(int(self._gs.value), o._last_update_step))   # pylint: disable=protected-access
+
+  def _eager(self):
+    loss = self._loss_fn()
+    self._opt.minimize(loss, self._gs)
+    self.eager_steps += 1
+    return loss
+
+  def __call__(self):
+    if self._eager_only or self._is_update():
+      return self._eager()
+    key = _lr_value(self._inner._lr, self._gs)                   # pylint: disable=protected-access
+    ent = self._graphs.get(key)
+    if ent is None:
+      if self._warmup > 0:                                         # allocator / workspace caches / descriptors settle first
+        self._warmup -= 1
+        return self._eager()
+      step0 = self._gs.value
+      side = torch.cuda.Stream()
+      side.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(side):
+        self._eager()                                              # one more on the capture stream's allocator pool
+      torch.cuda.current_stream().wait_stream(side)
+      torch.cuda.synchronize()
+      if self._is_update():
+        return self._eager()
+      graph = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(graph):
+        loss = self._loss_fn()
+        self._opt.minimize(loss, self._gs)                         # (capture enqueues nothing; the host side effect:)
+      self._gs.value = step0 + 1                                   # ... exactly one step was taken by the warm-up call
+      ent = self._graphs[key] = (graph, loss)
+      return self()                                                # now replay this iteration
+    graph, loss = ent
+    graph.replay()
+    self._gs.value += 1
+    self._inner.graph.shadows_dirty = True                         # the replayed update rewrote the weights
+    self.replays += 1
+    return loss
