@@ -191,8 +191,14 @@ class SparseSETOptimizerBase(train.Optimizer):
       if init is None:
         raise ValueError('Grow-Init: initial_dist needs weights.initial_value')
       divisor = extract_number(method)
-      perm = torch.randperm(init.numel(), device=init.device,
-                            generator=self._generator(weights, 'grow_init_i'))
+      # The reference shuffles with tf.random_shuffle (:372-380), a STATEFUL op whose stream hangs off the graph
+      # seed and the op's position in the graph -- there is no stream to be bit-compatible with, only the
+      # distribution: a uniform random permutation of the initial values.  Here the permutation is the stable
+      # argsort of this layer's stateless uniform stream (seed = hash(name + 'grow_init_i'), global_step), i.e.
+      # the same counter-based generator as every other random tensor of the update: identical on every replica
+      # by construction and reproducible from (seed offset, step) alone.  Parity: distribution only.
+      keys = self._random_uniform(tuple([init.numel()]), seed=self._seed(weights, 'grow_init_i'))
+      perm = torch.argsort(keys.reshape(-1), stable=True)
       return init.reshape(-1)[perm].reshape(init.shape) / divisor
     if method.startswith('random_normal'):
       divisor = extract_number(method)

@@ -247,22 +247,22 @@ class GraphedStep:
       if self._warmup > 0:                                         # allocator / workspace caches / descriptors settle first
         self._warmup -= 1
         return self._eager()
-      step0 = self._gs.value
       side = torch.cuda.Stream()
       side.wait_stream(torch.cuda.current_stream())
       with torch.cuda.stream(side):
-        self._eager()                                              # one more on the capture stream's allocator pool
+        out = self._eager()                                        # THIS call's step, on a side stream as torch's capture recipe asks
       torch.cuda.current_stream().wait_stream(side)
       torch.cuda.synchronize()
-      if self._is_update():
-        return self._eager()
+      if self._is_update() or _lr_value(self._inner._lr, self._gs) != key:   # pylint: disable=protected-access
+        return out                                                 # the next iteration is not an ordinary one at this lr: capture later
+      step1 = self._gs.value
       graph = torch.cuda.CUDAGraph()
       with torch.cuda.graph(graph):
         loss = self._loss_fn()
-        self._opt.minimize(loss, self._gs)                         # (capture enqueues nothing; the host side effect:)
-      self._gs.value = step0 + 1                                   # ... exactly one step was taken by the warm-up call
-      ent = self._graphs[key] = (graph, loss)
-      return self()                                                # now replay this iteration
+        self._opt.minimize(loss, self._gs)                         # capture enqueues nothing; undo its host side effect:
+      self._gs.value = step1
+      self._graphs[key] = (graph, loss)
+      return out
     graph, loss = ent
     graph.replay()
     self._gs.value += 1

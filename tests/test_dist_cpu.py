@@ -22,7 +22,7 @@ def _free_port():
   return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, bucket_bytes=4 * 4000):
   sys.path.insert(0, ROOT)
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)
@@ -39,7 +39,7 @@ def _worker(rank, world, port, q):
     bn = g.add_variable('bn/gamma', (64,), V.KIND_OTHER)
     g.finalize()
     # tiny buckets so that several are launched mid-"backward"
-    sync = GradSync(g, bucket_bytes=4 * 4000)
+    sync = GradSync(g, bucket_bytes=bucket_bytes)
     assert sync.world == world and sync.grad_scale == 1.0 / world
     ordered = sorted(vs, key=lambda v: v.offset)
     for trial, order in enumerate([list(reversed(ordered)),                       # normal backward order
@@ -83,6 +83,56 @@ def test_grad_sync_world2_gloo():
   for p in procs:
     p.join(timeout=60)
   assert all(r[1] == 'ok' for r in res), res
+
+
+def test_grad_sync_world4_gloo_uneven_bucket_tails():
+  """Four ranks, a bucket size that divides neither the arena nor any tensor (1777 elements): the tail buckets are
+  ragged and the last launch carries the head of the kernel segment plus the BN / bias segment."""
+  world = 4
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_worker, args=(r, world, port, q, 4 * 1777)) for r in range(world)]
+  for p in procs:
+    p.start()
+  res = [q.get(timeout=180) for _ in range(world)]
+  for p in procs:
+    p.join(timeout=60)
+  assert all(r[1] == 'ok' for r in res), res
+
+
+def test_grad_sync_timeline_records_every_bucket():
+  """The per-bucket record bench.py prints: one row per launch, offsets descending (backward order), bytes adding up
+  to the whole arena."""
+  sys.path.insert(0, ROOT)
+  import torch.distributed as dist
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(_free_port())
+  dist.init_process_group('gloo', rank=0, world_size=1)
+  try:
+    from rigl_amd import variables as V
+    from rigl_amd.dist import GradSync
+    g = V.Graph('cpu')
+    vs = [g.add_variable('l%d/weights' % i, (3, 3, 16, 16), V.KIND_MASKED) for i in range(6)]
+    bn = g.add_variable('bn/gamma', (64,), V.KIND_OTHER)
+    g.finalize()
+    s = GradSync(g, bucket_bytes=4 * 3000, enabled=True)      # world 1, exchange forced on: exercises every code path
+    s.reset_timeline(device_events=False)
+    for v in sorted(vs, key=lambda v: -v.offset):
+      v.grad.fill_(1.0)
+      s.notify_layer_grad_ready(v)
+    bn.grad.fill_(2.0)
+    s.all_reduce(g)
+    tl = s.timeline_summary()
+    rows = tl['buckets']
+    assert len(rows) == s.n_buckets_last >= 3
+    offs = [r['arena_offset'] for r in rows[:-1]]              # the final row is the BN / bias segment (gloo: its own launch)
+    assert offs == sorted(offs, reverse=True) and offs[-1] == 0
+    assert rows[-1]['arena_offset'] == g.seg[V.KIND_DENSE][1]
+    assert sum(r['bytes'] for r in rows) == 4 * g.G.numel()     # every element exchanged exactly once
+    assert torch.all(vs[0].grad == 1.0) and torch.all(bn.grad == 2.0)
+  finally:
+    dist.destroy_process_group()
 
 
 def test_grad_sync_single_process_is_noop():

@@ -90,6 +90,33 @@ def test_set_new_connection_zero_init():
     assert np.all(w1[np.logical_and(m0 == 0, m1 == 1)] == 0)
 
 
+def test_grow_init_initial_dist_is_a_stateless_permutation():
+  """grow_init='initial_dist_<d>' (sparse_optimizers_base.py:372-380): new connections start from a random
+  permutation of the variable's initial values / d.  The reference's tf.random_shuffle is a stateful op, so the
+  pinned properties are: a permutation (same multiset), reproducible from (seed offset, global step) alone --
+  replicas agree with no traffic --, different at another step, and the grown weights of an update are drawn from it."""
+  opt, loss_fn, mask, weight, gs = _setup('rigl', 15, 25, 0.5, 0, 4, 1)
+  opt._grow_init = 'initial_dist_2'
+  init = torch.randn(15, 25, device=DEV)
+  weight.initial_value = init
+  gs.value = 3
+  opt._global_step = gs
+  t1 = opt.get_grow_tensor(weight, 'initial_dist_2')
+  t1b = opt.get_grow_tensor(weight, 'initial_dist_2')
+  assert torch.equal(t1, t1b)
+  assert torch.equal(torch.sort(t1.reshape(-1)).values, torch.sort((init / 2).reshape(-1)).values)
+  assert not torch.equal(t1, init / 2)
+  gs.value = 4
+  assert not torch.equal(opt.get_grow_tensor(weight, 'initial_dist_2'), t1)
+  gs.value = 0
+  m0 = mask.numpy()
+  opt.minimize(loss_fn()[0], gs)                 # step 0 is a mask update (begin_step = 0)
+  grown = np.logical_and(m0 == 0, mask.numpy() == 1)
+  assert grown.any()
+  expect = opt.get_grow_tensor(weight, 'initial_dist_2').cpu().numpy()   # same (seed, step) -> same tensor
+  np.testing.assert_array_equal(weight.numpy()[grown], expect[grown])
+
+
 @pytest.mark.parametrize('n_inp,n_out,drop_frac', [(15, 25, 0.5), (15, 25, 0.2), (3, 5, 0.2)])
 def test_static_mask_never_changes(n_inp, n_out, drop_frac):
   # :225-244
