@@ -375,6 +375,18 @@ int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x,
 int rigl_stateless_random(float* out, int64_t n, int32_t seed0, int32_t seed1,
                           int32_t dist, float scale, float shift,
                           rigl_stream_t stream);
+/* The same for many tensors in one launch -- every layer's drop noise of one
+ * mask update (the reference builds one stateless_random_normal op per layer,
+ * rigl/sparse_optimizers_base.py:526-534, :411-416). */
+typedef struct {
+  float* out;
+  int64_t n;
+  int32_t seed0, seed1;
+  int32_t dist;            /* 0 uniform [0,1), 1 standard normal */
+  float scale, shift;
+} RiglRandomItem;
+int rigl_stateless_random_batched(const RiglRandomItem* items, int32_t n_items,
+                                  rigl_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Glue: max pooling, NHWC bf16 (tf.layers.max_pooling2d(3, 2, 'SAME') after the

@@ -61,6 +61,12 @@ class ConvDesc(C.Structure):
               ('pad_top', C.c_int32), ('pad_left', C.c_int32)]
 
 
+class RandomItem(C.Structure):
+  """RiglRandomItem"""
+  _fields_ = [('out', C.c_void_p), ('n', C.c_int64), ('seed0', C.c_int32), ('seed1', C.c_int32),
+              ('dist', C.c_int32), ('scale', C.c_float), ('shift', C.c_float)]
+
+
 class PendingReduce(C.Structure):
   """RiglPendingReduce: a layer's split-K reduce handed to the next backward launch."""
   _fields_ = [('slabs', C.c_void_p), ('dw', C.c_void_p), ('n_out', C.c_int64),
@@ -114,6 +120,7 @@ SIGNATURES = {
     'rigl_bn_bwd': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _SZ, _P]),
     'rigl_crc32c': (C.c_uint32, [_P, _SZ, C.c_uint32]),
     'rigl_stateless_random': (C.c_int, [_P, _I64, _I32, _I32, _I32, _F, _F, _P]),
+    'rigl_stateless_random_batched': (C.c_int, [C.POINTER(RandomItem), _I32, _P]),
     'rigl_maxpool_fwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     'rigl_maxpool_bwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     'rigl_global_avgpool_fwd': (C.c_int, [_I32, _I32, _I32, _P, _P, _P]),

@@ -572,6 +572,35 @@ def stateless_random(n, seed0, seed1, dist, scale=1.0, shift=0.0, device=None,
   return out
 
 
+def stateless_random_batched(items, device):
+  """items: [(n, seed0, seed1, 'uniform'|'normal', scale, shift)] -> list of fp32 [n] tensors (views of one
+  allocation, each starting on a 256-byte boundary), filled by ONE launch (rigl_stateless_random_batched)."""
+  def i32(v):
+    v = int(v) & 0xFFFFFFFF
+    return v - (1 << 32) if v >= 1 << 31 else v
+  if not items:
+    return []
+  offs, total = [], 0
+  for it in items:
+    offs.append(total)
+    total += (int(it[0]) + 63) // 64 * 64
+  buf = torch.empty(max(total, 1), dtype=torch.float32, device=device)
+  arr = (_lib.RandomItem * len(items))()
+  outs = []
+  for i, (n, s0, s1, dist, scale, shift) in enumerate(items):
+    if dist not in ('uniform', 'normal'):
+      raise ValueError('dist must be "uniform" or "normal"')
+    t = buf[offs[i]:offs[i] + int(n)]
+    outs.append(t)
+    arr[i].out = t.data_ptr() if int(n) else None
+    arr[i].n = int(n)
+    arr[i].seed0, arr[i].seed1 = i32(s0), i32(s1)
+    arr[i].dist = 1 if dist == 'normal' else 0
+    arr[i].scale, arr[i].shift = float(scale), float(shift)
+  check(_lib.load().rigl_stateless_random_batched(arr, len(items), _stream()))
+  return outs
+
+
 # ----------------------------------------------------------------------------
 # max pooling (glue)
 # ----------------------------------------------------------------------------

@@ -120,7 +120,12 @@ class SparseSETOptimizerBase(train.Optimizer):
     """All layers in ONE batched K2 call (the reference loops layers,
     :173-176)."""
     del gs
-    layers = [self._layer_request(l) for l in self.graph.masked_layers()]
+    mls = self.graph.masked_layers()
+    self._prefetch_drop_noise(mls)          # every layer's noise tensor in one launch
+    try:
+      layers = [self._layer_request(l) for l in mls]
+    finally:
+      self._noise_cache = {}
     self._run_update(layers)
 
   # ---- schedule (scalar host logic) ------------------------------------------
@@ -265,9 +270,26 @@ class SparseSETOptimizerBase(train.Optimizer):
       return None
     return self._optimizer.get_slot(lv.weights, names[0]).view(-1)
 
+  def _prefetch_drop_noise(self, layers):
+    """stateless_random_normal(shape, stddev, seed=[offset + hash(name + 'drop'), global_step]) of every layer
+    (:526-534) through rigl_stateless_random_batched: the same streams as the per-layer call, one launch."""
+    self._noise_cache = {}
+    std = self._noise_std
+    if not std or not layers:
+      return
+    items = []
+    for lv in layers:
+      s0, s1 = self._tf_seed(self._seed(lv.weights, 'drop'))
+      items.append((lv.weights.numel, s0, s1, 'normal', float(std), 0.0))
+    outs = ops.stateless_random_batched(items, self.graph.device)
+    self._noise_cache = {lv.weights.name: (float(std), t) for lv, t in zip(layers, outs)}
+
   def _drop_noise(self, lv, noise_std):
     if not noise_std:
       return None
+    hit = getattr(self, '_noise_cache', {}).get(lv.weights.name)
+    if hit is not None and hit[0] == float(noise_std):
+      return hit[1]
     return self._random_normal(lv.weights.shape, noise_std, torch.float32,
                                self._seed(lv.weights, 'drop')).view(-1)
 

@@ -111,3 +111,46 @@ def test_rigl_update_draws_the_reference_noise():
   s0, s1 = T.tf_seed_pair(17, pyhash.name_hash(lv.weights.name + 'drop'), 40)
   np.testing.assert_allclose(noise, T.stateless_random_normal(64 * 32, s0, s1, 0.0, 1e-5), rtol=0, atol=2e-11)
   assert lv.weights.name.endswith(':0')
+
+
+@pytest.mark.gpu
+def test_batched_fill_equals_the_single_calls():
+  """rigl_stateless_random_batched: every tensor of a mask update in one launch, bit for bit the per-tensor streams
+  (more items than one launch's table holds, empty and ragged sizes, both distributions)."""
+  import torch
+  from rigl_amd import ops
+  dev = 'cuda:0'
+  rs = np.random.RandomState(5)
+  items = []
+  for i in range(70):
+    n = int(rs.choice([0, 1, 3, 4, 5, 63, 64, 65, 1000, 4099, 36864, 2359296 if i == 7 else 147]))
+    items.append((n, int(rs.randint(-2**31, 2**31)), int(rs.randint(-2**31, 2**31)), 'normal' if i % 3 else 'uniform',
+                  float(rs.choice([1.0, 1e-5, 0.5])), float(rs.choice([0.0, -0.25]))))
+  outs = ops.stateless_random_batched(items, dev)
+  assert len(outs) == len(items)
+  for it, o in zip(items, outs):
+    assert o.numel() == it[0]
+    ref = ops.stateless_random(it[0], it[1], it[2], it[3], scale=it[4], shift=it[5], device=dev)
+    assert torch.equal(o, ref), it
+
+
+@pytest.mark.gpu
+def test_whole_model_update_uses_the_batched_noise():
+  """mask_update_op prefetches every layer's drop noise in one launch; the tensors are the per-layer streams."""
+  import torch
+  from rigl_amd import sparse_optimizers as SO, train, variables as V, pruning_layers as PL
+  g = V.reset_default_graph('cuda:0')
+  for i, (a, b) in enumerate([(64, 32), (32, 48), (48, 8)]):
+    PL.MaskedDense(g, 'fc%d' % i, a, b, use_bias=False, sparsity_technique='threshold')
+  g.finalize()
+  inner = train.GradientDescentOptimizer(0.1, graph=g)
+  opt = SO.SparseRigLOptimizer(inner, 0, 100, 10, drop_fraction=0.3, stateless_seed_offset=3, noise_std=1e-5)
+  gs = g.get_or_create_global_step()
+  gs.value = 20
+  opt._global_step = gs
+  single = [opt._drop_noise(lv, 1e-5).clone() for lv in g.masked_layers()]
+  opt._prefetch_drop_noise(g.masked_layers())
+  assert len(opt._noise_cache) == 3
+  for lv, s in zip(g.masked_layers(), single):
+    assert torch.equal(opt._drop_noise(lv, 1e-5), s)
+  opt._noise_cache = {}
