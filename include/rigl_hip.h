@@ -285,6 +285,38 @@ int rigl_masked_conv2d_bwd_deferred(const RiglConvDesc* d, const rigl_bf16* x,
                                     RiglPendingReduce* defer, rigl_stream_t stream);
 int rigl_wgrad_reduce_pending(const RiglPendingReduce* pending, rigl_stream_t stream);
 
+/* rigl_masked_conv2d_bwd_deferred with the BATCH-NORM BACKWARD REDUCTIONS of the
+ * tensor dX is the gradient of riding in the dgrad epilogue.  In the reference every
+ * conv input is y = relu?(batch_norm(x_bn) [+ shortcut]) (resnet_model.py:41-82,
+ * 456-501), and autodiff's batch-norm gradient starts with two per-channel sums
+ * over the whole tensor, sum(dz) and sum(dz * xhat), dz = relu-masked dL/dy -- a
+ * pass that re-reads dL/dy and x_bn.  The dgrad tile being stored IS dL/dy (after
+ * the fused `addend`), so the epilogue reads the matching x_bn tile and leaves
+ *   partial[p][0][c] = sum dz,  partial[p][1][c] = sum dz * (x_bn - mean) * invstd
+ * per row tile p < rigl_conv2d_dgrad_stats_parts(d) (fixed order, no atomics);
+ * rigl_bn_bwd_stats consumes them instead of running its reduction pass.
+ * x_bn / relu_bits have dX's shape [N,H,W,Cin]; params = the forward's saved
+ * [4][Cin] (mean, invstd, scale, shift); relu_bits (1 bit per element, from
+ * rigl_bn_fwd_stats) or NULL = the ReLU mask is recomputed from x_bn.
+ * rigl_conv2d_dgrad_stats_parts returns 0 for layers whose dgrad kernel has no
+ * such epilogue (cin or cout not a multiple of 8).                            */
+typedef struct RiglBnReduceFuse {
+  const rigl_bf16* x;
+  const uint8_t* relu_bits;   /* nullable */
+  const float* params;        /* [4][Cin] */
+  int32_t relu;
+  float* partial;             /* out: [parts][2][Cin] */
+  size_t partial_floats;
+} RiglBnReduceFuse;
+int32_t rigl_conv2d_dgrad_stats_parts(const RiglConvDesc* d);
+int rigl_masked_conv2d_bwd_bn(const RiglConvDesc* d, const rigl_bf16* x,
+                              const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                              const rigl_bf16* addend, float* dw, rigl_bf16* dx,
+                              void* workspace, size_t workspace_bytes,
+                              const RiglPendingReduce* flush, RiglPendingReduce* defer,
+                              const RiglBnReduceFuse* bn /* nullable */,
+                              rigl_stream_t stream);
+
 /* K1d: dense depthwise convolution (depth multiplier 1), NHWC bf16, fp32 HWIO
  * weights [kh][kw][c][1] read directly.  Replaces
  * contrib_layers.separable_conv2d(num_outputs=None)
@@ -360,6 +392,18 @@ int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x,
                 rigl_bf16* dresidual /* nullable */, float* dgamma,
                 float* dbeta, void* workspace, size_t workspace_bytes,
                 rigl_stream_t stream);
+/* rigl_bn_bwd whose reduction pass is replaced by the producer's partial sums:
+ * stats = [stats_parts][2][c] (sum dz, sum dz * xhat) from the dgrad epilogue
+ * that wrote dy (rigl_masked_conv2d_bwd_bn); stats == NULL: plain rigl_bn_bwd. */
+int rigl_bn_bwd_stats(int64_t m, int32_t c, const rigl_bf16* x,
+                      const rigl_bf16* y /* nullable */,
+                      const uint8_t* relu_bits /* nullable */, const rigl_bf16* dy,
+                      const float* gamma, const float* save_mean,
+                      const float* save_invstd, const float* save_scale,
+                      const float* save_shift, int32_t relu, rigl_bf16* dx,
+                      rigl_bf16* dresidual /* nullable */, float* dgamma,
+                      float* dbeta, const float* stats, int32_t stats_parts,
+                      void* workspace, size_t workspace_bytes, rigl_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Stateless random tensors with TensorFlow's bit layout:

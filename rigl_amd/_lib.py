@@ -61,6 +61,12 @@ class ConvDesc(C.Structure):
               ('pad_top', C.c_int32), ('pad_left', C.c_int32)]
 
 
+class BnReduceFuse(C.Structure):
+  """RiglBnReduceFuse: the batch norm whose backward reductions ride in a dgrad epilogue."""
+  _fields_ = [('x', C.c_void_p), ('relu_bits', C.c_void_p), ('params', C.c_void_p), ('relu', C.c_int32),
+              ('partial', C.c_void_p), ('partial_floats', C.c_size_t)]
+
+
 class RandomItem(C.Structure):
   """RiglRandomItem"""
   _fields_ = [('out', C.c_void_p), ('n', C.c_int64), ('seed0', C.c_int32), ('seed1', C.c_int32),
@@ -104,6 +110,9 @@ SIGNATURES = {
     'rigl_masked_conv2d_bwd_deferred': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ,
                                                   C.POINTER(PendingReduce), C.POINTER(PendingReduce), _P]),
     'rigl_wgrad_reduce_pending': (C.c_int, [C.POINTER(PendingReduce), _P]),
+    'rigl_conv2d_dgrad_stats_parts': (_I32, [C.POINTER(ConvDesc)]),
+    'rigl_masked_conv2d_bwd_bn': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ,
+                                            C.POINTER(PendingReduce), C.POINTER(PendingReduce), C.POINTER(BnReduceFuse), _P]),
     'rigl_masked_conv2d_bwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'rigl_masked_conv2d_wgrad': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P,
                                            _SZ, _P]),
@@ -118,6 +127,7 @@ SIGNATURES = {
     'rigl_bn_fwd': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'rigl_bn_fwd_stats': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _SZ, _P]),
     'rigl_bn_bwd': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _SZ, _P]),
+    'rigl_bn_bwd_stats': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _I32, _P, _SZ, _P]),
     'rigl_crc32c': (C.c_uint32, [_P, _SZ, C.c_uint32]),
     'rigl_stateless_random': (C.c_int, [_P, _I64, _I32, _I32, _I32, _F, _F, _P]),
     'rigl_stateless_random_batched': (C.c_int, [C.POINTER(RandomItem), _I32, _P]),

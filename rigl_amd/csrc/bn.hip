@@ -211,13 +211,15 @@ __global__ __launch_bounds__(THREADS) void k_fwd_apply(Geom G, const uint16_t* _
   }
 }
 
-// Backward finalize: dgamma, dbeta and the per-channel coefficients of dx.
+// Backward finalize: dgamma, dbeta and the per-channel coefficients of dx.  CL = 16 for the <= 512 partials of
+// k_reduce, 4 for the per-row-tile partials a dgrad epilogue leaves (rigl_masked_conv2d_bwd_bn: up to M / 128 of them).
+template <int CL>
 __global__ __launch_bounds__(THREADS) void k_bwd_finalize(Geom G, const float* __restrict__ partial,
                                                            const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            float* __restrict__ coef /*[3][C]: a, b, c*/) {
   double s0, s1; int c; bool leader;
-  sum_partials<16>(G, partial, s0, s1, c, leader);
+  sum_partials<CL>(G, partial, s0, s1, c, leader);
   if (!leader) return;
   dbeta[c] = (float)s0;
   dgamma[c] = (float)s1;
@@ -368,11 +370,12 @@ int rigl_bn_fwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* resid
                            save_invstd, save_scale, save_shift, nullptr, 0, nullptr, workspace, workspace_bytes, stream);
 }
 
-int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* y, const uint8_t* relu_bits,
-                const rigl_bf16* dy, const float* gamma,
-                const float* save_mean, const float* save_invstd, const float* save_scale, const float* save_shift,
-                int32_t relu, rigl_bf16* dx, rigl_bf16* dresidual, float* dgamma, float* dbeta, void* workspace,
-                size_t workspace_bytes, rigl_stream_t stream) {
+int rigl_bn_bwd_stats(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* y, const uint8_t* relu_bits,
+                      const rigl_bf16* dy, const float* gamma,
+                      const float* save_mean, const float* save_invstd, const float* save_scale, const float* save_shift,
+                      int32_t relu, rigl_bf16* dx, rigl_bf16* dresidual, float* dgamma, float* dbeta,
+                      const float* stats, int32_t stats_parts, void* workspace,
+                      size_t workspace_bytes, rigl_stream_t stream) {
   using namespace rigl;
   using namespace rigl::kbn;
   if (m <= 0 || c <= 0 || !x || !dy || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta)
@@ -381,6 +384,7 @@ int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* y, co
   if (relu && !y && !relu_bits && (!save_scale || !save_shift))
     return fail(RIGL_EINVAL, "rigl_bn_bwd: relu needs y, relu_bits or scale/shift");
   if (7 * (size_t)c * 4 > 65536) return fail(RIGL_EUNSUPPORTED, "rigl_bn_bwd: too many channels for the LDS parameter cache");
+  if (stats && stats_parts <= 0) return fail(RIGL_EINVAL, "rigl_bn_bwd_stats: stats_parts must be positive");
   const size_t need = rigl_bn_workspace_bytes(m, c);
   if (!workspace || workspace_bytes < need) return fail(RIGL_EWORKSPACE, "rigl_bn_bwd: workspace %zu < %zu", workspace_bytes, need);
   hipStream_t st = as_stream(stream);
@@ -389,14 +393,26 @@ int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* y, co
   float* coef = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)g.parts * 2 * c * 4, 256));
   dim3 rgrid((unsigned)g.parts, (unsigned)((g.cg + g.tpr - 1) / g.tpr));
   const int msk = relu_bits ? 2 : (y ? 1 : 0);
+  const float* red = partial;
+  if (stats) {
+    // the producer of dy (a dgrad epilogue, rigl_masked_conv2d_bwd_bn) left sum dz / sum dz * xhat per row tile:
+    // the reduction pass over dy and x is not run at all
+    red = stats;
+    g.parts = stats_parts;
+  } else {
 #define RIGL_BWD_REDUCE(R, K) hipLaunchKernelGGL((k_reduce<1, R, K>), rgrid, dim3(THREADS), 0, st, g, x, y, relu_bits, dy, save_mean, save_invstd, save_scale, save_shift, partial)
-  if (!relu) RIGL_BWD_REDUCE(false, 0);
-  else if (msk == 2) RIGL_BWD_REDUCE(true, 2);
-  else if (msk == 1) RIGL_BWD_REDUCE(true, 1);
-  else RIGL_BWD_REDUCE(true, 0);
+    if (!relu) RIGL_BWD_REDUCE(false, 0);
+    else if (msk == 2) RIGL_BWD_REDUCE(true, 2);
+    else if (msk == 1) RIGL_BWD_REDUCE(true, 1);
+    else RIGL_BWD_REDUCE(true, 0);
 #undef RIGL_BWD_REDUCE
-  hipLaunchKernelGGL(k_bwd_finalize, dim3((unsigned)((c + 15) / 16)), dim3(THREADS), 0, st, g, partial, gamma,
-                     save_invstd, dgamma, dbeta, coef);
+  }
+  if (g.parts > 256)
+    hipLaunchKernelGGL(k_bwd_finalize<4>, dim3((unsigned)((c + 3) / 4)), dim3(THREADS), 0, st, g, red, gamma,
+                       save_invstd, dgamma, dbeta, coef);
+  else
+    hipLaunchKernelGGL(k_bwd_finalize<16>, dim3((unsigned)((c + 15) / 16)), dim3(THREADS), 0, st, g, red, gamma,
+                       save_invstd, dgamma, dbeta, coef);
   const size_t lds = (size_t)7 * c * 4;
   dim3 agrid(apply_grid(g));
 #define RIGL_BWD_APPLY(R, K, D) hipLaunchKernelGGL((k_bwd_apply<R, K, D>), agrid, dim3(THREADS), lds, st, g, x, y, relu_bits, dy, save_mean, save_invstd, save_scale, save_shift, coef, dx, dresidual)
@@ -408,6 +424,15 @@ int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* y, co
 #undef RIGL_BWD_APPLY
   RIGL_CHECK_LAUNCH("rigl_bn_bwd");
   return RIGL_OK;
+}
+
+int rigl_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* y, const uint8_t* relu_bits,
+                const rigl_bf16* dy, const float* gamma,
+                const float* save_mean, const float* save_invstd, const float* save_scale, const float* save_shift,
+                int32_t relu, rigl_bf16* dx, rigl_bf16* dresidual, float* dgamma, float* dbeta, void* workspace,
+                size_t workspace_bytes, rigl_stream_t stream) {
+  return rigl_bn_bwd_stats(m, c, x, y, relu_bits, dy, gamma, save_mean, save_invstd, save_scale, save_shift, relu, dx,
+                           dresidual, dgamma, dbeta, nullptr, 0, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

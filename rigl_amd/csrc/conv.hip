@@ -124,7 +124,12 @@ struct IgemmArgs {
   const uint16_t* B;   // packed weights
   void* C;             // output rows
   const uint16_t* ADD; // optional bf16 tensor added to the bf16 output rows (same layout as C), or NULL
-  float* STATS;        // optional per-row-tile column statistics [tiles_m][2][N]: sum y, sum y^2 of the bf16 outputs
+  float* STATS;        // optional per-row-tile column statistics [tiles_m][2][N]: sum y, sum y^2 of the bf16 outputs (fwd);
+                       // with BNX (dgrad): sum dz, sum dz * xhat -- the batch-norm backward reductions of the produced tensor
+  const uint16_t* BNX; // dgrad only, optional: input x of the batch norm whose OUTPUT gradient this kernel produces ([M][N] like C)
+  const uint8_t* BNBITS;  // its 1-bit-per-element ReLU mask (relu(bn + residual)), or NULL: mask recomputed from BNX
+  const float* BNP;    // its saved statistics [4][N]: mean, invstd, scale, shift
+  int bn_relu;
   int M, N, Cred;      // GEMM rows, columns, reduction channels per tap
   int KH, KW;
   int RH, RW;          // spatial size of the row space (ho,wo | h,w)
@@ -159,7 +164,11 @@ constexpr int igemm_smem_bytes() {
   constexpr int EPI = OUT_F32 ? 0 : BM * (BN + 8) * 2;
   constexpr int EPI_TAB = EPI + (CLS ? BM * 4 : 0);
   constexpr int EPI_ALL = EPI_TAB + ((MODE == 0 && !OUT_F32) ? NT * 8 : 0);
-  return (NST * STAGE > EPI_ALL) ? NST * STAGE : EPI_ALL;
+  constexpr int BASE = (NST * STAGE > EPI_ALL) ? NST * STAGE : EPI_ALL;
+  // dgrad: + the batch-norm statistics of the tile's columns, outside the ring where the 64 KB of static LDS allow it
+  constexpr int EPI_PRM = EPI_TAB + 4 * BN * 4;
+  if (MODE == 1 && !OUT_F32) return (BASE + 4 * BN * 4 <= 65536 && WM == 2) ? BASE + 4 * BN * 4 : (BASE > EPI_PRM ? BASE : EPI_PRM);
+  return BASE;
 }
 
 template <int TM, int TN, int BK, int MODE /*0 fwd, 1 dgrad*/, bool OUT_F32, bool CLS, int STAGES, int WM = 2>
@@ -173,7 +182,12 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P, unsigned char* sm
   constexpr int EPI = OUT_F32 ? 0 : BM * CS_LD * 2;
   constexpr int EPI_TAB = EPI + (CLS ? BM * 4 : 0);       // + per-row output pixel table
   constexpr int EPI_ALL = EPI_TAB + ((MODE == 0 && !OUT_F32) ? THREADS * 8 : 0);   // + column-statistics scratch
-  constexpr int SMEM = (NST * STAGE > EPI_ALL) ? NST * STAGE : EPI_ALL;
+  constexpr int BASE = (NST * STAGE > EPI_ALL) ? NST * STAGE : EPI_ALL;
+  // dgrad: [4][BN] floats of batch-norm statistics -- behind ring and epilogue (filled at the top of the kernel) where
+  // the 64 KB static limit allows, else inside the epilogue area (filled in the epilogue)
+  constexpr bool PRM_OUT = MODE == 1 && !OUT_F32 && WM == 2 && BASE + 4 * BN * 4 <= 65536;
+  constexpr int PRM_OFF = PRM_OUT ? BASE : EPI_TAB;
+  constexpr int SMEM = (MODE == 1 && !OUT_F32) ? (PRM_OUT ? BASE + 4 * BN * 4 : (BASE > EPI_TAB + 4 * BN * 4 ? BASE : EPI_TAB + 4 * BN * 4)) : BASE;
   static_assert(SMEM <= 65536 || WM == 4, "static LDS limit (the 512-thread variant uses dynamic LDS)");
   static_assert(STAGES == 2 || (BM % RPP == 0 && BN % RPP == 0), "LDS-DMA needs whole 1-KB wave rows");
   static_assert(SMEM == igemm_smem_bytes<TM, TN, BK, MODE, OUT_F32, CLS, STAGES, WM>(), "LDS size formula out of sync");
@@ -257,6 +271,31 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P, unsigned char* sm
 #endif
   uint4 ra[APASS], rb[BPASS];
   __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.A, P.a_bytes), rsrcB = make_rsrc(P.B, P.b_bytes);
+  // dgrad with batch-norm reductions in the epilogue: request the x tile (and its ReLU bits) NOW -- nothing depends on
+  // it until the tile is stored, so it travels under the whole K loop instead of stalling the epilogue.  (Class-major
+  // rows only know their pixels in the epilogue; those few strided layers load there.)
+  constexpr int E_CH = BN / 8, E_ITERS = OUT_F32 ? 1 : BM * E_CH / THREADS;
+  uint4 bnx[E_ITERS];
+  uint32_t bnb[E_ITERS];
+  const bool bnst = MODE == 1 && !OUT_F32 && P.BNX != nullptr;
+  if (PRM_OUT && bnst) {
+    // ... and the per-channel statistics of the tile's columns, into LDS of their own (not part of the ring)
+    float* bprm_w = reinterpret_cast<float*>(smem + PRM_OFF);
+    for (int i = tid; i < 4 * BN; i += THREADS) {
+      const int k = i / BN, c = i % BN;
+      bprm_w[i] = (n0 + c < P.N) ? P.BNP[k * P.N + n0 + c] : 0.f;
+    }
+  }
+  if (MODE == 1 && !OUT_F32 && !CLS && bnst) {
+#pragma unroll
+    for (int it = 0; it < E_ITERS; ++it) {
+      const int idx = it * THREADS + tid, row = idx / E_CH, ch = idx % E_CH;
+      const int m = m0 + row, n = n0 + ch * 8;
+      const bool ok = m < P.M && n < P.N;
+      bnx[it] = ok ? *reinterpret_cast<const uint4*>(P.BNX + (int64_t)m * P.ldc + n) : make_uint4(0u, 0u, 0u, 0u);
+      bnb[it] = (ok && P.BNBITS) ? (uint32_t)P.BNBITS[((int64_t)m * P.ldc + n) >> 3] : 0u;
+    }
+  }
 
   // (macros, not lambdas: by-reference lambda captures of the staging arrays
   //  kept them in scratch memory instead of registers)
@@ -546,29 +585,120 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P, unsigned char* sm
     uint16_t* C = static_cast<uint16_t*>(P.C);
     constexpr int CH = BN / 8, ITERS = BM * CH / THREADS;
     static_assert(BM * CH % THREADS == 0, "whole output chunks per thread");
-    // fully unrolled, addend loads first: all of a thread's chunks are in flight together
-    // instead of one load -> add -> store round trip per chunk
-    uint4 addv[ITERS];
-    if (P.ADD) {
+    static_assert(THREADS % CH == 0, "a thread keeps its column chunk over all of its rows");
+    static_assert(CH == E_CH && ITERS == E_ITERS, "prefetch geometry == epilogue geometry");
+    float q0[8], q1[8];
+    if (!bnst) {
+      // fully unrolled, addend loads first: all of a thread's chunks are in flight together
+      // instead of one load -> add -> store round trip per chunk
+      uint4 addv[ITERS];
+      if (P.ADD) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          const int idx = it * THREADS + tid, row = idx / CH, ch = idx % CH;
+          const int m = CLS ? rowpix[row] : m0 + row, n = n0 + ch * 8;
+          addv[it] = (m >= 0 && m < P.M && n < P.N) ? *reinterpret_cast<const uint4*>(P.ADD + (int64_t)m * P.ldc + n)
+                                                    : make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
         const int idx = it * THREADS + tid, row = idx / CH, ch = idx % CH;
         const int m = CLS ? rowpix[row] : m0 + row, n = n0 + ch * 8;
-        addv[it] = (m >= 0 && m < P.M && n < P.N) ? *reinterpret_cast<const uint4*>(P.ADD + (int64_t)m * P.ldc + n)
-                                                  : make_uint4(0u, 0u, 0u, 0u);
+        if (m >= 0 && m < P.M && n < P.N) {
+          uint4 v = *reinterpret_cast<const uint4*>(Cs + row * CS_LD + ch * 8);
+          if (P.ADD) {   // fused gradient accumulation: out = bf16(bf16(acc) + addend), as the separate add would give
+            const uint4 q = addv[it];
+            v.x = add_bf16x2(v.x, q.x); v.y = add_bf16x2(v.y, q.y); v.z = add_bf16x2(v.z, q.z); v.w = add_bf16x2(v.w, q.w);
+          }
+          *reinterpret_cast<uint4*>(C + (int64_t)m * P.ldc + n) = v;
+        }
+      }
+    } else {
+      // Batch-norm backward reductions fused into the dgrad epilogue (rigl_masked_conv2d_bwd_bn): the tile being stored
+      // IS the gradient w.r.t. y = relu?(bn(x) [+ residual]); sum dz and sum dz * xhat (dz = relu-masked gradient) per
+      // column are exactly what the batch norm's own reduction pass would read this tensor and x again for
+      // (bn.hip k_reduce<1>: resnet_model.py:41-82 through autodiff).  A thread owns one 8-column chunk for all its
+      // rows; the per-channel statistics sit in LDS behind the staging tile; the matching x tile was requested at the
+      // top of the kernel (stride-1 layers) and has long arrived.
+      const int chf = tid % CH;
+      const float* bprm = reinterpret_cast<const float*>(smem + PRM_OFF);   // [4][BN]: mean, invstd, scale, shift (filled at the top)
+      if (!PRM_OUT) {
+        float* bw = reinterpret_cast<float*>(smem + PRM_OFF);
+        for (int i = tid; i < 4 * BN; i += THREADS) {
+          const int k = i / BN, c = i % BN;
+          bw[i] = (n0 + c < P.N) ? P.BNP[k * P.N + n0 + c] : 0.f;
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q0[j] = q1[j] = 0.f;
+      constexpr int BATCH = ITERS < 4 ? ITERS : 4;
+      static_assert(ITERS % BATCH == 0, "whole batches");
+#pragma unroll
+      for (int b0 = 0; b0 < ITERS; b0 += BATCH) {
+        uint4 addv[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+          const int idx = (b0 + u) * THREADS + tid, row = idx / CH, ch = idx % CH;
+          const int m = CLS ? rowpix[row] : m0 + row, n = n0 + ch * 8;
+          const bool ok = m >= 0 && m < P.M && n < P.N;
+          addv[u] = (P.ADD && ok) ? *reinterpret_cast<const uint4*>(P.ADD + (int64_t)m * P.ldc + n) : make_uint4(0u, 0u, 0u, 0u);
+          if constexpr (CLS) {      // class-major rows: the pixel table exists only now (batch by batch: register budget)
+            bnx[b0 + u] = ok ? *reinterpret_cast<const uint4*>(P.BNX + (int64_t)m * P.ldc + n) : make_uint4(0u, 0u, 0u, 0u);
+            bnb[b0 + u] = (ok && P.BNBITS) ? (uint32_t)P.BNBITS[((int64_t)m * P.ldc + n) >> 3] : 0u;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+          const int it = b0 + u;
+          const int idx = it * THREADS + tid, row = idx / CH, ch = idx % CH;
+          const int m = CLS ? rowpix[row] : m0 + row, n = n0 + ch * 8;
+          if (m >= 0 && m < P.M && n < P.N) {
+            uint4 v = *reinterpret_cast<const uint4*>(Cs + row * CS_LD + ch * 8);
+            if (P.ADD) {
+              const uint4 q = addv[u];
+              v.x = add_bf16x2(v.x, q.x); v.y = add_bf16x2(v.y, q.y); v.z = add_bf16x2(v.z, q.z); v.w = add_bf16x2(v.w, q.w);
+            }
+            *reinterpret_cast<uint4*>(C + (int64_t)m * P.ldc + n) = v;
+            const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, xw[4] = {bnx[it].x, bnx[it].y, bnx[it].z, bnx[it].w};
+            const float* pc = bprm + chf * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float dv = __uint_as_float((j & 1) ? (vw[j >> 1] & 0xFFFF0000u) : (vw[j >> 1] << 16));
+              const float xv = __uint_as_float((j & 1) ? (xw[j >> 1] & 0xFFFF0000u) : (xw[j >> 1] << 16));
+              bool on = true;
+              if (P.bn_relu) on = P.BNBITS ? ((bnb[it] >> j) & 1u) != 0u : (fmaf(xv, pc[2 * BN + j], pc[3 * BN + j]) > 0.f);
+              const float dz = on ? dv : 0.f;
+              q0[j] += dz;
+              q1[j] = fmaf(dz, (xv - pc[j]) * pc[BN + j], q1[j]);
+            }
+          }
+        }
       }
     }
+    if (bnst) {
+      // Combine the row groups of every column chunk in a fixed order (deterministic): the lanes of a wave that share a
+      // chunk are CH apart (xor-shuffle tree), the four waves meet in the staging area every thread has finished reading.
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      const int idx = it * THREADS + tid, row = idx / CH, ch = idx % CH;
-      const int m = CLS ? rowpix[row] : m0 + row, n = n0 + ch * 8;
-      if (m >= 0 && m < P.M && n < P.N) {
-        uint4 v = *reinterpret_cast<const uint4*>(Cs + row * CS_LD + ch * 8);
-        if (P.ADD) {   // fused gradient accumulation: out = bf16(bf16(acc) + addend), as the separate add would give
-          const uint4 q = addv[it];
-          v.x = add_bf16x2(v.x, q.x); v.y = add_bf16x2(v.y, q.y); v.z = add_bf16x2(v.z, q.z); v.w = add_bf16x2(v.w, q.w);
-        }
-        *reinterpret_cast<uint4*>(C + (int64_t)m * P.ldc + n) = v;
+      for (int off = CH; off < 64; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { q0[j] += __shfl_xor(q0[j], off); q1[j] += __shfl_xor(q1[j], off); }
+      }
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);           // [waves][CH][16]
+      if (lane < CH) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[(wave * CH + lane) * 16 + j] = q0[j]; red[(wave * CH + lane) * 16 + 8 + j] = q1[j]; }
+      }
+      __syncthreads();
+      if (tid < CH * 16) {
+        const int c = tid >> 4, v = tid & 15;
+        float sum = red[c * 16 + v];
+#pragma unroll
+        for (int wv = 1; wv < THREADS / 64; ++wv) sum += red[(wv * CH + c) * 16 + v];
+        const int n = n0 + c * 8 + (v & 7);
+        if (n < P.N) P.STATS[(int64_t)tile_m * 2 * P.N + (int64_t)(v >> 3) * P.N + n] = sum;
       }
     }
   }
@@ -1566,12 +1696,48 @@ static rigl::k1::IgemmArgs dgrad_args(const RiglConvDesc* d, const rigl_bf16* dy
   return a;
 }
 
+// Which dgrad kernel a layer gets decides whether its epilogue can carry the batch-norm backward reductions: only
+// the igemm body does (the default for every cin % 8 == cout % 8 == 0 layer); returns its number of row tiles, else 0.
+int32_t rigl_conv2d_dgrad_stats_parts(const RiglConvDesc* d) {
+  using namespace rigl;
+  using namespace rigl::k1;
+  if (!d || check_desc(d, "rigl_conv2d_dgrad_stats_parts")) return 0;
+  if ((d->cin % 8) || (d->cout % 8)) return 0;
+  if (plan_c3(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo, d->n, d->cin, d->cout, true).use ||
+      plan_t196(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo,
+                (int64_t)d->n * d->h * d->w, d->cin, d->cout, true).use)
+    return 0;
+  IgemmArgs a = dgrad_args(d, nullptr, nullptr, nullptr, nullptr);
+  const IgemmPlan pl = plan_igemm<1>(a);
+  return (int32_t)(pl.grid / (unsigned)a.tiles_n);
+}
+
+static int attach_bn(rigl::k1::IgemmArgs& a, const RiglConvDesc* d, const RiglBnReduceFuse* bn) {
+  using namespace rigl;
+  if (!bn) return RIGL_OK;
+  if (!bn->x || !bn->params || !bn->partial) return fail(RIGL_EINVAL, "rigl_masked_conv2d_bwd_bn: NULL pointer in the batch-norm block");
+  const int32_t parts = rigl_conv2d_dgrad_stats_parts(d);
+  if (parts <= 0) return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_bwd_bn: this layer's dgrad kernel has no reduction epilogue");
+  if (bn->partial_floats < (size_t)parts * 2 * d->cin)
+    return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd_bn: partial buffer %zu floats < %zu", bn->partial_floats, (size_t)parts * 2 * d->cin);
+  a.BNX = bn->x; a.BNBITS = bn->relu_bits; a.BNP = bn->params; a.bn_relu = bn->relu; a.STATS = bn->partial;
+  return RIGL_OK;
+}
+
+static int dgrad_impl(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf16* w_hwio, const rigl_bf16* addend,
+                      rigl_bf16* dx, const RiglBnReduceFuse* bn, rigl_stream_t stream);
+
 int rigl_masked_conv2d_dgrad_acc(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf16* w_hwio,
                                  const rigl_bf16* addend, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
                                  rigl_stream_t stream) {
+  (void)workspace; (void)workspace_bytes;
+  return dgrad_impl(d, dy, w_hwio, addend, dx, nullptr, stream);
+}
+
+static int dgrad_impl(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf16* w_hwio, const rigl_bf16* addend,
+                      rigl_bf16* dx, const RiglBnReduceFuse* bn, rigl_stream_t stream) {
   using namespace rigl;
   using namespace rigl::k1;
-  (void)workspace; (void)workspace_bytes;
   int rc = check_desc(d, "rigl_masked_conv2d_dgrad");
   if (rc) return rc;
   if (!dy || !w_hwio || !dx) return fail(RIGL_EINVAL, "rigl_masked_conv2d_dgrad: NULL tensor");
@@ -1601,6 +1767,8 @@ int rigl_masked_conv2d_dgrad_acc(const RiglConvDesc* d, const rigl_bf16* dy, con
     return RIGL_OK;
   }
   IgemmArgs a = dgrad_args(d, dy, w_hwio, addend, dx);
+  rc = attach_bn(a, d, bn);
+  if (rc) return rc;
   launch_igemm<1, false>(a, st);
   RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
   return RIGL_OK;
@@ -1731,10 +1899,29 @@ int rigl_wgrad_reduce_pending(const RiglPendingReduce* pending, rigl_stream_t st
   return RIGL_OK;
 }
 
+static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                    const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
+                    const RiglPendingReduce* flush, RiglPendingReduce* defer, const RiglBnReduceFuse* bn, rigl_stream_t stream);
+
 int rigl_masked_conv2d_bwd_deferred(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy,
                                     const rigl_bf16* w_hwio, const rigl_bf16* addend, float* dw, rigl_bf16* dx,
                                     void* workspace, size_t workspace_bytes, const RiglPendingReduce* flush,
                                     RiglPendingReduce* defer, rigl_stream_t stream) {
+  return bwd_impl(d, x, dy, w_hwio, addend, dw, dx, workspace, workspace_bytes, flush, defer, nullptr, stream);
+}
+
+// The same launch with the batch-norm backward reductions of the tensor dX is the gradient of riding in the dgrad epilogue.
+int rigl_masked_conv2d_bwd_bn(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                              const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
+                              const RiglPendingReduce* flush, RiglPendingReduce* defer, const RiglBnReduceFuse* bn,
+                              rigl_stream_t stream) {
+  if (bn && !dx) return rigl::fail(RIGL_EINVAL, "rigl_masked_conv2d_bwd_bn: the reductions ride on dX, which was not requested");
+  return bwd_impl(d, x, dy, w_hwio, addend, dw, dx, workspace, workspace_bytes, flush, defer, bn, stream);
+}
+
+static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                    const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
+                    const RiglPendingReduce* flush, RiglPendingReduce* defer, const RiglBnReduceFuse* bn, rigl_stream_t stream) {
   using namespace rigl;
   using namespace rigl::k1;
   static const bool fuse = [] { const char* e = getenv("RIGL_BWD_FUSED"); return e ? atoi(e) != 0 : true; }();
@@ -1756,6 +1943,8 @@ int rigl_masked_conv2d_bwd_deferred(const RiglConvDesc* d, const rigl_bf16* x, c
   if (fuse && !dgrad_196 && !wgrad_9 && dx && x && dy && w_hwio && dw && !tiny_cin(d) && !small_cin(d) && (d->cin % 8) == 0 && (d->cout % 8) == 0 &&
       wgrad_use_tr() && conv_dma_stages() == 3) {
     IgemmArgs ad = dgrad_args(d, dy, w_hwio, addend, dx);
+    rc = attach_bn(ad, d, bn);
+    if (rc) return rc;
     const IgemmPlan pd = plan_igemm<1>(ad);
     WgradArgs aw = {};
     aw.DY = dy; aw.M = d->n * d->ho * d->wo; aw.Cout = d->cout;
@@ -1821,7 +2010,7 @@ int rigl_masked_conv2d_bwd_deferred(const RiglConvDesc* d, const rigl_bf16* x, c
   }
   rc = rigl_masked_conv2d_wgrad(d, x, dy, dw, workspace, workspace_bytes, stream);
   if (rc || !dx) return rc;
-  return rigl_masked_conv2d_dgrad_acc(d, dy, w_hwio, addend, dx, workspace, workspace_bytes, stream);
+  return dgrad_impl(d, dy, w_hwio, addend, dx, bn, stream);
 }
 
 // Whole backward of one masked conv in one call: dW (dense) and, when dx is given, dX (+ addend).

@@ -393,14 +393,30 @@ def flush_pending_wgrad(device=None):
       done()
 
 
-def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None):
+def dgrad_stats_parts(d):
+  """Row tiles of this layer's dgrad kernel = rows of the batch-norm partials its epilogue can leave
+  (0: the layer's dgrad has no such epilogue)."""
+  v = getattr(d, '_dgrad_parts', None)
+  if v is None:
+    v = d._dgrad_parts = int(_lib.load().rigl_conv2d_dgrad_stats_parts(C.byref(d)))
+  return v
+
+
+def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None, bn_fuse=None):
   """dW (into ``dw``, dense fp32) and -- when ``need_dx`` -- dX (+ ``addend``) of
   one conv with a single host transition and, for ordinary layers, a single launch
   (rigl_masked_conv2d_bwd_deferred) followed by the split-K reduce that completes dW.
   With RIGL_WGRAD_DEFER=1 that reduce is handed to the NEXT conv_bwd call, which runs it
   as a third segment of its own launch; ``flush_pending_wgrad`` finishes the last one.
   ``on_dw_ready`` is called once dW's reduce has been enqueued (now, or when the next
-  call / the flush picks it up).  Returns dX or None."""
+  call / the flush picks it up).  Returns dX or None.
+  ``bn_fuse`` = dict(x=, saved=, relu=, relu_bits=) of the batch norm whose output this conv read: its backward
+  reductions are computed in the dgrad epilogue (rigl_masked_conv2d_bwd_bn) and returned as
+  ``bn_fuse['partials']`` (fp32 [parts, 2, Cin]) for bn_bwd; left unset where the layer's kernels cannot."""
+  if bn_fuse is not None:
+    bn_fuse.pop('partials', None)
+    if not (need_dx and not _SIDE_WGRAD and mfma_supported(d) and mfma_dgrad_supported(d) and dgrad_stats_parts(d) > 0):
+      bn_fuse = None
   if not (mfma_supported(d) and (not need_dx or mfma_dgrad_supported(d))):
     flush_pending_wgrad(x.device)
     conv_wgrad(d, x, dy, dw)
@@ -445,10 +461,23 @@ def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None):
     if addend is not None and addend.numel() != dx.numel():
       raise ValueError('addend must have the shape of dx')
   mine = _lib.PendingReduce() if _DEFER else None
-  check(lib.rigl_masked_conv2d_bwd_deferred(
+  bn = None
+  if bn_fuse is not None:
+    bx, saved = bn_fuse['x'], bn_fuse['saved']
+    _req(bx, torch.bfloat16, 'bn x')
+    _req(saved, torch.float32, 'bn saved')
+    bits = bn_fuse.get('relu_bits')
+    _req(bits, torch.uint8, 'bn relu_bits', allow_none=True)
+    if bx.numel() != dx.numel() or saved.numel() != 4 * d.cin:
+      raise ValueError('bn_fuse: x must have the shape of dx and saved must be [4, Cin]')
+    part = torch.empty((dgrad_stats_parts(d), 2, d.cin), dtype=torch.float32, device=dy.device)
+    bn = _lib.BnReduceFuse(bx.data_ptr(), bits.data_ptr() if bits is not None else None, saved.data_ptr(),
+                           int(bool(bn_fuse['relu'])), part.data_ptr(), part.numel())
+    bn_fuse['partials'] = part
+  check(lib.rigl_masked_conv2d_bwd_bn(
       C.byref(d), _ptr(x), _ptr(dy), _ptr(w_hwio), _ptr(addend), _ptr(dw), _ptr(dx), _ptr(ws),
       ws.numel() if ws is not None else 0, C.byref(prev[0]) if prev is not None else None,
-      C.byref(mine) if mine is not None else None, _stream()))
+      C.byref(mine) if mine is not None else None, C.byref(bn) if bn is not None else None, _stream()))
   if prev is not None and prev[2] is not None:
     prev[2]()                              # the previous layer's dW is now complete in stream order
   if mine is not None and mine.splits > 0:
@@ -529,10 +558,12 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu,
 
 
 def bn_bwd(x, y, dy, gamma, saved, relu, dgamma, dbeta, want_dres=False,
-           relu_bits=None):
+           relu_bits=None, partials=None):
   """Returns (dx, dres|None); dgamma / dbeta (fp32 [C]) are overwritten.  The
   ReLU mask comes from ``relu_bits`` (bn_fwd(want_relu_bits=True)), else ``y``,
-  else it is recomputed from x."""
+  else it is recomputed from x.  ``partials`` (fp32 [parts, 2, C]: sum dz, sum dz * xhat per row
+  tile, left by the dgrad epilogue that produced ``dy`` -- conv_bwd(bn_fuse=...)) replaces the
+  reduction pass over dy and x."""
   _req(relu_bits, torch.uint8, 'relu_bits', allow_none=True)
   _req(x, torch.bfloat16, 'x')
   _req(dy, torch.bfloat16, 'dy')
@@ -543,11 +574,15 @@ def bn_bwd(x, y, dy, gamma, saved, relu, dgamma, dbeta, want_dres=False,
   dx = torch.empty_like(x)
   dres = torch.empty_like(x) if want_dres else None
   ws = workspace(lib.rigl_bn_workspace_bytes(m, c), x.device)
-  check(lib.rigl_bn_bwd(m, c, _ptr(x), _ptr(y), _ptr(relu_bits), _ptr(dy), _ptr(gamma),
-                        _ptr(saved[0]), _ptr(saved[1]), _ptr(saved[2]),
-                        _ptr(saved[3]), int(bool(relu)), _ptr(dx), _ptr(dres),
-                        _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(),
-                        _stream()))
+  _req(partials, torch.float32, 'partials', allow_none=True)
+  if partials is not None and (partials.dim() != 3 or partials.shape[1] != 2 or partials.shape[2] != c):
+    raise ValueError('partials must be [parts, 2, %d]' % c)
+  check(lib.rigl_bn_bwd_stats(m, c, _ptr(x), _ptr(y), _ptr(relu_bits), _ptr(dy), _ptr(gamma),
+                              _ptr(saved[0]), _ptr(saved[1]), _ptr(saved[2]),
+                              _ptr(saved[3]), int(bool(relu)), _ptr(dx), _ptr(dres),
+                              _ptr(dgamma), _ptr(dbeta), _ptr(partials),
+                              partials.shape[0] if partials is not None else 0, _ptr(ws), ws.numel(),
+                              _stream()))
   return dx, dres
 
 

@@ -15,6 +15,7 @@ straight into the layer's slice of the gradient arena (RigL needs it dense,
 sparse_optimizers_base.py:478-485) -- there is no PyTorch fallback.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -35,12 +36,44 @@ def _valid_out(size, k, stride):
   return (size - k) // stride + 1
 
 
+# RIGL_BN_FUSE_BWD=1: a batch norm's backward reductions ride in the dgrad epilogue of its output's only consumer
+# (rigl_masked_conv2d_bwd_bn).  OFF by default: measured on ResNet-50 at batch 128 the reduction pass it removes costs
+# 10-17 us per layer and the epilogue work it adds 15-19 us (profiles/r2/README.md) -- 13.29 vs 13.30 ms per step
+# with K1's share of it up by 1 ms.
+_BN_FUSE_BWD = os.environ.get('RIGL_BN_FUSE_BWD', '0') == '1'
+# ... only for activations of at most this many MB (the large early tensors make the dgrad launch HBM-bound already)
+_BN_FUSE_MAX_BYTES = float(os.environ.get('RIGL_BN_FUSE_MAX_MB', '1e9')) * 1e6
+
+
+def _bn_source(x):
+  """The batch norm that produced ``x`` (workloads.nn.BatchNorm leaves a holder on its output): its backward
+  reductions can ride in this conv's dgrad epilogue.  Counted, because that is only right for the SOLE consumer."""
+  h = getattr(x, 'bn_ctx', None) if _BN_FUSE_BWD else None
+  if h is not None:
+    h.attached += 1
+  return h
+
+
+def _bn_fuse_request(holder, need_dx):
+  if holder is None or not need_dx or holder.attached != 1 or holder.x is None:
+    return None
+  if holder.x.numel() * 2 > _BN_FUSE_MAX_BYTES:
+    return None
+  return dict(x=holder.x, saved=holder.saved, relu=holder.relu, relu_bits=holder.bits)
+
+
+def _bn_fuse_publish(holder, req, dx):
+  if req is not None and req.get('partials') is not None and dx is not None:
+    holder.partials, holder.dx_ptr = req['partials'], dx.data_ptr()
+
+
 class _MaskedConvFn(torch.autograd.Function):
   """y = conv(x, mask*W) with dense dW written into lv.weights.grad."""
 
   @staticmethod
-  def forward(ctx, x, lv, desc, need_dx, want_stats=False):
+  def forward(ctx, x, lv, desc, need_dx, want_stats=False, bn_holder=None):
     ctx.lv, ctx.desc, ctx.need_dx = lv, desc, need_dx
+    ctx.bn_holder = bn_holder
     ctx.save_for_backward(x)
     if not want_stats:
       return ops.conv_fwd(desc, x, lv.ohwi)
@@ -61,8 +94,10 @@ class _MaskedConvFn(torch.autograd.Function):
     # dense dL/d(mask*W), fp32 HWIO, into this layer's slice of the G arena, and dX -- one call
     sync = getattr(lv.weights.graph, 'grad_sync', None)
     ready = (lambda: sync.notify_layer_grad_ready(lv.weights)) if sync is not None else None   # DP: overlap the all-reduce
-    dx = ops.conv_bwd(d, x, dy, lv.hwio, lv.weights.grad.view(-1), need_dx=ctx.need_dx, on_dw_ready=ready)
-    return dx, None, None, None, None
+    req = _bn_fuse_request(ctx.bn_holder, ctx.need_dx)
+    dx = ops.conv_bwd(d, x, dy, lv.hwio, lv.weights.grad.view(-1), need_dx=ctx.need_dx, on_dw_ready=ready, bn_fuse=req)
+    _bn_fuse_publish(ctx.bn_holder, req, dx)
+    return dx, None, None, None, None, None
 
 
 class _MaskedConvForkFn(torch.autograd.Function):
@@ -73,8 +108,9 @@ class _MaskedConvForkFn(torch.autograd.Function):
   separate AddN pass autodiff would emit (rigl_masked_conv2d_dgrad_acc)."""
 
   @staticmethod
-  def forward(ctx, x, lv, desc, want_stats=False):
+  def forward(ctx, x, lv, desc, want_stats=False, bn_holder=None):
     ctx.lv, ctx.desc = lv, desc
+    ctx.bn_holder = bn_holder
     ctx.save_for_backward(x)
     if not want_stats:
       return ops.conv_fwd(desc, x, lv.ohwi), x.view_as(x)
@@ -96,8 +132,12 @@ class _MaskedConvForkFn(torch.autograd.Function):
       dalias = dalias.contiguous()
     sync = getattr(lv.weights.graph, 'grad_sync', None)
     ready = (lambda: sync.notify_layer_grad_ready(lv.weights)) if sync is not None else None
-    dx = ops.conv_bwd(d, x, dy, lv.hwio, lv.weights.grad.view(-1), need_dx=True, addend=dalias, on_dw_ready=ready)
-    return dx, None, None, None
+    # dx = this conv's dgrad + the alias' gradient is the COMPLETE gradient of the forked tensor: the producing batch
+    # norm's reductions are taken on it
+    req = _bn_fuse_request(ctx.bn_holder, True)
+    dx = ops.conv_bwd(d, x, dy, lv.hwio, lv.weights.grad.view(-1), need_dx=True, addend=dalias, on_dw_ready=ready, bn_fuse=req)
+    _bn_fuse_publish(ctx.bn_holder, req, dx)
+    return dx, None, None, None, None
 
 
 class _Layer:
@@ -172,11 +212,12 @@ class MaskedConv2d(_Layer):
     n, h, w, _ = x.shape
     d = self.desc_for(n, h, w)
     need_dx = self.need_input_grad and x.requires_grad
+    holder = _bn_source(x) if need_dx else None
     if not x.requires_grad:
       x = x.detach().requires_grad_(True)  # keep the node so wgrad runs
     if not bn_stats:
-      return _MaskedConvFn.apply(x.contiguous(), self.vars, d, need_dx)
-    y, part = _MaskedConvFn.apply(x.contiguous(), self.vars, d, need_dx, True)
+      return _MaskedConvFn.apply(x.contiguous(), self.vars, d, need_dx, False, holder)
+    y, part = _MaskedConvFn.apply(x.contiguous(), self.vars, d, need_dx, True, holder)
     if part.numel():
       y.bn_partials = part
     return y
@@ -190,9 +231,10 @@ class MaskedConv2d(_Layer):
       return self(x, bn_stats), x
     self.graph.refresh_shadows()
     n, h, w, _ = x.shape
+    holder = _bn_source(x)
     if not bn_stats:
-      return _MaskedConvForkFn.apply(x.contiguous(), self.vars, self.desc_for(n, h, w))
-    y, alias, part = _MaskedConvForkFn.apply(x.contiguous(), self.vars, self.desc_for(n, h, w), True)
+      return _MaskedConvForkFn.apply(x.contiguous(), self.vars, self.desc_for(n, h, w), False, holder)
+    y, alias, part = _MaskedConvForkFn.apply(x.contiguous(), self.vars, self.desc_for(n, h, w), True, holder)
     if part.numel():
       y.bn_partials = part
     return y, alias

@@ -28,17 +28,29 @@ def nhwc_view(x):
   return x.permute(0, 2, 3, 1)
 
 
+class _BnBwdHolder:
+  """What the consumer of a batch norm's output needs to take that batch norm's backward reductions in its own dgrad
+  epilogue (pruning_layers._bn_source), and where it leaves them for the batch norm's backward."""
+  __slots__ = ('x', 'saved', 'bits', 'relu', 'attached', 'partials', 'dx_ptr')
+
+  def __init__(self, relu):
+    self.x = self.saved = self.bits = self.partials = self.dx_ptr = None
+    self.relu = relu
+    self.attached = 0
+
+
 class _FusedBNFn(torch.autograd.Function):
   """y = relu?(bn(x) (+ residual)) through rigl_bn_fwd / rigl_bn_bwd.  The
   parameter gradients go straight into the gradient arena (overwrite), like
   the conv kernels' dW; autograd only routes dx (and the residual's grad)."""
 
   @staticmethod
-  def forward(ctx, x, residual, bn, relu, partials=None):
+  def forward(ctx, x, residual, bn, relu, partials=None, holder=None):
     from rigl_amd import ops  # pylint: disable=import-outside-toplevel
     x = x.contiguous()
     res = residual.contiguous() if residual is not None else None
     ctx.bn, ctx.relu, ctx.has_res = bn, relu, res is not None
+    ctx.holder = holder
     # the ReLU mask of relu(bn + residual) is kept as 1 bit per element (the backward would
     # otherwise re-read the whole output twice); without a residual it is recomputed from x
     if relu and res is not None:
@@ -47,10 +59,13 @@ class _FusedBNFn(torch.autograd.Function):
                                   partials=partials, want_relu_bits=True)
       ctx.save_for_backward(x, saved, bits)
     else:
+      bits = None
       y, saved = ops.bn_fwd(x, bn.gamma.data, bn.beta.data, bn.moving_mean,
                             bn.moving_variance, 1.0 - bn.decay, bn.eps, relu, res,
                             partials=partials)
       ctx.save_for_backward(x, saved)
+    if holder is not None:
+      holder.x, holder.saved, holder.bits = x, saved, bits
     return y
 
   @staticmethod
@@ -61,11 +76,18 @@ class _FusedBNFn(torch.autograd.Function):
       x, saved, bits = ctx.saved_tensors
     else:
       (x, saved), bits = ctx.saved_tensors, None
-    dx, dres = ops.bn_bwd(x, None, dy.contiguous(), bn.gamma.data, saved, ctx.relu,
+    dy = dy.contiguous()
+    # sum dz / sum dz * xhat already taken by the kernel that produced dy (the sole consumer's dgrad epilogue)?
+    h, part = ctx.holder, None
+    if h is not None:
+      if h.partials is not None and h.dx_ptr == dy.data_ptr():
+        part = h.partials
+      h.partials = h.x = h.saved = h.bits = None
+    dx, dres = ops.bn_bwd(x, None, dy, bn.gamma.data, saved, ctx.relu,
                           bn.gamma.grad, bn.beta.grad,
                           want_dres=ctx.has_res and ctx.needs_input_grad[1],
-                          relu_bits=bits)
-    return dx, dres, None, None, None
+                          relu_bits=bits, partials=part)
+    return dx, dres, None, None, None, None
 
 
 class BatchNorm:
@@ -97,7 +119,10 @@ class BatchNorm:
       partials = getattr(x, 'bn_partials', None)   # left by the producing conv's epilogue
       if not x.requires_grad:
         x = x.detach().requires_grad_(True)
-      return _FusedBNFn.apply(x, residual, self, relu, partials)
+      holder = _BnBwdHolder(relu)
+      y = _FusedBNFn.apply(x, residual, self, relu, partials, holder)
+      y.bn_ctx = holder                            # a masked conv that is this tensor's only consumer picks it up
+      return y
     y = F.batch_norm(nchw_view(x), self.moving_mean, self.moving_variance,
                      bias_tensor(self.gamma), bias_tensor(self.beta),
                      is_training, 1.0 - self.decay, self.eps)

@@ -127,3 +127,70 @@ def test_fused_bn_from_producer_partials(shape):
   # outputs differ at most by one bf16 rounding where the fp32 value sits on a tie
   assert ((y0.float() - y1.float()).abs() <= 2.0**-7 * y0.float().abs() + 1e-6).all()
   assert (y0 != y1).float().mean() < 1e-3
+
+
+# ---------------------------------------------------------------- backward reductions riding in the dgrad epilogue
+@pytest.mark.parametrize('case', [
+    # N, H, W, Cin, Cout, k, stride, relu, residual(-> 1-bit mask), addend
+    (4, 14, 14, 256, 256, 3, 1, True, False, False),      # bn1 -> 3x3 conv, mask recomputed from x
+    (4, 14, 14, 64, 256, 1, 1, True, False, False),       # narrow 128x64 tile
+    (3, 28, 28, 128, 128, 3, 2, True, False, False),      # strided 3x3: parity-class rows
+    (3, 28, 28, 256, 512, 1, 2, True, True, True),        # projection: 1x1 / 2 (three all-zero classes), bit mask, addend
+    (4, 14, 14, 1024, 256, 1, 1, True, True, True),       # block output feeding conv1 + shortcut: bit mask + addend
+    (2, 9, 13, 40, 72, 3, 1, False, False, False),        # ragged rows / columns, no ReLU
+    (5, 7, 7, 2048, 512, 1, 1, True, True, False),
+])
+def test_bn_bwd_reductions_in_the_dgrad_epilogue(case):
+  """rigl_masked_conv2d_bwd_bn + rigl_bn_bwd_stats against the unfused pair: the conv's dX and dW
+  keep their bits; the batch norm's dgamma / dbeta agree with an fp64 reduction to fp32-accumulation accuracy
+  (1e-5 x the sum of the absolute terms) for BOTH paths, and its dx to one bf16 ulp of the unfused result."""
+  from rigl_amd import ops
+  N, H, W, Cin, Cout, k, stride, relu, has_res, has_add = case
+  g = torch.Generator(device=DEV).manual_seed(sum(int(v) for v in case))
+  pad = (k - 1) // 2
+  Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+  d = ops.conv_desc(N, H, W, Cin, Cout, k, k, stride, pad, pad, Ho, Wo)
+  x_bn = (torch.randn(N, H, W, Cin, generator=g, device=DEV) * 1.5 + 0.3).to(torch.bfloat16)
+  gamma = 1.0 + 0.3 * torch.randn(Cin, generator=g, device=DEV)
+  beta = 0.2 * torch.randn(Cin, generator=g, device=DEV)
+  res = torch.randn(N, H, W, Cin, generator=g, device=DEV).to(torch.bfloat16) if has_res else None
+  rm, rv = torch.zeros(Cin, device=DEV), torch.ones(Cin, device=DEV)
+  if has_res:
+    y, saved, bits = ops.bn_fwd(x_bn, gamma, beta, rm, rv, 0.1, 1e-5, relu, res, want_relu_bits=True)
+  else:
+    (y, saved), bits = ops.bn_fwd(x_bn, gamma, beta, rm, rv, 0.1, 1e-5, relu, res), None
+  dy = torch.randn(N, Ho, Wo, Cout, generator=g, device=DEV).to(torch.bfloat16)
+  w = (torch.randn(k * k * Cin * Cout, generator=g, device=DEV) * (k * k * Cin) ** -0.5)
+  hwio = torch.empty_like(w, dtype=torch.bfloat16)
+  ohwi = torch.empty_like(hwio)
+  ops.pack_weights(w, None, k * k * Cin, Cout, hwio, ohwi)
+  addend = torch.randn(N, H, W, Cin, generator=g, device=DEV).to(torch.bfloat16) if has_add else None
+  assert ops.dgrad_stats_parts(d) > 0
+  dw0, dw1 = torch.empty_like(w), torch.empty_like(w)
+  dx0 = ops.conv_bwd(d, y, dy, hwio, dw0, need_dx=True, addend=addend)
+  ops.flush_pending_wgrad()
+  req = dict(x=x_bn, saved=saved, relu=relu, relu_bits=bits)
+  dx1 = ops.conv_bwd(d, y, dy, hwio, dw1, need_dx=True, addend=addend, bn_fuse=req)
+  ops.flush_pending_wgrad()
+  assert req.get('partials') is not None and req['partials'].shape == (ops.dgrad_stats_parts(d), 2, Cin)
+  assert torch.equal(dx0, dx1) and torch.equal(dw0, dw1)
+  dg0, db0, dg1, db1 = [torch.empty(Cin, device=DEV) for _ in range(4)]
+  bx0, br0 = ops.bn_bwd(x_bn, None, dx0, gamma, saved, relu, dg0, db0, want_dres=has_res, relu_bits=bits)
+  bx1, br1 = ops.bn_bwd(x_bn, None, dx1, gamma, saved, relu, dg1, db1, want_dres=has_res, relu_bits=bits,
+                        partials=req['partials'])
+  # fp64 reference of the two reductions
+  xf, dz = x_bn.double().reshape(-1, Cin), dx0.double().reshape(-1, Cin)
+  if relu:
+    on = (y.reshape(-1, Cin) > 0)
+    dz = torch.where(on, dz, torch.zeros_like(dz))
+  xhat = (xf - saved[0].double()) * saved[1].double()
+  r0, r1 = dz.sum(0), (dz * xhat).sum(0)
+  t0, t1 = dz.abs().sum(0), (dz * xhat).abs().sum(0)
+  for db, dg in ((db0, dg0), (db1, dg1)):
+    assert ((db.double() - r0).abs() <= 1e-5 * t0 + 1e-6).all()
+    assert ((dg.double() - r1).abs() <= 1e-5 * t1 + 1e-6).all()
+  a, b = bx1.float(), bx0.float()
+  assert ((a - b).abs() <= 2.0**-7 * b.abs() + 1e-6 * b.abs().max()).all()
+  assert (bx1 != bx0).float().mean() < 0.02          # and almost every element keeps its bits
+  if has_res:
+    assert torch.equal(br0, br1)                     # dres = dz does not depend on the reductions

@@ -270,8 +270,8 @@ def test_resnet50_every_conv_in_situ_and_loss_vs_cpu_oracle(rn50):
   rec = []
   fwd0, bwd0 = PL._MaskedConvFn.forward, PL._MaskedConvFn.backward
 
-  def fwd(ctx, x, lv, desc, need_dx, want_stats=False):
-    out = fwd0(ctx, x, lv, desc, need_dx, want_stats)
+  def fwd(ctx, x, lv, desc, need_dx, want_stats=False, bn_holder=None):
+    out = fwd0(ctx, x, lv, desc, need_dx, want_stats, bn_holder)
     y = out[0] if want_stats else out
     rec.append(dict(lv=lv, d=desc, x=x.detach().clone(), y=y.detach().clone()))
     ctx.rec = rec[-1]
@@ -288,8 +288,8 @@ def test_resnet50_every_conv_in_situ_and_loss_vs_cpu_oracle(rn50):
   # the convs that share their input with a shortcut (fused gradient accumulation)
   ffwd0, fbwd0 = PL._MaskedConvForkFn.forward, PL._MaskedConvForkFn.backward
 
-  def ffwd(ctx, x, lv, desc, want_stats=False):
-    out = ffwd0(ctx, x, lv, desc, want_stats)
+  def ffwd(ctx, x, lv, desc, want_stats=False, bn_holder=None):
+    out = ffwd0(ctx, x, lv, desc, want_stats, bn_holder)
     rec.append(dict(lv=lv, d=desc, x=x.detach().clone(), y=out[0].detach().clone()))
     ctx.rec = rec[-1]
     return out
