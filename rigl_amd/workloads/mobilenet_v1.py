@@ -46,13 +46,13 @@ class MobileNetV1:
     key = (n, h, w)
     if key not in c._descs:
       c._descs[key] = ops.conv_desc(n, h, w, 3, 32, 3, 3, 2, 1, 1, (h - 1) // 2 + 1, (w - 1) // 2 + 1)
-    return c(images)
+    return c(images, bn_stats=True)           # the conv epilogue leaves the batch-norm statistics of its output
 
   def __call__(self, images, is_training=True):
     x = self.stem_bn(self._stem(images), is_training, relu=True)
     for dw, bn_a, pw, bn_b in self.blocks:
       x = bn_a(dw(x), is_training, relu=True)
-      x = bn_b(pw(x), is_training, relu=True)
+      x = bn_b(pw(x, bn_stats=True), is_training, relu=True)
     return self.fc(gnn.global_avg_pool(x))
 
   def loss(self, images, labels, label_smoothing=0.1, is_training=True):

@@ -60,7 +60,7 @@ class WideResNet:
       net = b['bn_a'](net, is_training, relu=True)
       if 'skip' in b:
         skip = b['skip'](net)
-      net = b['conv1'](net)
+      net = b['conv1'](net, bn_stats=True)          # its output goes straight into bn_b: statistics from the conv epilogue
       net = b['bn_b'](net, is_training, relu=True)
       net = b['conv2'](net)
       net = net + skip
