@@ -16,9 +16,21 @@ on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) streaming reads
 """
 import collections
 import csv
+import hashlib
 import json
 import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def lib_sha16():
+  """The build the counters were collected on (bench.py compares it with the library it runs)."""
+  try:
+    with open(os.environ.get('RIGL_HIP_LIB') or os.path.join(ROOT, 'rigl_amd', 'lib', 'librigl_hip.so'), 'rb') as fh:
+      return hashlib.sha256(fh.read()).hexdigest()[:16]
+  except OSError:
+    return None
 
 
 def load(path):
@@ -54,7 +66,7 @@ def main():
   n, rd, wr = tot['K1']
   out = {'kernel': 'K1 (all rigl::k1 launches of 6 ResNet-50 steps, batch 128)', 'launches': n,
          'read_bytes_per_launch': rd / n, 'write_bytes_per_launch': wr / n,
-         'bytes_per_launch': (rd + wr) / n,
+         'bytes_per_launch': (rd + wr) / n, 'lib_sha16': lib_sha16(),
          'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950 '
                    'wide-read correction), KB -> bytes'}
   json.dump(out, open(os.path.join(dst, 'k1_traffic.json'), 'w'), indent=1)

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-2 profile set, all from one box and one build: outputs under gpurun_out/r2prof (copied to profiles/r2 afterwards).
+set -u
+R="$(cd "$(dirname "$0")/.." && pwd)"
+O=$R/gpurun_out/r2prof; mkdir -p $O
+cd $R
+timeout 600 python bench.py > $O/bench_n1.json 2>$O/bench_err.txt; echo "bench rc=$?" | tee $O/log.txt
+for w in resnet50_erk99 mobilenet_v1 wrn22; do
+  timeout 300 python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2>>$O/bench_err.txt; echo "$w rc=$?" | tee -a $O/log.txt
+done
+timeout 300 python bench.py --workload wrn22 --graph --no-cpu-baseline > $O/bench_wrn22_graph.json 2>>$O/bench_err.txt; echo "wrn22 graph rc=$?" | tee -a $O/log.txt
+timeout 600 python tools/bench_kernels.py > $O/bench_kernels_per_layer.txt 2>&1; echo "bench_kernels rc=$?" | tee -a $O/log.txt
+timeout 300 python tools/k2_time.py > $O/k2_time.txt 2>&1
+cd /tmp; export TMPDIR=/tmp
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 30 --warmup 10 --no-cpu-baseline > $O/prof_run.txt 2>&1; echo "rocprof rc=$?" | tee -a $O/log.txt
+cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv; cp $(find $O/prof -name "*domain_stats.csv" | head -1) $O/bench_domain_stats.csv 2>/dev/null
+rm -rf $O/prof
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o pmc -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-prof > $O/pmc_run_$c.txt 2>&1; echo "pmc $c rc=$?" | tee -a $O/log.txt
+  f=$(find $O/pmc_$c -name "*counter_collection.csv" | head -1); mv $f $O/pmc_$c/pmc_counter_collection.csv 2>/dev/null
+done
+python $R/tools/pmc_summary.py $O $O | tee -a $O/log.txt
+rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
+  --output-format csv -d $O/pmc_sq -o pmc -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-prof > $O/pmc_run_sq.txt 2>&1; echo "pmc sq rc=$?" | tee -a $O/log.txt
+python $R/tools/pmc_sq_summary.py $(find $O/pmc_sq -name "*counter_collection.csv" | head -1) > $O/pmc_sq_k1.txt 2>&1
+rm -rf $O/pmc_sq
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/k2prof -o k2 -- python $R/tools/k2_profile.py > $O/k2_run.txt 2>&1
+python $R/tools/k2_profile.py --summarise $(find $O/k2prof -name "*kernel_stats.csv" | head -1) > $O/k2_kernels.txt 2>&1
+rm -rf $O/k2prof
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mbprof -o mb -- python $R/bench.py --workload mobilenet_v1 --steps 20 --warmup 5 --no-cpu-baseline --no-prof > $O/mb_run.txt 2>&1
+cp $(find $O/mbprof -name "*kernel_stats.csv" | head -1) $O/mobilenet_kernel_stats.csv; rm -rf $O/mbprof
+tail -3 $O/pmc_sq_k1.txt | tee -a $O/log.txt; tail -3 $O/k2_kernels.txt | tee -a $O/log.txt; tail -4 $O/bench_kernels_per_layer.txt | tee -a $O/log.txt
+ls -la $O | tee -a $O/log.txt
