@@ -598,7 +598,14 @@ class SparseSnipOptimizer(PruningGetterMixin, train.Optimizer):
       for l in self.graph.masked_layers():
         n = l.weights.numel
         n_keep = n - sparse_utils.get_n_zeros(n, sparsities[l.mask.name])
-        score = (l.weights.grad * l.weights.data).abs().contiguous().view(-1)   # |g * v|  (:301)
+        # |g * v| (:301) with g the gradient of the WHOLE loss w.r.t. the raw variable: at step 0 the layer is still
+        # dense, so g = dL/d(mask*W) + weight_decay * W -- the l2 term the update kernel otherwise folds in
+        # (``rigl_masked_sgd_momentum``) belongs in the score (the reference's loss includes the regulariser,
+        # imagenet_train_eval.py:578-584)
+        g_var = l.weights.grad
+        if l.weights.weight_decay:
+          g_var = g_var + float(l.weights.weight_decay) * l.weights.data
+        score = (g_var * l.weights.data).abs().contiguous().view(-1)
         items.append((score, n_keep, l.mask.bits))
       ops.topk_mask_batched(items)
       self.graph.shadows_dirty = True
@@ -638,7 +645,9 @@ class SparseDNWOptimizer(PruningGetterMixin, train.Optimizer):
 
   def apply_gradients(self, grads_and_vars, global_step=None, name=None):
     from rigl_amd import sparse_utils  # pylint: disable=import-outside-toplevel
-    self._optimizer.dense_masked_update = True       # no `mask *` on the gradient
+    # no `mask *` on the gradient, and NO l2 term on the masked kernels: the reference differentiates w.r.t. the
+    # masked_weights tensors (:375-386), which the regulariser -- a function of the raw variables -- does not reach
+    self._optimizer.dense_masked_update = True
     try:
       self._optimizer.apply_gradients(grads_and_vars, global_step=global_step,
                                       name=name)

@@ -131,6 +131,8 @@ class GradientDescentOptimizer(Optimizer):
         self._apply_per_variable(kind, lr, mu, scale)
         continue
       wd = wds.pop() if wds else 0.0
+      if kind == V.KIND_MASKED and self.dense_masked_update:
+        wd = 0.0                 # DNW: gradients are taken w.r.t. mask*W, which the l2 regulariser does not reach
       ops.masked_sgd_momentum(
           g.W[b:e], g.G[b:e], lr,
           momentum=self._slot[b:e] if self._slot is not None else None,
@@ -161,7 +163,7 @@ class GradientDescentOptimizer(Optimizer):
           g.W[o:o + n4], g.G[o:o + n4], lr,
           momentum=self._slot[o:o + n4] if self._slot is not None else None,
           mask_bits=(l.mask.bits if l.mask is not None and not self.dense_masked_update else None), mu=mu,
-          weight_decay=v.weight_decay, grad_scale=scale,
+          weight_decay=(0.0 if (kind == V.KIND_MASKED and self.dense_masked_update) else v.weight_decay), grad_scale=scale,
           nesterov=self._nesterov)
 
 
