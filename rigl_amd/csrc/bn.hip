@@ -407,7 +407,7 @@ int rigl_bn_bwd_stats(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16*
     else RIGL_BWD_REDUCE(true, 0);
 #undef RIGL_BWD_REDUCE
   }
-  if (g.parts > 256)
+  if (g.parts > MAX_PARTS)      // only a dgrad epilogue leaves more partial rows than k_reduce's cap (<16> is 0.7 us faster below it)
     hipLaunchKernelGGL(k_bwd_finalize<4>, dim3((unsigned)((c + 3) / 4)), dim3(THREADS), 0, st, g, red, gamma,
                        save_invstd, dgamma, dbeta, coef);
   else
