@@ -139,13 +139,18 @@ def main():
   dev_index = 0 if one_device else local_rank
   torch.cuda.set_device(dev_index)
   dev = torch.device('cuda', dev_index)
-  if world > 1:
+  # RIGL_BENCH_FORCE_SYNC=1: run the whole data-parallel machinery (process group, bucketed exchange launched from inside
+  # backward, coalesced last bucket, timeline, exposed-communication probe, mask check) even with ONE rank -- the only way
+  # to execute the RCCL code path on a single-GPU box (tests/test_dp_smoke_gpu.py); never used for numbers.
+  force_sync = os.environ.get('RIGL_BENCH_FORCE_SYNC', '0') == '1'
+  if world > 1 or force_sync:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29577')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC only on this pool (RCCL needs it)
     if backend == 'nccl':
-      dist.init_process_group('nccl', device_id=dev)
+      dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
     else:
-      dist.init_process_group(backend)
+      dist.init_process_group(backend, rank=rank, world_size=world)
   assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
   from rigl_amd import ops, sparse_optimizers, train, variables
@@ -154,12 +159,12 @@ def main():
 
   g = variables.reset_default_graph(dev)
   wl = build_workload(args.workload, g, dev, args.batch, rank, args.sparsity)
-  sync = GradSync(g, enabled=not args.no_sync) if world > 1 else None
+  sync = GradSync(g, enabled=not args.no_sync) if (world > 1 or force_sync) else None
   global_batch = args.batch * world
   lr = wl['lr'](global_batch)
   inner = train.MomentumOptimizer(lr, 0.9, use_nesterov=True, graph=g, grad_sync=sync)
   opt = sparse_optimizers.SparseRigLOptimizer(
-      inner, grow_init='zeros', initial_acc_scale=0.0, use_tpu=world > 1 and not args.no_sync, **wl['opt'])
+      inner, grow_init='zeros', initial_acc_scale=0.0, use_tpu=sync is not None and not args.no_sync, **wl['opt'])
   gs = g.get_or_create_global_step()
   loss_fn = wl['loss']
 
@@ -170,7 +175,7 @@ def main():
 
   def fence():
     torch.cuda.synchronize()
-    if world > 1:
+    if sync is not None:
       dist.barrier()
     torch.cuda.synchronize()
 
@@ -277,7 +282,7 @@ def main():
     dist.all_reduce(t_nosync, op=dist.ReduceOp.MAX)
     comm_exposed = {'ms_per_step_without_exchange': float(t_nosync.item()) * 1e3, 'steps': n_probe}
   t = torch.tensor([dt], dtype=torch.float64, device=dev)
-  if world > 1:
+  if sync is not None:
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
   dt = float(t.item())
   ms_per_step = dt / args.steps * 1e3
@@ -299,7 +304,7 @@ def main():
                    'global_batch': global_batch, 'per_gpu_batch': args.batch,
                    'parallelism': 'dp%d' % world, 'mask_updates_in_timed_region': n_updates,
                    'masks_identical_across_ranks': masks_same,
-                   'gradient_exchange': (None if world == 1 else ('off (--no-sync)' if args.no_sync else 'on')),
+                   'gradient_exchange': (None if sync is None else ('off (--no-sync)' if args.no_sync else 'on (%s, world %d)' % (backend, world))),
                    'execution': ('HIP graph replay of ordinary steps (%d replays, %d eager steps incl. mask updates)'
                                  % (graphed.replays, graphed.eager_steps)) if graphed is not None else 'eager',
                    'lib_sha16': lib_sha16()},
@@ -388,7 +393,7 @@ def main():
         out['cpu_baseline'] = {'value': None, 'unit': 'images/sec', 'cores': os.cpu_count(), 'kind': 'port',
                                'sample': 'failed: %r' % (e,)}
     print(json.dumps(out))
-  if world > 1:
+  if sync is not None:
     dist.barrier()
     dist.destroy_process_group()
 

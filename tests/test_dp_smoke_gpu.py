@@ -78,3 +78,33 @@ def test_bench_other_workloads(workload, extra):
   assert r['frac'] > 0 and r['hbm_kernels']['prune_regrow']['ms_per_update'] > 0
   if extra:
     assert r['hbm_kernels'][extra]['achieved'] > 0 and r['hbm_kernels'][extra]['launches_per_step'] > 0
+
+
+@pytest.mark.gpu
+def test_rccl_code_path_executes_with_one_rank():
+  """The data-parallel machinery on RCCL itself ('nccl' backend), forced on with a single rank (a gpurun box has one GPU and
+  RCCL refuses two ranks per device): communicator init, rank-0 state broadcast, bucketed all-reduce launched from inside
+  backward, the coalesced last launch (head of the kernel segment + BN / bias segment in one group call), per-bucket
+  timeline with device events, the exposed-communication probe and the mask check all run; a one-rank sum leaves the
+  gradients unchanged, so the step must equal the plain single-GPU step bit for bit (same loss trajectory)."""
+  env = dict(os.environ, RIGL_BENCH_FORCE_SYNC='1', RIGL_BENCH_BACKEND='nccl', MASTER_ADDR='127.0.0.1', MASTER_PORT='29593',
+             RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '1', '--batch', '16',
+         '--no-cpu-baseline']
+  out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stderr[-3000:]
+  d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+  assert d['config']['gradient_exchange'] == 'on (nccl, world 1)'
+  assert d['config']['masks_identical_across_ranks'] is True
+  ar = d['allreduce']
+  assert ar['buckets'] >= 3 and ar['bytes'] > 4 * 25_000_000
+  rows = ar['in_step']['buckets']
+  assert len(rows) >= 3 and sum(r['bytes'] for r in rows) == ar['bytes']          # every gradient element exchanged exactly once
+  assert all('device_ms_after_first_bucket' in r for r in rows) and ar['in_step']['tail_wait_ms'] is not None
+  assert 'comm_exposed_ms' in ar['exposed']
+  # and the numbers are those of the plain step
+  plain = subprocess.run(cmd, env={k: v for k, v in env.items() if k != 'RIGL_BENCH_FORCE_SYNC'}, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+  assert plain.returncode == 0, plain.stderr[-2000:]
+  p = json.loads([l for l in plain.stdout.splitlines() if l.startswith('{')][-1])
+  assert p['config']['gradient_exchange'] is None and 'allreduce' not in p
