@@ -144,3 +144,50 @@ def test_config5_mobilenet_v1_uniform90():
   # depthwise weights really train (dense gradient landed in the arena)
   dwv = [v for v in g.variables.values() if v.name.endswith('depthwise_weights:0')]
   assert len(dwv) == 13 and all(float(v.grad.abs().sum()) > 0 for v in dwv)
+
+
+def test_config1_mnist_trajectory_every_update_bit_exact():
+  """BASELINE config 1 over time: 330 iterations of the MNIST MLP (RigL dT = 100, cosine drop fraction), i.e. four mask
+  updates at different drop fractions with training in between.  At EVERY update iteration the oracle is fed the
+  device's own state (masks, weights, dense gradients, momentum) and must reproduce the new masks, the re-initialised
+  weights and the momentum reset bit for bit; between updates the schedule's bookkeeping (no step increment on update
+  iterations, last_update_step, drop fraction = fp32 cosine of the global step) is checked against the oracle."""
+  from rigl_amd import sparse_optimizers as SO, sparse_utils, train, variables as V
+  from rigl_amd.workloads import mnist_mlp
+  g = V.reset_default_graph(DEV)
+  model = mnist_mlp.MnistMLP(g)
+  np.random.seed(3)
+  sparse_utils.get_mask_init_fn(g.get_masks(), 'random', 0.9, {'layer3': 0.0})()
+  inner = train.MomentumOptimizer(0.2, 0.9, use_nesterov=True, graph=g)
+  begin, end, freq, f0 = 0, 300, 100, 0.3
+  opt = SO.SparseRigLOptimizer(inner, begin, end, freq, drop_fraction=f0, drop_fraction_anneal='cosine', noise_std=0.)
+  gs = g.get_or_create_global_step()
+  layers = g.masked_layers()
+  ones0 = [int(l.mask.numpy().sum()) for l in layers]
+  updates = []
+  for it in range(330):
+    x, y = mnist_mlp.synthetic_batch(100, DEV, seed=1000 + it)
+    step = int(gs.value)
+    is_upd = (begin <= step <= end) and (opt._last_update_step + freq <= step)
+    gv = opt.compute_gradients(model.loss(x, y))
+    if is_upd:
+      inner._ensure_slots()
+      before = [(l.mask.numpy().copy(), l.weights.numpy().copy(), l.weights.grad.cpu().numpy().copy(),
+                 inner.get_slot(l.weights, 'momentum').cpu().numpy().copy()) for l in layers]
+    opt.apply_gradients(gv, gs)
+    if not is_upd:
+      assert int(gs.value) == step + 1
+      continue
+    assert int(gs.value) == step and opt._last_update_step == step          # F9: an update iteration takes no step
+    frac = O.get_drop_fraction('cosine', f0, step, begin, end, True)
+    assert np.float32(opt.drop_fraction) == np.float32(frac)
+    for l, (m0, w0, g0, a0) in zip(layers, before):
+      r = O.rigl_mask_update(m0, w0, g0, frac, momentum=a0)
+      np.testing.assert_array_equal(l.mask.numpy(), r['mask'], err_msg='%s @ %d' % (l.scope, step))
+      np.testing.assert_array_equal(l.weights.numpy().view(np.uint32), r['weights'].view(np.uint32))
+      np.testing.assert_array_equal(inner.get_slot(l.weights, 'momentum').cpu().numpy().view(np.uint32),
+                                    r['momentum'].view(np.uint32))
+    updates.append((step, float(frac)))
+  assert [u[0] for u in updates] == [0, 100, 200, 300]
+  assert updates[0][1] > updates[1][1] > updates[2][1] > updates[3][1] >= 0.0     # cosine decay to zero at end_step
+  assert [int(l.mask.numpy().sum()) for l in layers] == ones0                       # connections conserved throughout
