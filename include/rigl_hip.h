@@ -326,6 +326,16 @@ int rigl_masked_conv2d_bwd_bn(const RiglConvDesc* d, const rigl_bf16* x,
 size_t rigl_depthwise_conv2d_workspace_bytes(const RiglConvDesc* d);
 int rigl_depthwise_conv2d_fwd(const RiglConvDesc* d, const rigl_bf16* x,
                               const float* w, rigl_bf16* y, rigl_stream_t stream);
+/* The forward that also leaves the batch-norm statistics of its output (every
+ * depthwise conv of mobilenetv1_model.py:188-198 is followed by a batch norm):
+ * stats[p][0][c] = sum, stats[p][1][c] = sum of squares of the bf16-rounded
+ * outputs of partial row p < rigl_depthwise_conv2d_stats_parts(d) (0: shape has
+ * no such epilogue: 3x3, stride 1 / 2, (channels / 8) dividing 256 do).
+ * Deterministic; consumed by rigl_bn_fwd_stats.  stats == NULL: plain forward. */
+int32_t rigl_depthwise_conv2d_stats_parts(const RiglConvDesc* d);
+int rigl_depthwise_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x,
+                                    const float* w, rigl_bf16* y, float* stats,
+                                    size_t stats_floats, rigl_stream_t stream);
 int rigl_depthwise_conv2d_dgrad(const RiglConvDesc* d, const rigl_bf16* dy,
                                 const float* w, rigl_bf16* dx,
                                 rigl_stream_t stream);

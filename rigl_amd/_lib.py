@@ -121,6 +121,8 @@ SIGNATURES = {
     'rigl_conv2d_wgrad_ref': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     'rigl_depthwise_conv2d_workspace_bytes': (_SZ, [C.POINTER(ConvDesc)]),
     'rigl_depthwise_conv2d_fwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    'rigl_depthwise_conv2d_stats_parts': (_I32, [C.POINTER(ConvDesc)]),
+    'rigl_depthwise_conv2d_fwd_stats': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _SZ, _P]),
     'rigl_depthwise_conv2d_dgrad': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     'rigl_depthwise_conv2d_wgrad': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _SZ, _P]),
     'rigl_bn_workspace_bytes': (_SZ, [_I64, _I32]),

@@ -221,18 +221,18 @@ struct G3 {
 
 // produced[n, p, q, c] = sum_{r, s} gathered[n, p S - pt + r, q S - pl + s, c] * w[tap(r, s), c]
 // FLIP (the stride-1 dgrad): tap(r, s) = (2 - r, 2 - s).
-template <int S, bool FLIP>
-__global__ __launch_bounds__(THREADS) void k_fwd3(G3 g, const uint16_t* __restrict__ in, const float* __restrict__ w,
-                                                  uint16_t* __restrict__ out) {
+// One work item (strip of TW produced pixels x 8 channels).  STATS: also add the bf16-rounded outputs and their squares to
+// q0 / q1 (the batch-norm statistics of the tensor as the batch norm will read it).
+template <int S, bool FLIP, bool STATS>
+__device__ __forceinline__ void fwd3_item(const G3& g, int i, const uint16_t* __restrict__ in, const float* __restrict__ w,
+                                          uint16_t* __restrict__ out, float q0[8], float q1[8]) {
   constexpr int NC = (TW - 1) * S + 3;
-  const int i = (int)xcd_remap(blockIdx.x, gridDim.x) * THREADS + threadIdx.x;
-  if (i >= g.total) return;
   const int t = fdiv(i, g.fd_cg), cgi = i - t * g.cg;
   const int t2 = fdiv(t, g.fd_sw), strip = t - t2 * g.SW;
   const int n = fdiv(t2, g.fd_ph), po = t2 - n * g.PH;
-  const int c0 = cgi * 8, q0 = strip * TW;
+  const int c0 = cgi * 8, q0s = strip * TW;
   const __amdgpu_buffer_rsrc_t rs = make_rsrc(in, g.g_bytes);
-  const int gw0 = q0 * S - g.pl;
+  const int gw0 = q0s * S - g.pl;
   float acc[TW][8];
 #pragma unroll
   for (int j = 0; j < TW; ++j)
@@ -276,9 +276,70 @@ __global__ __launch_bounds__(THREADS) void k_fwd3(G3 g, const uint16_t* __restri
   }
   const int obase = ((n * g.PH + po) * g.PW) * g.C + c0;
 #pragma unroll
-  for (int j = 0; j < TW; ++j)
-    if (q0 + j < g.PW) *reinterpret_cast<uint4*>(out + obase + (q0 + j) * g.C) = pack8(acc[j]);
+  for (int j = 0; j < TW; ++j) {
+    if (q0s + j < g.PW) {
+      const uint4 pk = pack8(acc[j]);
+      *reinterpret_cast<uint4*>(out + obase + (q0s + j) * g.C) = pk;
+      if (STATS) {
+        float v[8];
+        unpack8(pk, v);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { q0[c] += v[c]; q1[c] = fmaf(v[c], v[c], q1[c]); }
+      }
+    }
+  }
 }
+
+template <int S, bool FLIP>
+__global__ __launch_bounds__(THREADS) void k_fwd3(G3 g, const uint16_t* __restrict__ in, const float* __restrict__ w,
+                                                  uint16_t* __restrict__ out) {
+  const int i = (int)xcd_remap(blockIdx.x, gridDim.x) * THREADS + threadIdx.x;
+  if (i >= g.total) return;
+  fwd3_item<S, FLIP, false>(g, i, in, w, out, nullptr, nullptr);
+}
+
+// The forward with the batch-norm statistics of its output in the epilogue (MobileNet-v1 follows every depthwise conv with
+// a batch norm, mobilenetv1_model.py:188-198, whose first pass would re-read the tensor): a workgroup walks
+// stats_reps x 256 consecutive items -- the items of a thread are a multiple of 256 apart, so they share one channel
+// group ((channels / 8) divides 256) -- and leaves one partial row [2][C]: sum y, sum y^2 of the bf16 outputs, combined
+// over the threads of each channel group in a fixed order (deterministic).  Consumed by rigl_bn_fwd_stats.
+inline int stats_reps() {      // items per thread of the statistics forward (RIGL_DW_STATS_REPS, default 2: a wave waits for its stores between items)
+  static const int v = [] { const char* e = getenv("RIGL_DW_STATS_REPS"); const int r = e ? atoi(e) : 2; return r < 1 ? 1 : r > 64 ? 64 : r; }();
+  return v;
+}
+template <int S>
+__global__ __launch_bounds__(THREADS) void k_fwd3_stats(G3 g, int stats_reps, const uint16_t* __restrict__ in,
+                                                        const float* __restrict__ w, uint16_t* __restrict__ out,
+                                                        float* __restrict__ stats) {
+  __shared__ float red[THREADS / 64][64][17];
+  const int b = (int)xcd_remap(blockIdx.x, gridDim.x);
+  float q[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) q[c] = 0.f;
+#pragma unroll 1
+  for (int rep = 0; rep < stats_reps; ++rep) {
+    const int i = (b * stats_reps + rep) * THREADS + threadIdx.x;
+    if (i < g.total) fwd3_item<S, false, true>(g, i, in, w, out, q, q + 8);
+  }
+  // lanes cg apart hold the same channel group: butterfly over them first, then one LDS row per (wave, channel group)
+  const int span = g.cg < 64 ? g.cg : 64;
+  for (int off = 32; off >= span; off >>= 1)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) q[c] += __shfl_xor(q[c], off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < span)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) red[wave][lane][c] = q[c];
+  __syncthreads();
+  const int wps = g.cg > 64 ? g.cg >> 6 : 1;        // waves one pass over the channel groups takes
+  for (int p = threadIdx.x; p < g.cg * 16; p += THREADS) {
+    const int cgq = p >> 4, v = p & 15;
+    float sum = 0.f;
+    for (int r = cgq >> 6; r < THREADS / 64; r += wps) sum += red[r][cgq & 63][v];
+    stats[((int64_t)b * 2 + (v >> 3)) * g.C + cgq * 8 + (v & 7)] = sum;
+  }
+}
+
 
 // Stride-2 dgrad: dx[n, h, w, c] = sum over the taps whose parity matches, dy[n, (h + pt - r) / 2, (w + pl - s) / 2, c] * w[r, s, c].
 // A strip of 4 dx pixels (w0 % 4 == 0) touches 3 dy columns; which (pixel, tap) pairs meet which column depends only
@@ -521,6 +582,36 @@ size_t rigl_depthwise_conv2d_workspace_bytes(const RiglConvDesc* d) {
   }
   rigl::kdw::WGeom g = rigl::kdw::make_wgeom(d);
   return rigl::align_up((size_t)g.parts * d->kh * d->kw * d->cin * 4, 256);
+}
+
+// Partial rows the forward leaves with rigl_depthwise_conv2d_fwd_stats (0: this shape has no statistics epilogue).
+int32_t rigl_depthwise_conv2d_stats_parts(const RiglConvDesc* d) {
+  using namespace rigl;
+  if (!d || kdw::check(d, "rigl_depthwise_conv2d_stats_parts") || !kdw::use3(d)) return 0;
+  const int cg = d->cin / 8;
+  if (cg > kdw::THREADS || kdw::THREADS % cg) return 0;
+  const kdw::G3 g = kdw::make_g3(d, d->h, d->w, d->ho, d->wo, d->pad_top, d->pad_left, true);
+  const int64_t per = (int64_t)kdw::THREADS * kdw::stats_reps();
+  return (int32_t)((g.total + per - 1) / per);
+}
+
+int rigl_depthwise_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, const float* w, rigl_bf16* y, float* stats,
+                                    size_t stats_floats, rigl_stream_t stream) {
+  using namespace rigl;
+  if (!stats) return rigl_depthwise_conv2d_fwd(d, x, w, y, stream);
+  int rc = kdw::check(d, "rigl_depthwise_conv2d_fwd_stats");
+  if (rc) return rc;
+  if (!x || !w || !y) return fail(RIGL_EINVAL, "rigl_depthwise_conv2d_fwd_stats: NULL tensor");
+  const int32_t parts = rigl_depthwise_conv2d_stats_parts(d);
+  if (parts <= 0) return fail(RIGL_EUNSUPPORTED, "rigl_depthwise_conv2d_fwd_stats: no statistics epilogue for this shape");
+  if (stats_floats < (size_t)parts * 2 * d->cin)
+    return fail(RIGL_EWORKSPACE, "rigl_depthwise_conv2d_fwd_stats: stats buffer %zu floats < %zu", stats_floats, (size_t)parts * 2 * d->cin);
+  ProfScope prof(PROF_DEPTHWISE, as_stream(stream));
+  const kdw::G3 g = kdw::make_g3(d, d->h, d->w, d->ho, d->wo, d->pad_top, d->pad_left, true);
+  if (d->stride_h == 1) hipLaunchKernelGGL(kdw::k_fwd3_stats<1>, dim3((unsigned)parts), dim3(kdw::THREADS), 0, as_stream(stream), g, kdw::stats_reps(), x, w, y, stats);
+  else hipLaunchKernelGGL(kdw::k_fwd3_stats<2>, dim3((unsigned)parts), dim3(kdw::THREADS), 0, as_stream(stream), g, kdw::stats_reps(), x, w, y, stats);
+  RIGL_CHECK_LAUNCH("rigl_depthwise_conv2d_fwd_stats");
+  return RIGL_OK;
 }
 
 int rigl_depthwise_conv2d_fwd(const RiglConvDesc* d, const rigl_bf16* x, const float* w, rigl_bf16* y,

@@ -490,13 +490,24 @@ def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None, 
 # ----------------------------------------------------------------------------
 # K1d depthwise
 # ----------------------------------------------------------------------------
-def depthwise_fwd(d, x, w):
+def depthwise_fwd(d, x, w, stats=False):
+  """y = depthwise conv(x, w).  With ``stats`` returns (y, partials): fp32 [parts, 2, C] batch-norm partial sums of y left
+  by the kernel's epilogue (None for shapes without one)."""
   _count_depthwise(d)
   _req(x, torch.bfloat16, 'x')
   _req(w, torch.float32, 'w')
   y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16, device=x.device)
-  check(_lib.load().rigl_depthwise_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _stream()))
-  return y
+  lib = _lib.load()
+  if stats:
+    parts = getattr(d, '_dw_parts', None)
+    if parts is None:
+      parts = d._dw_parts = int(lib.rigl_depthwise_conv2d_stats_parts(C.byref(d)))
+    if parts > 0:
+      part = torch.empty((parts, 2, d.cout), dtype=torch.float32, device=x.device)
+      check(lib.rigl_depthwise_conv2d_fwd_stats(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(part), part.numel(), _stream()))
+      return y, part
+  check(lib.rigl_depthwise_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _stream()))
+  return (y, None) if stats else y
 
 
 def depthwise_dgrad(d, dy, w):

@@ -51,7 +51,7 @@ class MobileNetV1:
   def __call__(self, images, is_training=True):
     x = self.stem_bn(self._stem(images), is_training, relu=True)
     for dw, bn_a, pw, bn_b in self.blocks:
-      x = bn_a(dw(x), is_training, relu=True)
+      x = bn_a(dw(x, bn_stats=True), is_training, relu=True)
       x = bn_b(pw(x, bn_stats=True), is_training, relu=True)
     return self.fc(gnn.global_avg_pool(x))
 

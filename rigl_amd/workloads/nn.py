@@ -16,6 +16,7 @@ from rigl_amd.pruning_layers import bias_tensor
 
 BATCH_NORM_DECAY = 0.9      # resnet_model.py:37
 BATCH_NORM_EPSILON = 1e-5   # resnet_model.py:38
+_DW_STATS = os.environ.get('RIGL_DW_STATS', '1') != '0'   # depthwise forward leaves the next batch norm's statistics
 
 
 def nchw_view(x):
@@ -137,21 +138,28 @@ class BatchNorm:
 class _DepthwiseFn(torch.autograd.Function):
 
   @staticmethod
-  def forward(ctx, x, layer, desc):
+  def forward(ctx, x, layer, desc, want_stats=False):
     from rigl_amd import ops  # pylint: disable=import-outside-toplevel
     x = x.contiguous()
     ctx.layer, ctx.desc = layer, desc
     ctx.save_for_backward(x)
-    return ops.depthwise_fwd(desc, x, layer.weights.data.view(-1))
+    if not want_stats:
+      return ops.depthwise_fwd(desc, x, layer.weights.data.view(-1))
+    y, part = ops.depthwise_fwd(desc, x, layer.weights.data.view(-1), stats=True)
+    if part is None:
+      part = torch.empty(0, device=x.device)
+    ctx.mark_non_differentiable(part)
+    ctx.set_materialize_grads(False)
+    return y, part
 
   @staticmethod
-  def backward(ctx, dy):
+  def backward(ctx, dy, _dpart=None):
     from rigl_amd import ops  # pylint: disable=import-outside-toplevel
     (x,) = ctx.saved_tensors
     dy = dy.contiguous()
     w = ctx.layer.weights
     ops.depthwise_wgrad(ctx.desc, x, dy, w.grad.view(-1))          # dense fp32, into the gradient arena
-    return ops.depthwise_dgrad(ctx.desc, dy, w.data.view(-1)), None, None
+    return ops.depthwise_dgrad(ctx.desc, dy, w.data.view(-1)), None, None, None
 
 
 class DepthwiseConv2d:
@@ -167,7 +175,9 @@ class DepthwiseConv2d:
                                       V.KIND_OTHER, 0.0, init)
     self._descs = {}
 
-  def __call__(self, x):
+  def __call__(self, x, bn_stats=False):
+    """``bn_stats``: leave the batch-norm partial sums of the output on the returned tensor (``bn_partials``) for the
+    BatchNorm that follows, which then skips its statistics pass (rigl_depthwise_conv2d_fwd_stats)."""
     from rigl_amd import ops  # pylint: disable=import-outside-toplevel
     n, h, w, c = x.shape
     d = self._descs.get((n, h, w))
@@ -178,7 +188,12 @@ class DepthwiseConv2d:
       self._descs[(n, h, w)] = d
     if not x.requires_grad:
       x = x.detach().requires_grad_(True)
-    return _DepthwiseFn.apply(x, self, d)
+    if not (bn_stats and _DW_STATS):
+      return _DepthwiseFn.apply(x, self, d)
+    y, part = _DepthwiseFn.apply(x, self, d, True)
+    if part.numel():
+      y.bn_partials = part
+    return y
 
 
 class _MaxPoolFn(torch.autograd.Function):

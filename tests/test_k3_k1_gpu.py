@@ -454,3 +454,17 @@ def test_depthwise_conv(case):
   dw2 = torch.empty_like(dw)
   ops.depthwise_wgrad(d, x.to(DEV), dy.to(DEV), dw2)
   assert torch.equal(dw, dw2)
+  # the forward with the batch-norm statistics epilogue: same y bit for bit, partial rows that add up to the sums of the
+  # bf16-rounded outputs, and the same partial rows on a second launch
+  ys, part = ops.depthwise_fwd(d, x.to(DEV), wd, stats=True)
+  assert torch.equal(ys.float().cpu(), y)
+  if k == 3 and C % 8 == 0 and 256 % (C // 8) == 0:
+    assert part is not None and part.shape[1:] == (2, C)
+    y64 = ys.double().reshape(-1, C)
+    tot = part.double().sum(0)
+    assert (tot[0] - y64.sum(0)).abs().max() <= 1e-5 * y64.abs().sum(0).max() + 1e-6
+    assert (tot[1] - (y64 * y64).sum(0)).abs().max() <= 1e-5 * (y64 * y64).sum(0).max() + 1e-6
+    _, part2 = ops.depthwise_fwd(d, x.to(DEV), wd, stats=True)
+    assert torch.equal(part, part2)
+  else:
+    assert part is None
