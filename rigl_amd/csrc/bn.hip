@@ -133,10 +133,22 @@ __device__ __forceinline__ void sum_partials(const Geom& G, const float* __restr
   c = blockIdx.x * CL + cl;
   double a0 = 0.0, a1 = 0.0;
   if (c < G.C) {
-#pragma unroll 4
-    for (int p = pl; p < G.parts; p += PL) {
-      a0 += (double)partial[((int64_t)p * 2) * G.C + c];
-      a1 += (double)partial[((int64_t)p * 2 + 1) * G.C + c];
+    // FLIGHT rows of both quantities are requested before the first is added: the partials were written by other XCDs
+    // (they come from the fabric, not this L2), so the kernel's time is round trips, not bytes.  Rows past the end read
+    // as zero; the additions run in the same ascending order whatever FLIGHT is.
+    constexpr int FLIGHT = 16;
+    for (int p0 = pl; p0 < G.parts; p0 += PL * FLIGHT) {
+      float v0[FLIGHT], v1[FLIGHT];
+#pragma unroll
+      for (int j = 0; j < FLIGHT; ++j) {
+        const int p = p0 + j * PL;
+        const int pc = p < G.parts ? p : G.parts - 1;       // unconditional loads (a branch per load would serialise them)
+        const float l0 = partial[((int64_t)pc * 2) * G.C + c], l1 = partial[((int64_t)pc * 2 + 1) * G.C + c];
+        v0[j] = p < G.parts ? l0 : 0.f;
+        v1[j] = p < G.parts ? l1 : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < FLIGHT; ++j) { a0 += (double)v0[j]; a1 += (double)v1[j]; }
     }
   }
   acc[0][pl][cl] = a0; acc[1][pl][cl] = a1;
