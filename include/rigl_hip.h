@@ -453,6 +453,37 @@ int rigl_maxpool_fwd(const RiglConvDesc* d, const rigl_bf16* x, rigl_bf16* y,
                      uint8_t* argmax, rigl_stream_t stream);
 int rigl_maxpool_bwd(const RiglConvDesc* d, const rigl_bf16* dy,
                      const uint8_t* argmax, rigl_bf16* dx, rigl_stream_t stream);
+/* The stem's tail in one piece: batch_norm_relu followed by that max pooling
+ * (resnet_model.py:631-644) without the activated 112x112x64 tensor -- 205 MB at
+ * batch 128 -- ever being written.
+ *   rigl_bn_fwd_statistics: the statistics half of rigl_bn_fwd_stats (reduction
+ *     pass over x unless `stats` partial sums are given, then mean / invstd /
+ *     scale / shift and the moving averages); no apply pass.
+ *   rigl_bn_relu_maxpool_fwd: y, argmax = maxpool(bf16(relu(x*scale + shift))),
+ *     bit-identical to rigl_bn_fwd followed by rigl_maxpool_fwd.
+ *   rigl_bn_relu_maxpool_bwd: dx, dgamma, dbeta of the pair from the pooled
+ *     gradient dy: both batch-norm passes gather the pooling's input gradient
+ *     (rounded to bf16 as rigl_maxpool_bwd stores it) from dy / argmax on the fly.
+ *     dx equals rigl_maxpool_bwd + rigl_bn_bwd up to the fp32 summation order of
+ *     the two reductions.  3x3 / stride 2, (channels / 4) dividing 64.          */
+int rigl_bn_fwd_statistics(int64_t m, int32_t c, const rigl_bf16* x /* nullable with stats */,
+                           const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum,
+                           float eps, float* save_mean, float* save_invstd,
+                           float* save_scale, float* save_shift,
+                           const float* stats, int32_t stats_parts,
+                           void* workspace, size_t workspace_bytes, rigl_stream_t stream);
+int rigl_bn_relu_maxpool_fwd(const RiglConvDesc* d, const rigl_bf16* x,
+                             const float* scale, const float* shift, rigl_bf16* y,
+                             uint8_t* argmax, rigl_stream_t stream);
+size_t rigl_bn_relu_maxpool_bwd_workspace_bytes(const RiglConvDesc* d);
+int rigl_bn_relu_maxpool_bwd(const RiglConvDesc* d, const rigl_bf16* x,
+                             const rigl_bf16* dy, const uint8_t* argmax,
+                             const float* gamma, const float* save_mean,
+                             const float* save_invstd, const float* save_scale,
+                             const float* save_shift, rigl_bf16* dx, float* dgamma,
+                             float* dbeta, void* workspace, size_t workspace_bytes,
+                             rigl_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Glue: classifier head.  Global average pool over `pixels` positions of an

@@ -135,6 +135,10 @@ SIGNATURES = {
     'rigl_stateless_random_batched': (C.c_int, [C.POINTER(RandomItem), _I32, _P]),
     'rigl_maxpool_fwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     'rigl_maxpool_bwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    'rigl_bn_fwd_statistics': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I32, _P, _SZ, _P]),
+    'rigl_bn_relu_maxpool_fwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    'rigl_bn_relu_maxpool_bwd_workspace_bytes': (_SZ, [C.POINTER(ConvDesc)]),
+    'rigl_bn_relu_maxpool_bwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'rigl_global_avgpool_fwd': (C.c_int, [_I32, _I32, _I32, _P, _P, _P]),
     'rigl_global_avgpool_bwd': (C.c_int, [_I32, _I32, _I32, _P, _P, _P]),
     'rigl_softmax_xent': (C.c_int, [_I32, _I32, _P, _P, _F, _F, _P, _P, _P]),

@@ -320,6 +320,45 @@ static unsigned apply_grid(const Geom& g) {
   return (unsigned)b;
 }
 
+// Backward finalize for a caller that took the reductions itself (pool.hip: the fused stem tail).
+void launch_bwd_finalize(int64_t m, int c, const float* partial, int parts, const float* gamma, const float* invstd,
+                         float* dgamma, float* dbeta, float* coef, hipStream_t st) {
+  Geom g = make_geom(m, c);
+  g.parts = parts;
+  if (parts > MAX_PARTS)
+    hipLaunchKernelGGL(k_bwd_finalize<4>, dim3((unsigned)((c + 3) / 4)), dim3(THREADS), 0, st, g, partial, gamma, invstd,
+                       dgamma, dbeta, coef);
+  else
+    hipLaunchKernelGGL(k_bwd_finalize<16>, dim3((unsigned)((c + 15) / 16)), dim3(THREADS), 0, st, g, partial, gamma, invstd,
+                       dgamma, dbeta, coef);
+}
+
+// Statistics pass (unless the producer left partial sums) + finalize: everything of the forward but the apply pass.
+static int fwd_statistics(Geom& g, int32_t c, const rigl_bf16* x, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                          float* save_invstd, float* save_scale, float* save_shift, const float* stats,
+                          int32_t stats_parts, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  const float* partial = stats;
+  if (!stats) {
+    const size_t need = rigl_bn_workspace_bytes(g.M, c);
+    if (!workspace || workspace_bytes < need) return fail(RIGL_EWORKSPACE, "rigl_bn_fwd: workspace %zu < %zu", workspace_bytes, need);
+    float* ws_partial = static_cast<float*>(workspace);
+    dim3 rgrid((unsigned)g.parts, (unsigned)((g.cg + g.tpr - 1) / g.tpr));
+    hipLaunchKernelGGL((k_reduce<0, false, 0>), rgrid, dim3(THREADS), 0, st, g, x, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, ws_partial);
+    partial = ws_partial;
+  } else {
+    g.parts = stats_parts;               // the producer's partial sums [stats_parts][2][C] replace the reduction pass
+  }
+  if (g.parts > 256)
+    hipLaunchKernelGGL(k_fwd_finalize<4>, dim3((unsigned)((c + 3) / 4)), dim3(THREADS), 0, st, g, partial, gamma,
+                       beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale, save_shift);
+  else
+    hipLaunchKernelGGL(k_fwd_finalize<16>, dim3((unsigned)((c + 15) / 16)), dim3(THREADS), 0, st, g, partial, gamma,
+                       beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale, save_shift);
+  return RIGL_OK;
+}
+
 }  // namespace kbn
 }  // namespace rigl
 
@@ -346,24 +385,9 @@ int rigl_bn_fwd_stats(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16*
   if (stats && stats_parts <= 0) return fail(RIGL_EINVAL, "rigl_bn_fwd_stats: stats_parts must be positive");
   hipStream_t st = as_stream(stream);
   Geom g = make_geom(m, c);
-  const float* partial = stats;
-  if (!stats) {
-    const size_t need = rigl_bn_workspace_bytes(m, c);
-    if (!workspace || workspace_bytes < need) return fail(RIGL_EWORKSPACE, "rigl_bn_fwd: workspace %zu < %zu", workspace_bytes, need);
-    float* ws_partial = static_cast<float*>(workspace);
-    dim3 rgrid((unsigned)g.parts, (unsigned)((g.cg + g.tpr - 1) / g.tpr));
-    hipLaunchKernelGGL((k_reduce<0, false, 0>), rgrid, dim3(THREADS), 0, st, g, x, nullptr, nullptr, nullptr, nullptr, nullptr,
-                       nullptr, nullptr, ws_partial);
-    partial = ws_partial;
-  } else {
-    g.parts = stats_parts;               // the producer's partial sums [stats_parts][2][C] replace the reduction pass
-  }
-  if (g.parts > 256)
-    hipLaunchKernelGGL(k_fwd_finalize<4>, dim3((unsigned)((c + 3) / 4)), dim3(THREADS), 0, st, g, partial, gamma,
-                       beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale, save_shift);
-  else
-    hipLaunchKernelGGL(k_fwd_finalize<16>, dim3((unsigned)((c + 15) / 16)), dim3(THREADS), 0, st, g, partial, gamma,
-                       beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale, save_shift);
+  int rc = fwd_statistics(g, c, x, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+                          save_scale, save_shift, stats, stats_parts, workspace, workspace_bytes, st);
+  if (rc) return rc;
   const size_t lds = (size_t)2 * c * 4;
   dim3 agrid(apply_grid(g));
   if (relu && residual) hipLaunchKernelGGL((k_fwd_apply<true, true>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y, relu_bits);
@@ -380,6 +404,24 @@ int rigl_bn_fwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* resid
                 void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
   return rigl_bn_fwd_stats(m, c, x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, y, save_mean,
                            save_invstd, save_scale, save_shift, nullptr, 0, nullptr, workspace, workspace_bytes, stream);
+}
+
+int rigl_bn_fwd_statistics(int64_t m, int32_t c, const rigl_bf16* x, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                           float* save_invstd, float* save_scale, float* save_shift, const float* stats,
+                           int32_t stats_parts, void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+  using namespace rigl;
+  using namespace rigl::kbn;
+  if (m <= 0 || c <= 0 || (!x && !stats) || !gamma || !beta || !save_mean || !save_invstd || !save_scale || !save_shift)
+    return fail(RIGL_EINVAL, "rigl_bn_fwd_statistics: bad arguments");
+  if (c % 8) return fail(RIGL_EUNSUPPORTED, "rigl_bn_fwd_statistics: channels %% 8 != 0");
+  if (stats && stats_parts <= 0) return fail(RIGL_EINVAL, "rigl_bn_fwd_statistics: stats_parts must be positive");
+  Geom g = make_geom(m, c);
+  int rc = fwd_statistics(g, c, x, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+                          save_scale, save_shift, stats, stats_parts, workspace, workspace_bytes, as_stream(stream));
+  if (rc) return rc;
+  RIGL_CHECK_LAUNCH("rigl_bn_fwd_statistics");
+  return RIGL_OK;
 }
 
 int rigl_bn_bwd_stats(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* y, const uint8_t* relu_bits,

@@ -668,6 +668,44 @@ def maxpool_bwd(d, dy, arg):
   return dx
 
 
+def bn_relu_maxpool_fwd(d, x, gamma, beta, running_mean, running_var, momentum, eps, partials=None):
+  """maxpool(relu(batch_norm(x))) for the pooling geometry ``d`` without the activated tensor
+  (rigl_bn_fwd_statistics + rigl_bn_relu_maxpool_fwd).  Returns (y, argmax, saved) -- saved = fp32 [4, C]
+  (mean, invstd, scale, shift) as bn_fwd returns it."""
+  _req(x, torch.bfloat16, 'x')
+  c = x.shape[-1]
+  m = x.numel() // c
+  lib = _lib.load()
+  saved = torch.empty((4, c), dtype=torch.float32, device=x.device)
+  if partials is not None:
+    _req(partials, torch.float32, 'partials')
+    ws = None
+  else:
+    ws = workspace(lib.rigl_bn_workspace_bytes(m, c), x.device)
+  check(lib.rigl_bn_fwd_statistics(
+      m, c, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
+      _ptr(saved[0]), _ptr(saved[1]), _ptr(saved[2]), _ptr(saved[3]), _ptr(partials),
+      partials.shape[0] if partials is not None else 0, _ptr(ws), ws.numel() if ws is not None else 0, _stream()))
+  y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16, device=x.device)
+  arg = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.uint8, device=x.device)
+  check(lib.rigl_bn_relu_maxpool_fwd(C.byref(d), _ptr(x), _ptr(saved[2]), _ptr(saved[3]), _ptr(y), _ptr(arg), _stream()))
+  return y, arg, saved
+
+
+def bn_relu_maxpool_bwd(d, x, dy, arg, gamma, saved, dgamma, dbeta):
+  """Gradient of bn_relu_maxpool_fwd w.r.t. x; dgamma / dbeta (fp32 [C]) are overwritten."""
+  _req(x, torch.bfloat16, 'x')
+  _req(dy, torch.bfloat16, 'dy')
+  _req(arg, torch.uint8, 'argmax')
+  lib = _lib.load()
+  ws = workspace(lib.rigl_bn_relu_maxpool_bwd_workspace_bytes(C.byref(d)), x.device)
+  dx = torch.empty_like(x)
+  check(lib.rigl_bn_relu_maxpool_bwd(C.byref(d), _ptr(x), _ptr(dy), _ptr(arg), _ptr(gamma), _ptr(saved[0]), _ptr(saved[1]),
+                                     _ptr(saved[2]), _ptr(saved[3]), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
+                                     ws.numel(), _stream()))
+  return dx
+
+
 # ----------------------------------------------------------------------------
 # classifier head glue
 # ----------------------------------------------------------------------------

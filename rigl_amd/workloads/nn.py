@@ -214,6 +214,58 @@ class _MaxPoolFn(torch.autograd.Function):
     return ops.maxpool_bwd(ctx.desc, dy.contiguous(), arg), None
 
 
+class _BnReluMaxPoolFn(torch.autograd.Function):
+  """maxpool_3x3_s2_same(relu(bn(x))) as one node: the activated tensor is never written, the backward's two
+  batch-norm passes gather the pooling gradient on the fly (rigl_bn_relu_maxpool_fwd / _bwd)."""
+
+  @staticmethod
+  def forward(ctx, x, bn, desc, partials=None):
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    x = x.contiguous()
+    y, arg, saved = ops.bn_relu_maxpool_fwd(desc, x, bn.gamma.data, bn.beta.data, bn.moving_mean, bn.moving_variance,
+                                            1.0 - bn.decay, bn.eps, partials=partials)
+    ctx.bn, ctx.desc = bn, desc
+    ctx.save_for_backward(x, arg, saved)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    x, arg, saved = ctx.saved_tensors
+    bn = ctx.bn
+    dx = ops.bn_relu_maxpool_bwd(ctx.desc, x, dy.contiguous(), arg, bn.gamma.data, saved, bn.gamma.grad, bn.beta.grad)
+    return dx, None, None, None
+
+
+_STEM_TAIL_FUSED = os.environ.get('RIGL_STEM_TAIL', '1') != '0'
+
+
+def _pool_desc(x):
+  from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+  n, h, w, c = x.shape
+  key = (n, h, w, c)
+  d = _POOL_DESCS.get(key)
+  if d is None:
+    ho, wo = -(-h // 2), -(-w // 2)
+    ph = max((ho - 1) * 2 + 3 - h, 0)
+    pw = max((wo - 1) * 2 + 3 - w, 0)
+    d = ops.conv_desc(n, h, w, c, c, 3, 3, 2, ph // 2, pw // 2, ho, wo)
+    _POOL_DESCS[key] = d
+  return d
+
+
+def bn_relu_max_pool_3x3_s2_same(bn, x, is_training=True):
+  """batch_norm_relu followed by tf.layers.max_pooling2d(3, 2, 'SAME') (resnet_model.py:631-644)."""
+  c = x.shape[-1]
+  if (_STEM_TAIL_FUSED and bn.fused and is_training and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
+      and c % 8 == 0 and c <= 256 and 64 % (c // 4) == 0 and x.numel() // 4 < (1 << 31)):
+    partials = getattr(x, 'bn_partials', None)
+    if not x.requires_grad:
+      x = x.detach().requires_grad_(True)
+    return _BnReluMaxPoolFn.apply(x, bn, _pool_desc(x), partials)
+  return max_pool_3x3_s2_same(bn(x, is_training, relu=True))
+
+
 _POOL_DESCS = {}
 
 
@@ -222,17 +274,7 @@ def max_pool_3x3_s2_same(x):
   (resnet_model.py:637-644): TF pads (0,1) on even inputs, i.e. only at the
   bottom / right -- not torchvision's symmetric pad 1."""
   if x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[-1] % 8 == 0:
-    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
-    n, h, w, c = x.shape
-    key = (n, h, w, c)
-    d = _POOL_DESCS.get(key)
-    if d is None:
-      ho, wo = -(-h // 2), -(-w // 2)
-      ph = max((ho - 1) * 2 + 3 - h, 0)
-      pw = max((wo - 1) * 2 + 3 - w, 0)
-      d = ops.conv_desc(n, h, w, c, c, 3, 3, 2, ph // 2, pw // 2, ho, wo)
-      _POOL_DESCS[key] = d
-    return _MaxPoolFn.apply(x, d)
+    return _MaxPoolFn.apply(x, _pool_desc(x))
   # TF SAME on an even size pads only bottom/right with -inf; windows start at
   # 0, 2, 4, ... -- exactly max_pool2d(3, 2, padding=0, ceil_mode=True), with no
   # padded copy of the 205 MB stem activation.

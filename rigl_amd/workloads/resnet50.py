@@ -108,8 +108,7 @@ class ResNet50:
 
   def __call__(self, images, is_training=True):
     """images: [N,224,224,3] bf16 (already mean/std normalised)."""
-    x = self.stem_bn(self.stem(images), is_training, relu=True)
-    x = gnn.max_pool_3x3_s2_same(x)
+    x = gnn.bn_relu_max_pool_3x3_s2_same(self.stem_bn, self.stem(images), is_training)
     for b in self.blocks:
       x = b(x, is_training)
     x = gnn.global_avg_pool(x)

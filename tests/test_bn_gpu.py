@@ -194,3 +194,74 @@ def test_bn_bwd_reductions_in_the_dgrad_epilogue(case):
   assert (bx1 != bx0).float().mean() < 0.02          # and almost every element keeps its bits
   if has_res:
     assert torch.equal(br0, br1)                     # dres = dz does not depend on the reductions
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 16, 64), (3, 15, 13, 64), (2, 9, 12, 8), (1, 6, 6, 256), (4, 112, 112, 64),
+                                   (2, 7, 7, 32)])
+def test_bn_relu_maxpool_in_one_piece(shape):
+  """relu(bn(x)) -> 3x3 / 2 'SAME' max pooling without the activated tensor (rigl_bn_relu_maxpool_fwd / _bwd, the
+  ResNet stem's tail) against the three-kernel form it replaces (bn_fwd, maxpool_fwd; maxpool_bwd, bn_bwd): pooled
+  output, argmax bytes, saved statistics and moving averages bit-identical; dx / dgamma / dbeta equal up to the fp32
+  summation order of the two reductions (the gathered gradient is rounded to bf16 at the same point)."""
+  from rigl_amd import ops
+  from rigl_amd.workloads import nn as gnn
+  n, h, w, c = shape
+  gen = torch.Generator(device=DEV).manual_seed(sum(shape))
+  x = (torch.randn(shape, generator=gen, device=DEV) * 1.3 + 0.2).to(torch.bfloat16)
+  gamma = torch.rand(c, generator=gen, device=DEV) + 0.5
+  beta = torch.randn(c, generator=gen, device=DEV) * 0.3
+  d = gnn._pool_desc(x)
+  dyp = torch.randn((n, d.ho, d.wo, c), generator=gen, device=DEV).to(torch.bfloat16)
+  # three-kernel form
+  rm0, rv0 = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+  a, saved0 = ops.bn_fwd(x, gamma, beta, rm0, rv0, 0.1, 1e-5, True)
+  y0, arg0 = ops.maxpool_fwd(d, a)
+  da = ops.maxpool_bwd(d, dyp, arg0)
+  dg0, db0 = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+  dx0, _ = ops.bn_bwd(x, None, da, gamma, saved0, True, dg0, db0)
+  # one piece
+  rm1, rv1 = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+  y1, arg1, saved1 = ops.bn_relu_maxpool_fwd(d, x, gamma, beta, rm1, rv1, 0.1, 1e-5)
+  assert torch.equal(saved0, saved1) and torch.equal(rm0, rm1) and torch.equal(rv0, rv1)
+  assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+  assert torch.equal(arg0, arg1)
+  dg1, db1 = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+  dx1 = ops.bn_relu_maxpool_bwd(d, x, dyp, arg1, gamma, saved1, dg1, db1)
+  scale = lambda t: t.abs().max().item() + 1e-12
+  assert (dg1 - dg0).abs().max().item() <= 1e-5 * scale(dg0) + 1e-6
+  assert (db1 - db0).abs().max().item() <= 1e-5 * scale(db0) + 1e-6
+  # dx: same formula on coefficients that differ in their last fp32 bits -> at most an occasional bf16 ulp
+  diff = (dx1.float() - dx0.float()).abs()
+  assert (diff <= 2.0**-7 * dx0.float().abs() + 1e-6 * scale(dx0.float())).all()
+  assert (diff > 0).float().mean().item() < 0.02
+  # deterministic
+  dg2, db2 = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+  dx2 = ops.bn_relu_maxpool_bwd(d, x, dyp, arg1, gamma, saved1, dg2, db2)
+  assert torch.equal(dx1.view(torch.int16), dx2.view(torch.int16)) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
+
+
+def test_bn_relu_maxpool_autograd_node_equals_the_two_nodes():
+  """nn.bn_relu_max_pool_3x3_s2_same through autograd (fused node vs BatchNorm + max pool nodes)."""
+  import importlib
+  from rigl_amd import variables as V
+  from rigl_amd.workloads import nn as gnn
+  outs = []
+  for fused in (True, False):
+    gnn._STEM_TAIL_FUSED = fused
+    g = V.Graph(DEV)
+    bn = gnn.BatchNorm(g, 'bn', 64)
+    g.finalize()
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    bn.gamma.data.copy_(torch.rand(64, generator=gen, device=DEV) + 0.5)
+    bn.beta.data.copy_(torch.randn(64, generator=gen, device=DEV) * 0.2)
+    x = torch.randn((4, 20, 20, 64), generator=gen, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    y = gnn.bn_relu_max_pool_3x3_s2_same(bn, x, True)
+    dy = torch.randn(y.shape, generator=gen, device=DEV).to(torch.bfloat16)
+    y.backward(dy)
+    outs.append((y.detach(), x.grad.float(), bn.gamma.grad.clone(), bn.beta.grad.clone(), bn.moving_mean.clone()))
+  gnn._STEM_TAIL_FUSED = True
+  (y1, dx1, dg1, db1, mm1), (y0, dx0, dg0, db0, mm0) = outs
+  assert torch.equal(y1.view(torch.int16), y0.view(torch.int16)) and torch.equal(mm1, mm0)
+  assert (dg1 - dg0).abs().max() <= 1e-5 * dg0.abs().max() + 1e-6
+  assert (db1 - db0).abs().max() <= 1e-5 * db0.abs().max() + 1e-6
+  assert ((dx1 - dx0).abs() <= 2.0**-7 * dx0.abs() + 1e-6 * dx0.abs().max()).all()
