@@ -415,6 +415,34 @@ int rigl_bn_bwd_stats(int64_t m, int32_t c, const rigl_bf16* x,
                       float* dbeta, const float* stats, int32_t stats_parts,
                       void* workspace, size_t workspace_bytes, rigl_stream_t stream);
 
+/* Two batch norms meeting in one add: out = relu?(bn(x) + bn2(x2)) -- the first
+ * block of every ResNet group, whose shortcut is projection conv + batch norm
+ * (resnet_model.py:456-501: `shortcut = projection_shortcut(inputs)` ...
+ * `tf.nn.relu(inputs + shortcut)`).  The normalised shortcut and (backward) the
+ * relu-masked gradient are never written.  bn2's statistics come from
+ * rigl_bn_fwd_statistics (scale2 / shift2 = its save_scale / save_shift); the
+ * forward rounds the shortcut to bf16 where bn2 alone would have stored it and
+ * the backward keeps rigl_bn_bwd's row partition, so y, relu_bits, dx, dx2 and
+ * all four parameter gradients are bit-identical to rigl_bn_fwd(x2) ->
+ * rigl_bn_fwd_stats(x, residual) and rigl_bn_bwd(dresidual) -> rigl_bn_bwd.
+ * Backward: relu on, relu_bits required.                                      */
+int rigl_bn_add_bn_fwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* x2,
+                       const float* scale2, const float* shift2,
+                       const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, float momentum, float eps, int32_t relu,
+                       rigl_bf16* y, float* save_mean, float* save_invstd,
+                       float* save_scale, float* save_shift, const float* stats,
+                       int32_t stats_parts, uint8_t* relu_bits /* nullable */,
+                       void* workspace, size_t workspace_bytes, rigl_stream_t stream);
+size_t rigl_bn_add_bn_bwd_workspace_bytes(int64_t m, int32_t c);
+int rigl_bn_add_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* x2,
+                       const uint8_t* relu_bits, const rigl_bf16* dy,
+                       const float* gamma, const float* save_mean, const float* save_invstd,
+                       const float* gamma2, const float* save_mean2, const float* save_invstd2,
+                       rigl_bf16* dx, rigl_bf16* dx2, float* dgamma, float* dbeta,
+                       float* dgamma2, float* dbeta2, void* workspace,
+                       size_t workspace_bytes, rigl_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Stateless random tensors with TensorFlow's bit layout:
  *   out[i] = rnd_i * scale + shift,  rnd = tf.random.stateless_{uniform,normal}

@@ -136,6 +136,9 @@ SIGNATURES = {
     'rigl_maxpool_fwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     'rigl_maxpool_bwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     'rigl_bn_fwd_statistics': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I32, _P, _SZ, _P]),
+    'rigl_bn_add_bn_fwd': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _SZ, _P]),
+    'rigl_bn_add_bn_bwd_workspace_bytes': (_SZ, [_I64, _I32]),
+    'rigl_bn_add_bn_bwd': (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'rigl_bn_relu_maxpool_fwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     'rigl_bn_relu_maxpool_bwd_workspace_bytes': (_SZ, [C.POINTER(ConvDesc)]),
     'rigl_bn_relu_maxpool_bwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -286,6 +286,172 @@ __global__ __launch_bounds__(THREADS) void k_bwd_apply(Geom G, const uint16_t* _
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Two batch norms meeting in one add: out = relu(bn(x) + bn2(x2)) -- the first block of every ResNet group, whose
+// shortcut is a projection conv + batch norm (resnet_model.py:456-501).  As separate calls the shortcut is written by
+// its batch norm and read back by the main one, and in the backward the masked gradient dz is written by the main
+// batch norm for the shortcut's to read twice.  Here neither tensor exists: the forward applies both affine maps in
+// one pass (the shortcut rounded to bf16 in the register, where it would have been stored), the backward takes both
+// batch norms' reductions in one pass over dy and writes both input gradients in another.  Same arithmetic in the same
+// order as the separate calls: bit-identical results (tests/test_bn_gpu.py).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool RELU>
+__global__ __launch_bounds__(THREADS) void k_fwd_apply_pair(Geom G, const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ scale2, const float* __restrict__ shift2,
+                                                             uint16_t* __restrict__ y, uint8_t* __restrict__ mbits) {
+  extern __shared__ __attribute__((aligned(16))) float prm[];   // [4][C]
+  for (int i = threadIdx.x; i < G.C; i += THREADS) {
+    prm[i] = scale[i]; prm[G.C + i] = shift[i]; prm[2 * G.C + i] = scale2[i]; prm[3 * G.C + i] = shift2[i];
+  }
+  __syncthreads();
+  const int64_t total = G.M * G.cg;
+  const int64_t stride = (int64_t)gridDim.x * THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += stride) {
+    const int c0 = (int)(i % G.cg) * 8;
+    float xv[8], rv[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + i * 8), xv);
+    unpack8(*reinterpret_cast<const uint4*>(x2 + i * 8), rv);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      // the shortcut as its own batch norm would have stored it
+      const uint32_t pk = pack2(fmaf(rv[j], prm[2 * G.C + c0 + j], prm[3 * G.C + c0 + j]),
+                                fmaf(rv[j + 1], prm[2 * G.C + c0 + j + 1], prm[3 * G.C + c0 + j + 1]));
+      float v0 = fmaf(xv[j], prm[c0 + j], prm[G.C + c0 + j]);
+      float v1 = fmaf(xv[j + 1], prm[c0 + j + 1], prm[G.C + c0 + j + 1]);
+      v0 += bf_lo(pk); v1 += bf_hi(pk);
+      o[j] = RELU ? fmaxf(v0, 0.f) : v0;
+      o[j + 1] = RELU ? fmaxf(v1, 0.f) : v1;
+    }
+    uint4 out;
+    out.x = pack2(o[0], o[1]); out.y = pack2(o[2], o[3]); out.z = pack2(o[4], o[5]); out.w = pack2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(y + i * 8) = out;
+    if (RELU && mbits) {
+      uint32_t mb = 0u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mb |= (o[j] > 0.f ? 1u : 0u) << j;
+      mbits[i] = (uint8_t)mb;
+    }
+  }
+}
+
+// One pass over dy for both batch norms: (sum dz, sum dz * xhat) and (sum dz, sum dz * xhat2), dz = dy where the ReLU
+// bit is set.  Row partition and combine order are k_reduce's, so each pair of sums has k_reduce's bits.
+__global__ __launch_bounds__(THREADS) void k_reduce_pair(Geom G, const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2,
+                                                          const uint8_t* __restrict__ mbits, const uint16_t* __restrict__ dy,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ mean2, const float* __restrict__ invstd2,
+                                                          float* __restrict__ partial, float* __restrict__ partial2) {
+  __shared__ float red[THREADS][25];
+  const int tx = threadIdx.x % G.tpr, ty = threadIdx.x / G.tpr;
+  const int cgi = blockIdx.y * G.tpr + tx;
+  const bool c_ok = cgi < G.cg;
+  const int64_t r0 = (int64_t)blockIdx.x * G.rows_per_part;
+  int64_t r1 = r0 + G.rows_per_part;
+  if (r1 > G.M) r1 = G.M;
+  float q0[8], q1[8], q2[8], mu[8], is[8], mu2[8], is2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { q0[j] = q1[j] = q2[j] = 0.f; mu[j] = is[j] = mu2[j] = is2[j] = 0.f; }
+  if (c_ok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mu[j] = mean[cgi * 8 + j]; is[j] = invstd[cgi * 8 + j]; mu2[j] = mean2[cgi * 8 + j]; is2[j] = invstd2[cgi * 8 + j];
+    }
+#pragma unroll 2
+    for (int64_t r = r0 + ty; r < r1; r += G.rpb) {
+      const int64_t off = r * G.C + (int64_t)cgi * 8;
+      float xv[8], x2v[8], dv[8];
+      unpack8(*reinterpret_cast<const uint4*>(x + off), xv);
+      unpack8(*reinterpret_cast<const uint4*>(x2 + off), x2v);
+      unpack8(*reinterpret_cast<const uint4*>(dy + off), dv);
+      const uint32_t mb = mbits[r * G.cg + cgi];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dz = ((mb >> j) & 1u) != 0u ? dv[j] : 0.f;
+        q0[j] += dz;
+        q1[j] = fmaf(dz, (xv[j] - mu[j]) * is[j], q1[j]);
+        q2[j] = fmaf(dz, (x2v[j] - mu2[j]) * is2[j], q2[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = q0[j]; red[threadIdx.x][8 + j] = q1[j]; red[threadIdx.x][16 + j] = q2[j]; }
+  __syncthreads();
+  for (int s = G.rpb >> 1; s > 0; s >>= 1) {
+    if (ty < s) {
+#pragma unroll
+      for (int j = 0; j < 24; ++j) red[threadIdx.x][j] += red[threadIdx.x + s * G.tpr][j];
+    }
+    __syncthreads();
+  }
+  if (ty == 0 && c_ok) {
+    float* p = partial + ((int64_t)blockIdx.x * 2) * G.C + cgi * 8;
+    float* p2 = partial2 + ((int64_t)blockIdx.x * 2) * G.C + cgi * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      p[j] = red[threadIdx.x][j]; p[G.C + j] = red[threadIdx.x][8 + j];
+      p2[j] = red[threadIdx.x][j]; p2[G.C + j] = red[threadIdx.x][16 + j];
+    }
+  }
+}
+
+struct FinSet { const float* partial; const float* gamma; const float* invstd; float* dgamma; float* dbeta; float* coef; };
+
+template <int CL>
+__global__ __launch_bounds__(THREADS) void k_bwd_finalize_pair(Geom G, FinSet s0, FinSet s1) {
+  const FinSet& f = blockIdx.y == 0 ? s0 : s1;
+  double a0, a1; int c; bool leader;
+  sum_partials<CL>(G, f.partial, a0, a1, c, leader);
+  if (!leader) return;
+  f.dbeta[c] = (float)a0;
+  f.dgamma[c] = (float)a1;
+  f.coef[c] = f.gamma[c] * f.invstd[c];
+  f.coef[G.C + c] = (float)(a0 / (double)G.M);
+  f.coef[2 * G.C + c] = (float)(a1 / (double)G.M);
+}
+
+// dx = a * (dz - b - xhat * c) and dx2 = a2 * (dz - b2 - xhat2 * c2) in one pass
+__global__ __launch_bounds__(THREADS) void k_bwd_apply_pair(Geom G, const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2,
+                                                             const uint8_t* __restrict__ mbits, const uint16_t* __restrict__ dy,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ mean2, const float* __restrict__ invstd2,
+                                                             const float* __restrict__ coef, const float* __restrict__ coef2,
+                                                             uint16_t* __restrict__ dx, uint16_t* __restrict__ dx2) {
+  extern __shared__ __attribute__((aligned(16))) float prm[];   // [10][C]: mean, invstd, a, b, c of either side
+  for (int i = threadIdx.x; i < G.C; i += THREADS) {
+    prm[i] = mean[i]; prm[G.C + i] = invstd[i];
+    prm[2 * G.C + i] = coef[i]; prm[3 * G.C + i] = coef[G.C + i]; prm[4 * G.C + i] = coef[2 * G.C + i];
+    prm[5 * G.C + i] = mean2[i]; prm[6 * G.C + i] = invstd2[i];
+    prm[7 * G.C + i] = coef2[i]; prm[8 * G.C + i] = coef2[G.C + i]; prm[9 * G.C + i] = coef2[2 * G.C + i];
+  }
+  __syncthreads();
+  const int64_t total = G.M * G.cg;
+  const int64_t stride = (int64_t)gridDim.x * THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += stride) {
+    const int c0 = (int)(i % G.cg) * 8;
+    float xv[8], x2v[8], dv[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + i * 8), xv);
+    unpack8(*reinterpret_cast<const uint4*>(x2 + i * 8), x2v);
+    unpack8(*reinterpret_cast<const uint4*>(dy + i * 8), dv);
+    const uint32_t mb = mbits[i];
+    float o[8], o2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float dz = ((mb >> j) & 1u) != 0u ? dv[j] : 0.f;
+      const float xh = (xv[j] - prm[c0 + j]) * prm[G.C + c0 + j];
+      o[j] = prm[2 * G.C + c0 + j] * (dz - prm[3 * G.C + c0 + j] - xh * prm[4 * G.C + c0 + j]);
+      const float xh2 = (x2v[j] - prm[5 * G.C + c0 + j]) * prm[6 * G.C + c0 + j];
+      o2[j] = prm[7 * G.C + c0 + j] * (dz - prm[8 * G.C + c0 + j] - xh2 * prm[9 * G.C + c0 + j]);
+    }
+    uint4 out;
+    out.x = pack2(o[0], o[1]); out.y = pack2(o[2], o[3]); out.z = pack2(o[4], o[5]); out.w = pack2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(dx + i * 8) = out;
+    out.x = pack2(o2[0], o2[1]); out.y = pack2(o2[2], o2[3]); out.z = pack2(o2[4], o2[5]); out.w = pack2(o2[6], o2[7]);
+    *reinterpret_cast<uint4*>(dx2 + i * 8) = out;
+  }
+}
+
 static Geom make_geom(int64_t m, int c) {
   Geom g;
   g.M = m; g.C = c; g.cg = c / 8;
@@ -421,6 +587,74 @@ int rigl_bn_fwd_statistics(int64_t m, int32_t c, const rigl_bf16* x, const float
                           save_scale, save_shift, stats, stats_parts, workspace, workspace_bytes, as_stream(stream));
   if (rc) return rc;
   RIGL_CHECK_LAUNCH("rigl_bn_fwd_statistics");
+  return RIGL_OK;
+}
+
+int rigl_bn_add_bn_fwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* x2, const float* scale2,
+                       const float* shift2, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, float momentum, float eps, int32_t relu, rigl_bf16* y, float* save_mean,
+                       float* save_invstd, float* save_scale, float* save_shift, const float* stats,
+                       int32_t stats_parts, uint8_t* relu_bits, void* workspace, size_t workspace_bytes,
+                       rigl_stream_t stream) {
+  using namespace rigl;
+  using namespace rigl::kbn;
+  if (m <= 0 || c <= 0 || !x || !x2 || !scale2 || !shift2 || !gamma || !beta || !y || !save_mean || !save_invstd ||
+      !save_scale || !save_shift)
+    return fail(RIGL_EINVAL, "rigl_bn_add_bn_fwd: bad arguments");
+  if (c % 8) return fail(RIGL_EUNSUPPORTED, "rigl_bn_add_bn_fwd: channels %% 8 != 0");
+  if (4 * (size_t)c * 4 > 65536) return fail(RIGL_EUNSUPPORTED, "rigl_bn_add_bn_fwd: too many channels for the LDS parameter cache");
+  if (stats && stats_parts <= 0) return fail(RIGL_EINVAL, "rigl_bn_add_bn_fwd: stats_parts must be positive");
+  hipStream_t st = as_stream(stream);
+  Geom g = make_geom(m, c);
+  int rc = fwd_statistics(g, c, x, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+                          save_scale, save_shift, stats, stats_parts, workspace, workspace_bytes, st);
+  if (rc) return rc;
+  const size_t lds = (size_t)4 * c * 4;
+  dim3 agrid(apply_grid(g));
+  if (relu) hipLaunchKernelGGL(k_fwd_apply_pair<true>, agrid, dim3(THREADS), lds, st, g, x, x2, save_scale, save_shift, scale2, shift2, y, relu_bits);
+  else hipLaunchKernelGGL(k_fwd_apply_pair<false>, agrid, dim3(THREADS), lds, st, g, x, x2, save_scale, save_shift, scale2, shift2, y, nullptr);
+  RIGL_CHECK_LAUNCH("rigl_bn_add_bn_fwd");
+  return RIGL_OK;
+}
+
+size_t rigl_bn_add_bn_bwd_workspace_bytes(int64_t m, int32_t c) { return 2 * rigl_bn_workspace_bytes(m, c); }
+
+int rigl_bn_add_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16* x2, const uint8_t* relu_bits,
+                       const rigl_bf16* dy, const float* gamma, const float* save_mean, const float* save_invstd,
+                       const float* gamma2, const float* save_mean2, const float* save_invstd2, rigl_bf16* dx,
+                       rigl_bf16* dx2, float* dgamma, float* dbeta, float* dgamma2, float* dbeta2, void* workspace,
+                       size_t workspace_bytes, rigl_stream_t stream) {
+  using namespace rigl;
+  using namespace rigl::kbn;
+  if (m <= 0 || c <= 0 || !x || !x2 || !relu_bits || !dy || !gamma || !save_mean || !save_invstd || !gamma2 || !save_mean2 ||
+      !save_invstd2 || !dx || !dx2 || !dgamma || !dbeta || !dgamma2 || !dbeta2)
+    return fail(RIGL_EINVAL, "rigl_bn_add_bn_bwd: bad arguments");
+  if (c % 8) return fail(RIGL_EUNSUPPORTED, "rigl_bn_add_bn_bwd: channels %% 8 != 0");
+  const size_t lds = (size_t)10 * c * 4;
+  if (lds > 160 * 1024 - 1024) return fail(RIGL_EUNSUPPORTED, "rigl_bn_add_bn_bwd: too many channels for the LDS parameter cache");
+  const size_t need = rigl_bn_add_bn_bwd_workspace_bytes(m, c);
+  if (!workspace || workspace_bytes < need) return fail(RIGL_EWORKSPACE, "rigl_bn_add_bn_bwd: workspace %zu < %zu", workspace_bytes, need);
+  static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_apply_pair),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess;
+  if (lds > 65536 && !big_lds) return fail(RIGL_ELAUNCH, "rigl_bn_add_bn_bwd: cannot raise the dynamic LDS limit");
+  hipStream_t st = as_stream(stream);
+  Geom g = make_geom(m, c);
+  const size_t half = rigl_bn_workspace_bytes(m, c);
+  const size_t part_bytes = align_up((size_t)g.parts * 2 * c * 4, 256);
+  char* w0 = static_cast<char*>(workspace);
+  float* partial = reinterpret_cast<float*>(w0);
+  float* coef = reinterpret_cast<float*>(w0 + part_bytes);
+  float* partial2 = reinterpret_cast<float*>(w0 + half);
+  float* coef2 = reinterpret_cast<float*>(w0 + half + part_bytes);
+  dim3 rgrid((unsigned)g.parts, (unsigned)((g.cg + g.tpr - 1) / g.tpr));
+  hipLaunchKernelGGL(k_reduce_pair, rgrid, dim3(THREADS), 0, st, g, x, x2, relu_bits, dy, save_mean, save_invstd, save_mean2,
+                     save_invstd2, partial, partial2);
+  const FinSet f0 = {partial, gamma, save_invstd, dgamma, dbeta, coef};
+  const FinSet f1 = {partial2, gamma2, save_invstd2, dgamma2, dbeta2, coef2};
+  hipLaunchKernelGGL(k_bwd_finalize_pair<16>, dim3((unsigned)((c + 15) / 16), 2), dim3(THREADS), 0, st, g, f0, f1);
+  hipLaunchKernelGGL(k_bwd_apply_pair, dim3(apply_grid(g)), dim3(THREADS), lds, st, g, x, x2, relu_bits, dy, save_mean, save_invstd,
+                     save_mean2, save_invstd2, coef, coef2, dx, dx2);
+  RIGL_CHECK_LAUNCH("rigl_bn_add_bn_bwd");
   return RIGL_OK;
 }
 

@@ -668,10 +668,9 @@ def maxpool_bwd(d, dy, arg):
   return dx
 
 
-def bn_relu_maxpool_fwd(d, x, gamma, beta, running_mean, running_var, momentum, eps, partials=None):
-  """maxpool(relu(batch_norm(x))) for the pooling geometry ``d`` without the activated tensor
-  (rigl_bn_fwd_statistics + rigl_bn_relu_maxpool_fwd).  Returns (y, argmax, saved) -- saved = fp32 [4, C]
-  (mean, invstd, scale, shift) as bn_fwd returns it."""
+def bn_statistics(x, gamma, beta, running_mean, running_var, momentum, eps, partials=None):
+  """The statistics half of bn_fwd (no apply pass): returns saved = fp32 [4, C] (mean, invstd, scale, shift) and updates
+  the moving averages (rigl_bn_fwd_statistics)."""
   _req(x, torch.bfloat16, 'x')
   c = x.shape[-1]
   m = x.numel() // c
@@ -686,6 +685,57 @@ def bn_relu_maxpool_fwd(d, x, gamma, beta, running_mean, running_var, momentum, 
       m, c, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
       _ptr(saved[0]), _ptr(saved[1]), _ptr(saved[2]), _ptr(saved[3]), _ptr(partials),
       partials.shape[0] if partials is not None else 0, _ptr(ws), ws.numel() if ws is not None else 0, _stream()))
+  return saved
+
+
+def bn_add_bn_fwd(x, x2, saved2, gamma, beta, running_mean, running_var, momentum, eps, relu, partials=None):
+  """relu?(bn(x) + bn2(x2)) in one apply pass; ``saved2`` = bn_statistics(x2, ...).  Returns (y, saved, relu_bits|None)."""
+  _req(x, torch.bfloat16, 'x')
+  _req(x2, torch.bfloat16, 'x2')
+  if x2.shape != x.shape:
+    raise ValueError('x2 must have the shape of x')
+  c = x.shape[-1]
+  m = x.numel() // c
+  lib = _lib.load()
+  y = torch.empty_like(x)
+  saved = torch.empty((4, c), dtype=torch.float32, device=x.device)
+  bits = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device) if relu else None
+  if partials is not None:
+    _req(partials, torch.float32, 'partials')
+    ws = None
+  else:
+    ws = workspace(lib.rigl_bn_workspace_bytes(m, c), x.device)
+  check(lib.rigl_bn_add_bn_fwd(
+      m, c, _ptr(x), _ptr(x2), _ptr(saved2[2]), _ptr(saved2[3]), _ptr(gamma), _ptr(beta), _ptr(running_mean),
+      _ptr(running_var), float(momentum), float(eps), int(bool(relu)), _ptr(y), _ptr(saved[0]), _ptr(saved[1]),
+      _ptr(saved[2]), _ptr(saved[3]), _ptr(partials), partials.shape[0] if partials is not None else 0, _ptr(bits),
+      _ptr(ws), ws.numel() if ws is not None else 0, _stream()))
+  return y, saved, bits
+
+
+def bn_add_bn_bwd(x, x2, relu_bits, dy, gamma, saved, gamma2, saved2, dgamma, dbeta, dgamma2, dbeta2):
+  """Gradients of relu(bn(x) + bn2(x2)) w.r.t. x and x2 (returns (dx, dx2)); the four parameter gradients are overwritten."""
+  _req(x, torch.bfloat16, 'x')
+  _req(x2, torch.bfloat16, 'x2')
+  _req(dy, torch.bfloat16, 'dy')
+  _req(relu_bits, torch.uint8, 'relu_bits')
+  c = x.shape[-1]
+  m = x.numel() // c
+  lib = _lib.load()
+  ws = workspace(lib.rigl_bn_add_bn_bwd_workspace_bytes(m, c), x.device)
+  dx, dx2 = torch.empty_like(x), torch.empty_like(x2)
+  check(lib.rigl_bn_add_bn_bwd(m, c, _ptr(x), _ptr(x2), _ptr(relu_bits), _ptr(dy), _ptr(gamma), _ptr(saved[0]), _ptr(saved[1]),
+                               _ptr(gamma2), _ptr(saved2[0]), _ptr(saved2[1]), _ptr(dx), _ptr(dx2), _ptr(dgamma), _ptr(dbeta),
+                               _ptr(dgamma2), _ptr(dbeta2), _ptr(ws), ws.numel(), _stream()))
+  return dx, dx2
+
+
+def bn_relu_maxpool_fwd(d, x, gamma, beta, running_mean, running_var, momentum, eps, partials=None):
+  """maxpool(relu(batch_norm(x))) for the pooling geometry ``d`` without the activated tensor
+  (rigl_bn_fwd_statistics + rigl_bn_relu_maxpool_fwd).  Returns (y, argmax, saved) -- saved = fp32 [4, C]
+  (mean, invstd, scale, shift) as bn_fwd returns it."""
+  saved = bn_statistics(x, gamma, beta, running_mean, running_var, momentum, eps, partials=partials)
+  lib = _lib.load()
   y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16, device=x.device)
   arg = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.uint8, device=x.device)
   check(lib.rigl_bn_relu_maxpool_fwd(C.byref(d), _ptr(x), _ptr(saved[2]), _ptr(saved[3]), _ptr(y), _ptr(arg), _stream()))

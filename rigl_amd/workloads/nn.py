@@ -91,6 +91,50 @@ class _FusedBNFn(torch.autograd.Function):
     return dx, dres, None, None, None, None
 
 
+class _BnAddBnFn(torch.autograd.Function):
+  """relu(bn(x) + bn2(x2)) as one node (rigl_bn_add_bn_fwd / _bwd): the normalised shortcut and the relu-masked
+  gradient between the two batch norms are never written.  Bit-identical to bn(x, residual=bn2(x2))."""
+
+  @staticmethod
+  def forward(ctx, x, x2, bn, bn2, partials, partials2):
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    x, x2 = x.contiguous(), x2.contiguous()
+    saved2 = ops.bn_statistics(x2, bn2.gamma.data, bn2.beta.data, bn2.moving_mean, bn2.moving_variance,
+                               1.0 - bn2.decay, bn2.eps, partials=partials2)
+    y, saved, bits = ops.bn_add_bn_fwd(x, x2, saved2, bn.gamma.data, bn.beta.data, bn.moving_mean, bn.moving_variance,
+                                       1.0 - bn.decay, bn.eps, True, partials=partials)
+    ctx.bn, ctx.bn2 = bn, bn2
+    ctx.save_for_backward(x, x2, saved, saved2, bits)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    x, x2, saved, saved2, bits = ctx.saved_tensors
+    bn, bn2 = ctx.bn, ctx.bn2
+    dx, dx2 = ops.bn_add_bn_bwd(x, x2, bits, dy.contiguous(), bn.gamma.data, saved, bn2.gamma.data, saved2,
+                                bn.gamma.grad, bn.beta.grad, bn2.gamma.grad, bn2.beta.grad)
+    return dx, dx2, None, None, None, None
+
+
+_BN_PAIR_FUSED = os.environ.get('RIGL_BN_PAIR', '1') != '0'
+
+
+def bn_add_bn_relu(bn, x, bn2, x2, is_training=True):
+  """relu(bn(x) + bn2(x2)): a residual block whose shortcut is projection conv + batch norm
+  (resnet_model.py:456-501)."""
+  c = x.shape[-1]
+  if (_BN_PAIR_FUSED and bn.fused and bn2.fused and is_training and x.is_cuda and x.dtype == torch.bfloat16
+      and x2.dtype == torch.bfloat16 and x2.shape == x.shape and c % 8 == 0 and c <= 3968):
+    px, px2 = getattr(x, 'bn_partials', None), getattr(x2, 'bn_partials', None)
+    if not x.requires_grad:
+      x = x.detach().requires_grad_(True)
+    if not x2.requires_grad:
+      x2 = x2.detach().requires_grad_(True)
+    return _BnAddBnFn.apply(x, x2, bn, bn2, px, px2)
+  return bn(x, is_training, relu=True, residual=bn2(x2, is_training, relu=False))
+
+
 class BatchNorm:
   """tf.layers.batch_normalization(momentum=0.9, eps=1e-5, fused) over the
   channel axis (resnet_model.py:41-82), optionally fused with the residual add

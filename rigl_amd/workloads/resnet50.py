@@ -74,12 +74,15 @@ class _Bottleneck:
     # gradient it accumulates in its own dgrad epilogue (no separate AddN pass).
     if self.proj is not None:
       p, x = self.proj.fork(x)
-      shortcut = self.proj_bn(p, is_training, relu=False)
       y = self.c1(x)
     else:
       y, shortcut = self.c1.fork(x)
     y = self.bn1(y, is_training, relu=True)
     y = self.bn2(self.c2(y), is_training, relu=True)
+    if self.proj is not None:
+      # relu(bn3(conv3) + bn_proj(projection)) in one piece: neither the normalised shortcut nor the masked gradient
+      # between the two batch norms is written
+      return gnn.bn_add_bn_relu(self.bn3, self.c3(y), self.proj_bn, p, is_training)
     return self.bn3(self.c3(y), is_training, relu=True, residual=shortcut)   # relu(bn3 + shortcut)
 
 

@@ -265,3 +265,72 @@ def test_bn_relu_maxpool_autograd_node_equals_the_two_nodes():
   assert (dg1 - dg0).abs().max() <= 1e-5 * dg0.abs().max() + 1e-6
   assert (db1 - db0).abs().max() <= 1e-5 * db0.abs().max() + 1e-6
   assert ((dx1 - dx0).abs() <= 2.0**-7 * dx0.abs() + 1e-6 * dx0.abs().max()).all()
+
+
+@pytest.mark.parametrize('shape', [(4, 14, 14, 64), (2, 7, 7, 2048), (3, 9, 5, 16), (2, 28, 28, 256), (33, 3, 3, 40),
+                                   (8, 56, 56, 256)])
+def test_two_batch_norms_meeting_in_one_add(shape):
+  """relu(bn(x) + bn2(x2)) in one piece (rigl_bn_add_bn_fwd / _bwd, the projection-shortcut blocks) against the calls
+  it replaces -- bn_fwd(x2) -> bn_fwd(x, residual) and bn_bwd(want_dres) -> bn_bwd(dres): same arithmetic in the same
+  order, so output, ReLU bits, statistics, moving averages, both input gradients and all four parameter gradients are
+  compared bit for bit."""
+  from rigl_amd import ops
+  gen = torch.Generator(device=DEV).manual_seed(sum(shape) + 7)
+  c = shape[-1]
+  x = (torch.randn(shape, generator=gen, device=DEV) * 1.7 + 0.3).to(torch.bfloat16)
+  x2 = (torch.randn(shape, generator=gen, device=DEV) * 0.8 - 0.1).to(torch.bfloat16)
+  dy = torch.randn(shape, generator=gen, device=DEV).to(torch.bfloat16)
+  gamma, gamma2 = torch.rand(c, generator=gen, device=DEV) + 0.5, torch.rand(c, generator=gen, device=DEV) + 0.5
+  beta, beta2 = torch.randn(c, generator=gen, device=DEV) * 0.3, torch.randn(c, generator=gen, device=DEV) * 0.3
+  mk = lambda: (torch.zeros(c, device=DEV), torch.ones(c, device=DEV))
+  # separate calls
+  (rm, rv), (rm2, rv2) = mk(), mk()
+  sc, s2 = ops.bn_fwd(x2, gamma2, beta2, rm2, rv2, 0.1, 1e-5, False)
+  y0, s1, bits0 = ops.bn_fwd(x, gamma, beta, rm, rv, 0.1, 1e-5, True, sc, want_relu_bits=True)
+  g = [torch.empty(c, device=DEV) for _ in range(4)]
+  dx0, dres = ops.bn_bwd(x, None, dy, gamma, s1, True, g[0], g[1], want_dres=True, relu_bits=bits0)
+  dx20, _ = ops.bn_bwd(x2, None, dres, gamma2, s2, False, g[2], g[3])
+  # one piece
+  (qm, qv), (qm2, qv2) = mk(), mk()
+  t2 = ops.bn_statistics(x2, gamma2, beta2, qm2, qv2, 0.1, 1e-5)
+  y1, t1, bits1 = ops.bn_add_bn_fwd(x, x2, t2, gamma, beta, qm, qv, 0.1, 1e-5, True)
+  h = [torch.empty(c, device=DEV) for _ in range(4)]
+  dx1, dx21 = ops.bn_add_bn_bwd(x, x2, bits1, dy, gamma, t1, gamma2, t2, h[0], h[1], h[2], h[3])
+  for a, b in ((s1, t1), (s2, t2), (rm, qm), (rv, qv), (rm2, qm2), (rv2, qv2), (bits0, bits1)):
+    assert torch.equal(a, b)
+  assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+  assert torch.equal(dx0.view(torch.int16), dx1.view(torch.int16))
+  assert torch.equal(dx20.view(torch.int16), dx21.view(torch.int16))
+  for a, b in zip(g, h):
+    assert torch.equal(a, b)
+
+
+def test_bottleneck_with_projection_shortcut_fused_equals_unfused():
+  """A ResNet-50 bottleneck with a projection shortcut through autograd: the paired batch-norm node vs the two nodes."""
+  from rigl_amd import variables as V
+  from rigl_amd.workloads import nn as gnn, resnet50 as R, shapes as WS
+  res = []
+  for fused in (True, False):
+    gnn._BN_PAIR_FUSED = fused
+    from rigl_amd import pruning_layers as PL
+    PL.set_init_seed(0)
+    g = V.Graph(DEV)
+    convs = [c for grp, n, cs in WS.resnet50_blocks() for c in cs if grp == 2 and n == 0]
+    blk = R._Bottleneck(g, convs, 'threshold', 1e-4, 'blk')
+    g.finalize()
+    g.refresh_shadows()
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    for bn in (blk.bn1, blk.bn2, blk.bn3, blk.proj_bn):
+      bn.gamma.data.copy_(torch.rand(bn.channels, generator=gen, device=DEV) + 0.5)
+    x = torch.randn((4, 56, 56, 256), generator=gen, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    y = blk(x, True)
+    dy = torch.randn(y.shape, generator=gen, device=DEV).to(torch.bfloat16)
+    y.backward(dy)
+    from rigl_amd import ops
+    ops.flush_pending_wgrad()
+    res.append((y.detach().clone(), x.grad.clone(), g.G.clone()))
+  gnn._BN_PAIR_FUSED = True
+  (y1, dx1, G1), (y0, dx0, G0) = res
+  assert torch.equal(y1.view(torch.int16), y0.view(torch.int16))
+  assert torch.equal(dx1.view(torch.int16), dx0.view(torch.int16))
+  assert torch.equal(G1, G0)
