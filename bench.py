@@ -107,7 +107,18 @@ def lib_sha16():
     return None
 
 
+def _claim_stdout():
+  """The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio on rank 0 (buffered, so it
+  lands AFTER anything Python printed when stdout is a pipe or a file), and libraries may print more: everything written
+  to file descriptor 1 from here on goes to stderr, and the returned descriptor is the real stdout for the JSON line."""
+  sys.stdout.flush()
+  real = os.dup(1)
+  os.dup2(2, 1)
+  return real
+
+
 def main():
+  real_stdout = _claim_stdout()
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=100)
@@ -392,7 +403,7 @@ def main():
       except Exception as e:  # pylint: disable=broad-except
         out['cpu_baseline'] = {'value': None, 'unit': 'images/sec', 'cores': os.cpu_count(), 'kind': 'port',
                                'sample': 'failed: %r' % (e,)}
-    print(json.dumps(out))
+    os.write(real_stdout, (json.dumps(out) + '\n').encode())
   if sync is not None:
     dist.barrier()
     dist.destroy_process_group()

@@ -38,6 +38,7 @@ def test_bench_contract_single_gpu():
   assert out.returncode == 0, out.stderr[-2000:]
   lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
   assert len(lines) == 1                                   # exactly one JSON line
+  assert out.stdout.strip().splitlines() == lines          # ... and nothing else on stdout
   d = json.loads(lines[0])
   for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
             'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
@@ -93,6 +94,8 @@ def test_rccl_code_path_executes_with_one_rank():
          '--no-cpu-baseline']
   out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
   assert out.returncode == 0, out.stderr[-3000:]
+  # RCCL prints a version banner through C stdio; bench.py keeps stdout for the JSON line alone (the driver parses it)
+  assert len(out.stdout.strip().splitlines()) == 1, out.stdout[-600:]
   d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
   assert d['config']['gradient_exchange'] == 'on (nccl, world 1)'
   assert d['config']['masks_identical_across_ranks'] is True
