@@ -37,6 +37,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# dmabuf IPC only on this pool (RCCL's peer-memory exchange needs it); read when the HSA runtime starts, i.e. before the
+# first HIP call, so it is set before torch is imported
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
