@@ -192,3 +192,28 @@ def test_workload_tables_match_reference_sizes():
   assert list(WS.wide_resnet_masks(22, 1).items()) == list(LS.wide_resnet(22, 1).items())
   assert sum(int(np.prod(s)) for s in WS.wide_resnet_masks(22, 1).values()) == 270464
   assert sum(int(np.prod(s)) for s in WS.mobilenet_v1_masks().values()) == 4163584
+
+
+def test_glue_compositions_fall_back_to_the_plain_ops_off_the_gpu():
+  """nn.bn_add_bn_relu / nn.bn_relu_max_pool_3x3_s2_same are single nodes on the GPU (bn.hip / pool.hip); anywhere else --
+  fp32 tensors on the host, evaluation mode -- they must be exactly the composition they replace
+  (resnet_model.py:456-501, :631-644)."""
+  import torch
+  from rigl_amd import variables as V
+  from rigl_amd.workloads import nn as gnn
+  g = V.Graph('cpu')
+  bn, bn2 = gnn.BatchNorm(g, 'a', 16), gnn.BatchNorm(g, 'b', 16)
+  g.finalize()
+  gen = torch.Generator().manual_seed(0)
+  for b in (bn, bn2):
+    b.gamma.data.copy_(torch.rand(16, generator=gen) + 0.5)
+    b.beta.data.copy_(torch.randn(16, generator=gen) * 0.1)
+  x, x2 = torch.randn(2, 6, 6, 16, generator=gen), torch.randn(2, 6, 6, 16, generator=gen)
+  for training in (True, False):
+    # (training-mode outputs use batch statistics, evaluation mode does not touch the moving ones: calling twice is fair)
+    got = gnn.bn_add_bn_relu(bn, x, bn2, x2, training)
+    want = bn(x, training, relu=True, residual=bn2(x2, training, relu=False))
+    assert torch.equal(got, want)
+    got = gnn.bn_relu_max_pool_3x3_s2_same(bn, x, training)
+    want = gnn.max_pool_3x3_s2_same(bn(x, training, relu=True))
+    assert got.shape == (2, 3, 3, 16) and torch.equal(got, want)
