@@ -242,7 +242,6 @@ def test_bn_relu_maxpool_in_one_piece(shape):
 
 def test_bn_relu_maxpool_autograd_node_equals_the_two_nodes():
   """nn.bn_relu_max_pool_3x3_s2_same through autograd (fused node vs BatchNorm + max pool nodes)."""
-  import importlib
   from rigl_amd import variables as V
   from rigl_amd.workloads import nn as gnn
   outs = []
