@@ -28,7 +28,9 @@ DEBUG = os.environ.get('RIGL_DEBUG', '0') == '1'     # check_masks_identical aft
 
 class GradSync:
 
-  def __init__(self, graph, bucket_bytes=32 << 20, group=None, enabled=None):
+  def __init__(self, graph, bucket_bytes=None, group=None, enabled=None):
+    if bucket_bytes is None:
+      bucket_bytes = int(float(os.environ.get('RIGL_DP_BUCKET_MB', '32')) * (1 << 20))
     self.graph = graph
     self.group = group
     self.world = dist.get_world_size(group) if dist.is_initialized() else 1
