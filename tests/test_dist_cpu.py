@@ -148,3 +148,17 @@ def test_grad_sync_single_process_is_noop():
   s.notify_layer_grad_ready(v)
   s.all_reduce(g)
   assert torch.all(v.grad == 2.0)
+
+
+def test_bucket_size_default_and_knob(monkeypatch):
+  """GradSync's bucket size: 32 MB unless RIGL_DP_BUCKET_MB says otherwise (an explicit argument wins)."""
+  from rigl_amd import variables as V
+  from rigl_amd.dist import GradSync
+  g = V.Graph('cpu')
+  g.add_variable('l/weights', (3, 3, 8, 8), V.KIND_MASKED)
+  g.finalize()
+  monkeypatch.delenv('RIGL_DP_BUCKET_MB', raising=False)
+  assert GradSync(g, enabled=False).bucket_elems == (32 << 20) // 4
+  monkeypatch.setenv('RIGL_DP_BUCKET_MB', '8')
+  assert GradSync(g, enabled=False).bucket_elems == (8 << 20) // 4
+  assert GradSync(g, bucket_bytes=4000, enabled=False).bucket_elems == 1000
