@@ -541,6 +541,25 @@ int rigl_softmax_xent(int32_t rows, int32_t classes, const rigl_bf16* logits,
 int rigl_prof_enable(int32_t on);
 int rigl_prof_collect(double* ms_per_kind /*[8]*/, int64_t* launches /*[8]*/);
 
+/* Measurement aid (the MFMA peak "re-measured on the box"):
+ * enqueues blocks x 4 waves, each issuing iters x 8 independent
+ * v_mfma_f32_32x32x16_bf16 (32768 FLOP per wave-instruction) on register
+ * operands; the caller brackets it with events.  `sink`: blocks*256 floats.  */
+int rigl_probe_mfma_bf16(int32_t blocks, int32_t iters, float* sink, rigl_stream_t stream);
+
+/* Development knobs: the run-time twin of the RIGL_* environment variables, so
+ * that one process can A/B kernel selections (tools/bench_kernels.py,
+ * tests/k1_check.py).  Process-wide state, NOT part of the drop-in surface: a
+ * caller that never sets a knob gets the built-in selection rules.  Keys:
+ *   "pp_fwd" / "pp_dgrad"   K1 tile of the 8-wave ping-pong body for the
+ *                           forward / dgrad GEMM: -1 built-in rule (default),
+ *                           0 never, 1 256x256, 2 128x256, 3 256x128, 4 512x128
+ *                           (ignored where the shape does not admit the tile).
+ * No reference counterpart (the reference selects cuDNN/TPU algorithms inside
+ * TensorFlow: rigl/imagenet_resnet/pruning_layers.py:139-157).              */
+int rigl_tune_set(const char* key, int32_t value);
+int32_t rigl_tune_get(const char* key, int32_t dflt);
+
 #ifdef __cplusplus
 }
 #endif

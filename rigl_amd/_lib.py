@@ -147,6 +147,9 @@ SIGNATURES = {
     'rigl_softmax_xent': (C.c_int, [_I32, _I32, _P, _P, _F, _F, _P, _P, _P]),
     'rigl_prof_enable': (C.c_int, [_I32]),
     'rigl_prof_collect': (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64)]),
+    'rigl_probe_mfma_bf16': (C.c_int, [_I32, _I32, _P, _P]),
+    'rigl_tune_set': (C.c_int, [C.c_char_p, _I32]),
+    'rigl_tune_get': (_I32, [C.c_char_p, _I32]),
 }
 
 _lib = None

@@ -13,6 +13,10 @@ namespace rigl {
 void set_error(const char* fmt, ...);
 int fail(int code, const char* fmt, ...);
 
+// Process-wide development knobs (rigl_tune_set): the run-time twin of the RIGL_* environment variables, for
+// A/B runs inside one process.  Unknown keys read as the caller's default.
+int tune_get(const char* key, int dflt);
+
 inline hipStream_t as_stream(rigl_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Checks the last launch.  hipGetLastError is cheap and does not synchronise.

@@ -1334,6 +1334,30 @@ static TinyGeom tiny_geom(const RiglConvDesc* d) {
   return g;
 }
 
+// MFMA issue-rate probe ("re-measured on the box before use"): every wave of a 256-thread workgroup issues
+// `iters` x 8 independent v_mfma_f32_32x32x16_bf16 back to back on register operands -- no memory traffic -- so the
+// rate it reaches is the clock-and-power-limited dense bf16 peak of THIS box (bench.py prints it beside roofline.peak).
+__global__ __launch_bounds__(THREADS) void k_mfma_probe(float* __restrict__ sink, int iters, float seed) {
+  bf16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + 0.001f * (float)((threadIdx.x + i) & 63)); b[i] = (__bf16)(1.0f - 0.002f * (float)((threadIdx.x * 3 + i) & 31)); }
+  f32x16 acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[k], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += acc[k][e];
+  if (s == 12345.678f) sink[blockIdx.x * THREADS + threadIdx.x] = s;   // keeps the chain live, (almost) never stores
+}
+
 // ------------------------------------------------------------------ dispatch
 static int conv_dma_stages() {
   static const int stages = [] { const char* e = getenv("RIGL_CONV_STAGES"); return (e && atoi(e) == 4) ? 4 : 3; }();
@@ -1373,9 +1397,7 @@ static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, int bk, b
 struct IgemmPlan { bool wide_n, dma, w4, cls, big; int bk; unsigned grid; };
 
 static int num_cus();
-#include "conv196.hpp"
-#include "conv3x3.hpp"
-#include "wgrad9.hpp"
+#include "convpp.hpp"
 // The 512-thread kernel needs 72 KB of dynamic LDS: opt in once; if the runtime refuses, the plan never picks it.
 template <int MODE>
 static bool big_tile_ready() {
@@ -1577,13 +1599,7 @@ size_t rigl_conv2d_workspace_bytes(const RiglConvDesc* d, int32_t which) {
   }
   if (which == 2) {
     WgradPlan p = plan_wgrad((int)M, d->cin, d->cout, d->kh * d->kw);
-    size_t need = p.splits > 1 ? align_up((size_t)p.splits * p.slab * 4, 256) : 0;
-    const W9Plan p9 = plan_w9(d);          // the all-taps 3x3 kernel has its own split plan; the buffer serves either
-    if (p9.use && p9.splits > 1) {
-      const size_t n9 = align_up((size_t)p9.splits * p9.slab * 4, 256);
-      if (n9 > need) need = n9;
-    }
-    return need;
+    return p.splits > 1 ? align_up((size_t)p.splits * p.slab * 4, 256) : 0;
   }
   return 0;
 }
@@ -1592,13 +1608,6 @@ int32_t rigl_conv2d_stats_parts(const RiglConvDesc* d) {
   if (!d || d->cout <= 0 || (d->cout % 8)) return 0;
   const int64_t M = (int64_t)d->n * d->ho * d->wo;
   using namespace rigl::k1;
-  if (!tiny_cin(d) && !small_cin(d)) {
-    const C3Plan p3 = plan_c3(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo, d->n, d->cout, d->cin);
-    if (p3.use) return (int32_t)p3.tiles_m;   // 3x3 slab forward: one partial per tile of whole image rows
-  }
-  if (!tiny_cin(d) && !small_cin(d) &&
-      plan_t196(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo, M, d->cout, d->cin).use)
-    return (int32_t)(M / T196_BMV);      // tile196 forward: one partial per 196-row tile
   return (int32_t)((M + 127) / 128);     // one partial per 128-row output tile
 }
 
@@ -1645,33 +1654,16 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, cons
     a.sh = a.sw = 1; a.ph = a.pw = 0; a.b_row_stride = Kp; a.b_tap_stride = 0;
     a.a_bytes = (uint32_t)((size_t)a.M * Kp * 2); a.b_bytes = (uint32_t)((size_t)d->cout * Kp * 2);
   } else {
-    const C3Plan p3 = plan_c3(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo, d->n, d->cout, d->cin);
-    if (p3.use) {
-      C3Args t = {};
-      t.A = x; t.B = w_ohwi; t.C = y; t.STATS = stats; t.M = a.M; t.N = d->cout; t.Cred = d->cin; t.H = d->h; t.W = d->w; t.nimg = d->n;
-      t.b_row_stride = 9 * d->cin; t.b_tap_stride = d->cin; t.ldc = d->cout;
-      t.a_bytes = (uint32_t)((size_t)a.M * d->cin * 2); t.b_bytes = (uint32_t)((size_t)9 * d->cin * d->cout * 2);
-      if (!launch_c3<0>(p3, t, st)) return fail(RIGL_ELAUNCH, "rigl_masked_conv2d_fwd: 3x3 slab kernel could not get its LDS");
-      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
-      return RIGL_OK;
-    }
-    const T196Plan tp = plan_t196(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo,
-                                  a.M, d->cout, d->cin);
-    if (tp.use) {
-      T196Args t = {};
-      t.A = x; t.B = w_ohwi; t.C = y; t.STATS = stats; t.M = a.M; t.N = d->cout; t.Cred = d->cin; t.H = d->h; t.W = d->w;
-      t.b_row_stride = d->kh * d->kw * d->cin; t.b_tap_stride = d->cin; t.ldc = d->cout;
-      t.a_bytes = (uint32_t)((size_t)a.M * d->cin * 2);
-      t.b_bytes = (uint32_t)((size_t)d->kh * d->kw * d->cin * d->cout * 2);
-      if (!launch_t196<0>(tp, t, st)) return fail(RIGL_ELAUNCH, "rigl_masked_conv2d_fwd: tile196 kernel could not get its LDS");
-      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
-      return RIGL_OK;
-    }
     a.A = x; a.B = w_ohwi; a.Cred = d->cin; a.a_pix_stride = d->cin; a.KH = d->kh; a.KW = d->kw; a.RH = d->ho; a.RW = d->wo;
     a.GH = d->h; a.GW = d->w; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
     a.b_row_stride = d->kh * d->kw * d->cin; a.b_tap_stride = d->cin;
     a.a_bytes = (uint32_t)((size_t)d->n * d->h * d->w * d->cin * 2);
     a.b_bytes = (uint32_t)((size_t)d->kh * d->kw * d->cin * d->cout * 2);
+    const PPPlan pp = plan_pp<0>(a);           // long reductions: the 8-wave ping-pong body
+    if (pp.variant && launch_pp<0>(pp, a, st)) {
+      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
+      return RIGL_OK;
+    }
   }
   launch_igemm<0, false>(a, st);
   RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
@@ -1703,11 +1695,8 @@ int32_t rigl_conv2d_dgrad_stats_parts(const RiglConvDesc* d) {
   using namespace rigl::k1;
   if (!d || check_desc(d, "rigl_conv2d_dgrad_stats_parts")) return 0;
   if ((d->cin % 8) || (d->cout % 8)) return 0;
-  if (plan_c3(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo, d->n, d->cin, d->cout, true).use ||
-      plan_t196(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo,
-                (int64_t)d->n * d->h * d->w, d->cin, d->cout, true).use)
-    return 0;
   IgemmArgs a = dgrad_args(d, nullptr, nullptr, nullptr, nullptr);
+  if (plan_pp<1>(a).variant) return 0;        // the ping-pong dgrad has no reduction epilogue
   const IgemmPlan pl = plan_igemm<1>(a);
   return (int32_t)(pl.grid / (unsigned)a.tiles_n);
 }
@@ -1744,31 +1733,14 @@ static int dgrad_impl(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf1
   if ((d->cin % 8) || (d->cout % 8)) return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_dgrad: cin/cout %% 8 != 0 (use the reference kernel)");
   hipStream_t st = as_stream(stream);
   ProfFamily prof(PROF_CONV_DGRAD);
-  const C3Plan p3 = plan_c3(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo, d->n, d->cin, d->cout, true);
-  if (p3.use) {
-    C3Args t = {};
-    t.A = dy; t.B = w_hwio; t.C = dx; t.ADD = addend; t.M = d->n * d->h * d->w; t.N = d->cin; t.Cred = d->cout;
-    t.H = d->h; t.W = d->w; t.nimg = d->n; t.b_row_stride = d->cout; t.b_tap_stride = d->cin * d->cout; t.ldc = d->cin;
-    t.a_bytes = (uint32_t)((size_t)t.M * d->cout * 2); t.b_bytes = (uint32_t)((size_t)9 * d->cin * d->cout * 2);
-    if (!launch_c3<1>(p3, t, st)) return fail(RIGL_ELAUNCH, "rigl_masked_conv2d_dgrad: 3x3 slab kernel could not get its LDS");
-    RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
-    return RIGL_OK;
-  }
-  const T196Plan tp = plan_t196(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo,
-                                (int64_t)d->n * d->h * d->w, d->cin, d->cout, true);
-  if (tp.use) {
-    T196Args t = {};
-    t.A = dy; t.B = w_hwio; t.C = dx; t.ADD = addend; t.M = d->n * d->h * d->w; t.N = d->cin; t.Cred = d->cout;
-    t.H = d->h; t.W = d->w; t.b_row_stride = d->cout; t.b_tap_stride = d->cin * d->cout; t.ldc = d->cin;
-    t.a_bytes = (uint32_t)((size_t)t.M * d->cout * 2);
-    t.b_bytes = (uint32_t)((size_t)d->kh * d->kw * d->cin * d->cout * 2);
-    if (!launch_t196<1>(tp, t, st)) return fail(RIGL_ELAUNCH, "rigl_masked_conv2d_dgrad: tile196 kernel could not get its LDS");
-    RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
-    return RIGL_OK;
-  }
   IgemmArgs a = dgrad_args(d, dy, w_hwio, addend, dx);
   rc = attach_bn(a, d, bn);
   if (rc) return rc;
+  const PPPlan pp = plan_pp<1>(a);
+  if (pp.variant && launch_pp<1>(pp, a, st)) {
+    RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
+    return RIGL_OK;
+  }
   launch_igemm<1, false>(a, st);
   RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
   return RIGL_OK;
@@ -1791,26 +1763,6 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   const size_t need = rigl_conv2d_workspace_bytes(d, 2);
   if (need && (!workspace || workspace_bytes < need)) return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
   ProfFamily prof(PROF_CONV_WGRAD);
-  {
-    const W9Plan p9 = plan_w9(d);
-    if (p9.use && !tiny_cin(d) && !small_cin(d)) {
-      W9Args w = {};
-      w.X = x; w.DY = dy; w.M = d->n * d->h * d->w; w.Cin = d->cin; w.Cout = d->cout; w.H = d->h; w.W = d->w;
-      w.tiles_ci = p9.tiles_ci; w.tiles_co = p9.tiles_co; w.splits = p9.splits; w.kt_per_split = p9.kt_per_split;
-      w.hb = p9.hb; w.slab_elems = p9.slab;
-      w.x_bytes = (uint32_t)((size_t)w.M * d->cin * 2); w.dy_bytes = (uint32_t)((size_t)w.M * d->cout * 2);
-      w.fd_w = make_fastdiv(d->w); w.fd_h = make_fastdiv(d->h);
-      w.OUT = p9.splits > 1 ? static_cast<float*>(workspace) : dw;
-      const dim3 grid9((unsigned)((int64_t)p9.tiles_ci * p9.tiles_co * p9.splits));
-      RIGL_K_LAUNCH(k_wgrad9, grid9, dim3(THREADS), 0, st, w);
-      if (p9.splits > 1) {
-        ReduceArgs ra = {static_cast<const float*>(workspace), dw, p9.slab, p9.slab, p9.splits};
-        launch_wgrad_reduce(ra, st);
-      }
-      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_wgrad");
-      return RIGL_OK;
-    }
-  }
   WgradArgs a = {};
   a.DY = dy; a.M = d->n * d->ho * d->wo; a.Cout = d->cout;
   a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
@@ -1931,16 +1883,15 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
   const bool have_flush = flush && flush->splits > 0;
   if (have_flush && (!flush->slabs || !flush->dw)) return fail(RIGL_EINVAL, "rigl_masked_conv2d_bwd: NULL buffer in the pending reduce");
   hipStream_t st = as_stream(stream);
-  // RIGL_T196_BWD=1: layers whose dgrad has a tile196 plan run wgrad and that dgrad as two launches instead of sharing one
   // A layer's dX must come from the same kernel whichever entry point computes it (rigl_masked_conv2d_dgrad or this
-  // one): the 3x3 slab / tile196 kernels accumulate in another order than the igemm body of the shared launch, so layers
-  // that have such a dgrad plan run wgrad and dgrad as two launches.
-  const bool dgrad_196 = dx && (d->cin % 8) == 0 && (d->cout % 8) == 0 &&
-      (plan_c3(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo, d->n, d->cin, d->cout, true).use ||
-       plan_t196(d->kh, d->kw, d->stride_h, d->stride_w, d->pad_top, d->pad_left, d->h, d->w, d->ho, d->wo,
-                 (int64_t)d->n * d->h * d->w, d->cin, d->cout, true).use);
-  const bool wgrad_9 = !tiny_cin(d) && !small_cin(d) && plan_w9(d).use;      // the all-taps 3x3 weight gradient is its own launch
-  if (fuse && !dgrad_196 && !wgrad_9 && dx && x && dy && w_hwio && dw && !tiny_cin(d) && !small_cin(d) && (d->cin % 8) == 0 && (d->cout % 8) == 0 &&
+  // one): the ping-pong body accumulates in another order than the igemm body of the shared launch, so layers whose
+  // dgrad has a ping-pong plan run wgrad and dgrad as two launches.
+  bool dgrad_pp = false;
+  if (dx && (d->cin % 8) == 0 && (d->cout % 8) == 0 && !bn) {
+    const IgemmArgs ap = dgrad_args(d, dy, w_hwio, addend, dx);
+    dgrad_pp = plan_pp<1>(ap).variant != 0;
+  }
+  if (fuse && !dgrad_pp && dx && x && dy && w_hwio && dw && !tiny_cin(d) && !small_cin(d) && (d->cin % 8) == 0 && (d->cout % 8) == 0 &&
       wgrad_use_tr() && conv_dma_stages() == 3) {
     IgemmArgs ad = dgrad_args(d, dy, w_hwio, addend, dx);
     rc = attach_bn(ad, d, bn);
@@ -2022,6 +1973,18 @@ int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl
                            rigl_stream_t stream) {
   return rigl_masked_conv2d_bwd_deferred(d, x, dy, w_hwio, addend, dw, dx, workspace, workspace_bytes, nullptr, nullptr,
                                          stream);
+}
+
+
+// Dense bf16 MFMA probe: enqueues blocks x 256 threads x iters x 8 MFMAs (2*32*32*16 FLOP each per wave); the caller
+// times it with events and divides.  `sink` needs blocks*256 floats (never written in practice).
+int rigl_probe_mfma_bf16(int32_t blocks, int32_t iters, float* sink, rigl_stream_t stream) {
+  using namespace rigl;
+  using namespace rigl::k1;
+  if (blocks <= 0 || iters <= 0 || !sink) return fail(RIGL_EINVAL, "rigl_probe_mfma_bf16: bad argument");
+  hipLaunchKernelGGL(k_mfma_probe, dim3((unsigned)blocks), dim3(THREADS), 0, as_stream(stream), sink, (int)iters, 0.5f);
+  RIGL_CHECK_LAUNCH("rigl_probe_mfma_bf16");
+  return RIGL_OK;
 }
 
 }  // extern "C"

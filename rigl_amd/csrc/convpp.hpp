@@ -1,0 +1,425 @@
+// K1 "ping-pong" implicit-GEMM body for the long-reduction layers (3x3 convs, 1x1 convs with >= 512 reduction
+// channels): 512 threads = 8 waves, TWO waves per SIMD that alternate roles every phase -- while one wave of a SIMD
+// runs a cluster of MFMAs, its partner issues the LDS fragment reads and the LDS-DMA loads of later K-tiles -- in the
+// spirit of the 8-phase schedule of cdna_hip_programming.md section 5 (raw s_barrier twice per phase, counted vmcnt,
+// no vmcnt(0) in steady state, DMA loads in flight across four phases).  Included by conv.hip (same namespace, same
+// IgemmArgs: reference call site rigl/imagenet_resnet/pruning_layers.py:139-157 fwd, autodiff dX
+// sparse_optimizers_base.py:478-485).
+//
+// Geometry (template): WM x WN waves (= 8), each wave TM x TN MFMA tiles of 32x32 (v_mfma_f32_32x32x16_bf16, operands
+// swapped like igemm_body so a lane holds 4 consecutive output channels), BK = 64 (one filter tap x 64 channels):
+//   <2,4,4,2> 256x256 tile, 128x64 per wave   (N % 256 == 0)
+//   <2,4,2,2> 128x256 tile,  64x64 per wave   (N % 256 == 0, layers with few rows)
+//   <4,2,2,2> 256x128 tile,  64x64 per wave   (N % 128 == 0)
+//   <4,2,4,2> 512x128 tile, 128x64 per wave   (N % 128 == 0, many rows)
+//
+// A K-tile lives in LDS as four PIECES: A0 / A1 = the first / second half of every wave's rows, B0 / B1 = the first /
+// second half of every wave's columns ([row][64] bf16 = 128-byte rows, XOR-swizzled 16-byte chunks; the swizzle is
+// applied on the DMA's SOURCE side because `buffer_load ... lds` writes lane-linear).  A wave multiplies a K-tile in four
+// phases, one quadrant each: (A0,B0) (A0,B1) (A1,B1) (A1,B0); fragments are read once per K-tile (A half 2x, B halves
+// kept in registers).  Two K-tile stages; every phase re-fills one dead piece:
+//   tile t phase 0: B1(t+1)   phase 1: A1(t+1)   phase 2: A0(t+2)   phase 3: B0(t+2)
+// so a piece is issued >= 2 phases after its slot's last read (WAR across the one-barrier stagger of the two wave
+// groups) and lands 4 phases before it is read; the covering `s_waitcnt vmcnt(N)` sits at the end of the read segment
+// of the phase BEFORE the reading phase (every wave's wait precedes, by a barrier, every wave's read -- the stagger
+// makes "wait and read in the same phase" a race), N = the loads of the (at most four) younger pieces.
+#pragma once
+// (included inside namespace rigl::k1 of conv.hip)
+
+template <int WM, int WN, int TM, int TN>
+struct PPGeom {
+  static_assert(WM * WN == 8, "eight waves");
+  static_assert(TM % 2 == 0 && TN % 2 == 0, "a wave tile splits into 2 x 2 quadrants");
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  static constexpr int AH_ROWS = BM / 2, BH_ROWS = BN / 2;
+  static constexpr int AH_BYTES = AH_ROWS * 128, BH_BYTES = BH_ROWS * 128;
+  static constexpr int STAGE = 2 * AH_BYTES + 2 * BH_BYTES;
+  static constexpr int NA = AH_ROWS / 64, NB = BH_ROWS / 64;       // LDS-DMA instructions per thread per piece
+  static_assert(AH_ROWS % 64 == 0 && BH_ROWS % 64 == 0, "a piece is whole rounds of 8 waves x 8 rows");
+  static constexpr int QM = TM / 2, QN = TN / 2;                   // MFMA tiles per quadrant
+  static constexpr int EPI_ROWB = TN * 64 + 16;                    // bytes per staged output row of a wave (+16: bank spread)
+  static constexpr int EPI_WAVE = QM * 32 * EPI_ROWB;              // one half of a wave's rows at a time
+  static constexpr int EPI_STATS = 8 * EPI_WAVE;                   // [8 waves][2][TN*32] floats behind the staging areas
+  static constexpr int EPI_ALL = EPI_STATS + 8 * 2 * TN * 32 * 4;
+  static constexpr int SMEM = (2 * STAGE > EPI_ALL) ? 2 * STAGE : EPI_ALL;
+  static_assert(SMEM <= 160 * 1024, "LDS per CU");
+};
+
+struct PPCursor { int tap, cb, r, s; };
+
+template <int WM, int WN, int TM, int TN, int MODE /*0 fwd, 1 dgrad (stride 1)*/>
+__global__ __launch_bounds__(512) void k_igemm_pp(IgemmArgs P) {
+  using G = PPGeom<WM, WN, TM, TN>;
+  constexpr int BM = G::BM, BN = G::BN, NA = G::NA, NB = G::NB, QM = G::QM, QN = G::QN;
+  constexpr int STAGE = G::STAGE, AH_BYTES = G::AH_BYTES, BH_BYTES = G::BH_BYTES;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_pp[];
+  unsigned char* const smem = smem_pp;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int grp = wave >> 2;                 // waves w and w + 4 share a SIMD: one of each group per SIMD
+  const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = (int)(tile / (uint32_t)P.tiles_n);
+  const int n0 = (int)(tile % (uint32_t)P.tiles_n) * BN;
+  const int m0 = tile_m * BM;
+
+  // ---- per-thread DMA rows (fixed for the whole K loop) -----------------------------------------------------------
+  // Piece h, instruction j of wave w fills piece rows (j*8 + w)*8 .. +7; lane l: row +(l >> 3), 16-byte slot l & 7,
+  // fetching source chunk slot ^ ((row >> 1) & 7).
+  const int taps = P.KH * P.KW;
+  int a_base[2][NA];
+  uint32_t a_mask[2][NA];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int lr = (j * 8 + wave) * 8 + (lane >> 3);
+      const int wmr = lr / (QM * 32), rem = lr % (QM * 32);
+      const int m = m0 + wmr * TM * 32 + h * QM * 32 + rem;
+      const int dchunk = (lane & 7) ^ ((lr >> 1) & 7);
+      const bool ok = m < P.M;
+      const int mm = ok ? m : 0;
+      const int t = fdiv(mm, P.fd_rw);
+      const int rw = mm - t * P.RW, n = fdiv(t, P.fd_rh), rh = t - n * P.RH;
+      const int c0 = MODE == 0 ? rh * P.sh - P.ph : rh + P.ph, c1 = MODE == 0 ? rw * P.sw - P.pw : rw + P.pw;
+      a_base[h][j] = ((n * P.GH + c0) * P.GW + c1) * P.a_pix_stride + dchunk * 8;
+      uint32_t mk = 0u;
+      if (ok) {
+        int tp = 0;
+        for (int r = 0; r < P.KH; ++r)
+          for (int s = 0; s < P.KW; ++s, ++tp) {
+            const int gh = MODE == 0 ? c0 + r : c0 - r, gw = MODE == 0 ? c1 + s : c1 - s;
+            if ((unsigned)gh < (unsigned)P.GH && (unsigned)gw < (unsigned)P.GW) mk |= 1u << tp;
+          }
+      }
+      a_mask[h][j] = mk;
+    }
+  int b_base[2][NB];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int lr = (j * 8 + wave) * 8 + (lane >> 3);
+      const int wnc = lr / (QN * 32), rem = lr % (QN * 32);
+      const int nn = n0 + wnc * TN * 32 + h * QN * 32 + rem;
+      const int dchunk = (lane & 7) ^ ((lr >> 1) & 7);
+      b_base[h][j] = nn * P.b_row_stride + dchunk * 8;
+    }
+  const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.A, P.a_bytes), rsrcB = make_rsrc(P.B, P.b_bytes);
+  const int kcb = P.Cred >> 6;
+  const int KT = taps * kcb;
+  const int a_row_step = (MODE == 0 ? P.GW : -P.GW) * P.a_pix_stride, a_col_step = (MODE == 0 ? 1 : -1) * P.a_pix_stride;
+
+#define PP_NEXT(c_) { if (++(c_).cb == kcb) { (c_).cb = 0; ++(c_).tap; if (++(c_).s == P.KW) { (c_).s = 0; ++(c_).r; } } }
+#define PP_ISSUE_A(h_, stage_, c_)                                                                       \
+  {                                                                                                      \
+    const int da_ = (c_).r * a_row_step + (c_).s * a_col_step + ((c_).cb << 6);                          \
+    _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                     \
+      const bool ok_ = ((a_mask[h_][j] >> (c_).tap) & 1u) != 0u;                                         \
+      const int off_ = ok_ ? (int)((uint32_t)(a_base[h_][j] + da_) * 2u) : (int)OOB;                     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                          \
+          rsrcA, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + (h_) * AH_BYTES + (j * 8 + wave) * 1024), \
+          16, off_, 0, 0, 0);                                                                            \
+    }                                                                                                    \
+  }
+#define PP_ISSUE_B(h_, stage_, c_)                                                                       \
+  {                                                                                                      \
+    const int db_ = (c_).tap * P.b_tap_stride + ((c_).cb << 6);                                          \
+    _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                                     \
+      const int off_ = (int)((uint32_t)(b_base[h_][j] + db_) * 2u);                                      \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                          \
+          rsrcB, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + 2 * AH_BYTES + (h_) * BH_BYTES + (j * 8 + wave) * 1024), \
+          16, off_, 0, 0, 0);                                                                            \
+    }                                                                                                    \
+  }
+
+  // ---- fragment read addresses --------------------------------------------------------------------------------------
+  // MFMA operand fragment: lane l holds row (l & 31), 8 consecutive k at chunk 2*ks + (l >> 5) of the 64-wide K-tile.
+  const int sw = ((lane & 31) >> 1) & 7, hi = lane >> 5;
+  int kof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kof[ks] = (((ks * 2 + hi) ^ sw) << 4);
+  const int a_row_off = (wm * QM * 32 + (lane & 31)) * 128, b_row_off = (wn * QN * 32 + (lane & 31)) * 128;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  bf16x8 af[QM][4], b0[QN][4], b1[QN][4];
+
+#define PP_READ_A(h_, stage_)                                                                            \
+  _Pragma("unroll") for (int i = 0; i < QM; ++i)                                                         \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                     \
+      af[i][ks] = *reinterpret_cast<const bf16x8*>(smem + (stage_) * STAGE + (h_) * AH_BYTES + a_row_off + i * 4096 + kof[ks]);
+#define PP_READ_B(dst_, h_, stage_)                                                                      \
+  _Pragma("unroll") for (int j = 0; j < QN; ++j)                                                         \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                     \
+      dst_[j][ks] = *reinterpret_cast<const bf16x8*>(smem + (stage_) * STAGE + 2 * AH_BYTES + (h_) * BH_BYTES + b_row_off + j * 4096 + kof[ks]);
+  // quadrant (ha_, hb_): rows ha_*QM.., columns hb_*QN.. of the wave tile; D = W-fragment x X-fragment (transposed tile)
+#define PP_MFMA(ha_, hb_, bsrc_)                                                                         \
+  {                                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                     \
+      _Pragma("unroll") for (int i = 0; i < QM; ++i)                                                     \
+        _Pragma("unroll") for (int j = 0; j < QN; ++j)                                                   \
+          acc[(ha_) * QM + i][(hb_) * QN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                 \
+              bsrc_[j][ks], af[i][ks], acc[(ha_) * QM + i][(hb_) * QN + j], 0, 0, 0);                    \
+    __builtin_amdgcn_s_setprio(0);                                                                       \
+  }
+#define PP_BARRIER()                                                                                     \
+  {                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    asm volatile("" ::: "memory");                                                                       \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    asm volatile("" ::: "memory");                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  }
+  // loads that may stay in flight behind a wait: k_ youngest pieces of the issue order ... A0 B0 B1 A1 A0 B0 B1 A1
+  constexpr int W4 = 2 * NA + 2 * NB, W2 = NA + NB, W1 = NA;
+
+  // ---- prologue: pieces A0(0) B0(0) B1(0) A1(0) A0(1) B0(1) --------------------------------------------------------
+  PPCursor c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};     // tiles t + 1 and t + 2
+  PP_ISSUE_A(0, 0, c1); PP_ISSUE_B(0, 0, c1); PP_ISSUE_B(1, 0, c1); PP_ISSUE_A(1, 0, c1);
+  PP_NEXT(c1);
+  c2 = c1;
+  if (KT > 1) {
+    PP_ISSUE_A(0, 1, c1); PP_ISSUE_B(0, 1, c1);
+    PP_NEXT(c2);
+    wait_vmcnt<W4>();
+  } else {
+    wait_vmcnt<W2>();
+  }
+  PP_BARRIER();
+  if (grp == 1) PP_BARRIER();                        // the stagger: group 1 runs one barrier behind group 0
+
+  // one K-tile = four phases; S_ = its stage (compile-time), t_ its index
+#define PP_TILE(S_, t_)                                                                                  \
+  {                                                                                                      \
+    const bool n1_ = (t_) + 1 < KT, n2_ = (t_) + 2 < KT;                                                 \
+    /* phase 0: (A0, B0) */                                                                              \
+    PP_READ_A(0, S_); PP_READ_B(b0, 0, S_);                                                              \
+    if (n1_) { PP_ISSUE_B(1, (S_) ^ 1, c1); wait_vmcnt<W4>(); } else { wait_vmcnt<W1>(); }               \
+    PP_BARRIER();                                                                                        \
+    PP_MFMA(0, 0, b0);                                                                                   \
+    PP_BARRIER();                                                                                        \
+    /* phase 1: (A0, B1) */                                                                              \
+    PP_READ_B(b1, 1, S_);                                                                                \
+    if (n1_) { PP_ISSUE_A(1, (S_) ^ 1, c1); wait_vmcnt<W4>(); } else { wait_vmcnt<0>(); }                \
+    PP_BARRIER();                                                                                        \
+    PP_MFMA(0, 1, b1);                                                                                   \
+    PP_BARRIER();                                                                                        \
+    /* phase 2: (A1, B1) -- phase 3 reads nothing new, so no wait here */                                \
+    PP_READ_A(1, S_);                                                                                    \
+    if (n2_) { PP_ISSUE_A(0, S_, c2); }                                                                  \
+    PP_BARRIER();                                                                                        \
+    PP_MFMA(1, 1, b1);                                                                                   \
+    PP_BARRIER();                                                                                        \
+    /* phase 3: (A1, B0) */                                                                              \
+    if (n2_) { PP_ISSUE_B(0, S_, c2); wait_vmcnt<W4>(); } else if (n1_) { wait_vmcnt<W2>(); }            \
+    PP_BARRIER();                                                                                        \
+    PP_MFMA(1, 0, b0);                                                                                   \
+    PP_BARRIER();                                                                                        \
+    c1 = c2;                                                                                             \
+    PP_NEXT(c2);                                                                                         \
+  }
+  for (int t = 0; t < KT; t += 2) {
+    PP_TILE(0, t);
+    if (t + 1 < KT) PP_TILE(1, t + 1);
+  }
+  if (grp == 0) PP_BARRIER();                        // group 0 waits for group 1's last MFMA phase
+#undef PP_TILE
+#undef PP_READ_A
+#undef PP_READ_B
+#undef PP_MFMA
+#undef PP_ISSUE_A
+#undef PP_ISSUE_B
+#undef PP_NEXT
+
+  // ---- epilogue ------------------------------------------------------------------------------------------------------
+  // Every wave stages its own tile (half of its rows at a time) in a private LDS area and stores full 128-byte row
+  // segments: no workgroup barrier.  D layout: col = lane & 31 -> pixel, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+  // -> channel.
+  constexpr int ROWB = G::EPI_ROWB, WCOLS = TN * 32, CH = WCOLS / 8, RPI = 64 / CH, ITERS = QM * 32 / RPI;
+  static_assert(CH == 8, "a wave's 64 columns = 8 chunks of 16 bytes per row");
+  unsigned char* const stg = smem + wave * G::EPI_WAVE;
+  uint16_t* const C = static_cast<uint16_t*>(P.C);
+  const int ch = lane & 7, rsub = lane >> 3;
+  const int ncol = n0 + wn * WCOLS + ch * 8;
+  float sy[8], sq[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) sy[c] = sq[c] = 0.f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int i = 0; i < QM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = i * 32 + (lane & 31), col = j * 32 + 8 * q + 4 * (lane >> 5);
+          const f32x16& a = acc[h * QM + i][j];
+          const f32x2 lo = {a[4 * q], a[4 * q + 1]}, hi2 = {a[4 * q + 2], a[4 * q + 3]};
+          uint2 pk;
+          pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));
+          pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi2, bf16x2));
+          *reinterpret_cast<uint2*>(stg + row * ROWB + col * 2) = pk;
+        }
+    const int mrow0 = m0 + wm * TM * 32 + h * QM * 32;
+    uint4 addv[ITERS];
+    if (P.ADD) {
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int m = mrow0 + it * RPI + rsub;
+        addv[it] = m < P.M ? *reinterpret_cast<const uint4*>(P.ADD + (int64_t)m * P.ldc + ncol) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int row = it * RPI + rsub, m = mrow0 + row;
+      uint4 v = *reinterpret_cast<const uint4*>(stg + row * ROWB + ch * 16);
+      if (MODE == 0 && P.STATS) {
+        const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float f = __uint_as_float((c & 1) ? (vw[c >> 1] & 0xFFFF0000u) : (vw[c >> 1] << 16));
+          sy[c] += f; sq[c] = fmaf(f, f, sq[c]);
+        }
+      }
+      if (m < P.M) {
+        if (P.ADD) {
+          const uint4 q = addv[it];
+          v.x = add_bf16x2(v.x, q.x); v.y = add_bf16x2(v.y, q.y); v.z = add_bf16x2(v.z, q.z); v.w = add_bf16x2(v.w, q.w);
+        }
+        *reinterpret_cast<uint4*>(C + (int64_t)m * P.ldc + ncol) = v;
+      }
+    }
+  }
+  if (MODE == 0 && P.STATS) {
+    // Batch-norm statistics of the bf16 outputs, one partial row per 128 output rows (rigl_conv2d_stats_parts): a wave's
+    // column sums over its rows (rows beyond M hold exact zeros), lanes combined by a fixed xor tree, then the waves
+    // that share a 128-row unit in wave-row order -- deterministic.
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { sy[c] += __shfl_xor(sy[c], off); sq[c] += __shfl_xor(sq[c], off); }
+    float* const wst = reinterpret_cast<float*>(smem + G::EPI_STATS);   // [8 waves][2][WCOLS]
+    if (lane < 8) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { wst[(wave * 2 + 0) * WCOLS + lane * 8 + c] = sy[c]; wst[(wave * 2 + 1) * WCOLS + lane * 8 + c] = sq[c]; }
+    }
+    __syncthreads();
+    constexpr int WPU = 128 / (TM * 32) > 0 ? 128 / (TM * 32) : 1;      // wave rows per 128-row unit (1 when a wave owns 128 rows)
+    constexpr int UNITS = BM / 128;
+    static_assert(TM * 32 <= 128, "a wave's rows fit one statistics unit");
+    for (int idx = tid; idx < UNITS * 2 * BN; idx += 512) {
+      const int u = idx / (2 * BN), k = (idx / BN) & 1, col = idx % BN;
+      const int wcol = col / WCOLS, cc = col % WCOLS;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WPU; ++w) s += wst[(((u * WPU + w) * WN + wcol) * 2 + k) * WCOLS + cc];
+      const int64_t unit = (int64_t)tile_m * UNITS + u;
+      if (unit * 128 < P.M) P.STATS[unit * 2 * P.N + (int64_t)k * P.N + n0 + col] = s;
+    }
+  }
+#undef PP_BARRIER
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+// Variant ids (rigl_tune_set("pp_fwd" / "pp_dgrad", id) forces one; 0 = never; -1 = the built-in rule)
+enum { PP_NONE = 0, PP_256x256 = 1, PP_128x256 = 2, PP_256x128 = 3, PP_512x128 = 4 };
+
+struct PPPlan { int variant; unsigned grid; int bm, bn; };
+
+
+
+template <int WM, int WN, int TM, int TN, int MODE>
+static bool pp_ready() {
+  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm_pp<WM, WN, TM, TN, MODE>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                PPGeom<WM, WN, TM, TN>::SMEM) == hipSuccess;
+  return ready;
+}
+
+static inline void pp_dims(int variant, int& bm, int& bn) {
+  switch (variant) {
+    case PP_256x256: bm = 256; bn = 256; break;
+    case PP_128x256: bm = 128; bn = 256; break;
+    case PP_256x128: bm = 256; bn = 128; break;
+    case PP_512x128: bm = 512; bn = 128; break;
+    default: bm = bn = 0;
+  }
+}
+
+// Is the ping-pong body legal for this GEMM at all?
+template <int MODE>
+static bool pp_legal(const IgemmArgs& a, int variant) {
+  int bm, bn;
+  pp_dims(variant, bm, bn);
+  if (!bm) return false;
+  if (a.Cred % 64 || a.a_pix_stride != a.Cred) return false;
+  if (a.N % bn) return false;
+  if (a.KH * a.KW > 32) return false;
+  if (MODE == 1 && (a.sh != 1 || a.sw != 1)) return false;
+  if (a.BNX) return false;
+  if (a.M < bm) return false;
+  return true;
+}
+
+template <int MODE>
+static PPPlan plan_pp(const IgemmArgs& a) {
+  PPPlan p = {PP_NONE, 0u, 0, 0};
+  const int forced = tune_get(MODE == 0 ? "pp_fwd" : "pp_dgrad", -1);
+  int v = PP_NONE;
+  if (forced >= 0) v = forced;
+  else {
+    // built-in rule: long reductions only (>= 8 K-tiles of 64); the tile by the column count and by how many row tiles
+    // the layer has for the 256 CUs (one workgroup per CU)
+    const int kt = a.KH * a.KW * (a.Cred / 64);
+    if (kt >= 8) {
+      const int64_t cus = num_cus();
+      if (a.N % 256 == 0) {
+        const int64_t t256 = (int64_t)((a.M + 255) / 256) * (a.N / 256);
+        v = t256 >= cus ? PP_256x256 : PP_128x256;
+      } else if (a.N % 128 == 0) {
+        v = PP_256x128;
+      }
+    }
+  }
+  if (v == PP_NONE || !pp_legal<MODE>(a, v)) return p;
+  pp_dims(v, p.bm, p.bn);
+  p.variant = v;
+  p.grid = (unsigned)(((a.M + p.bm - 1) / p.bm) * (a.N / p.bn));
+  return p;
+}
+
+template <int MODE>
+static bool launch_pp(const PPPlan& p, const IgemmArgs& a0, hipStream_t st) {
+  IgemmArgs a = a0;
+  a.fd_rw = make_fastdiv(a.RW); a.fd_rh = make_fastdiv(a.RH);
+  a.tiles_n = a.N / p.bn;
+  const dim3 grid(p.grid), blk(512);
+  switch (p.variant) {
+    case PP_256x256:
+      if (!pp_ready<2, 4, 4, 2, MODE>()) return false;
+      RIGL_K_LAUNCH((k_igemm_pp<2, 4, 4, 2, MODE>), grid, blk, (PPGeom<2, 4, 4, 2>::SMEM), st, a);
+      return true;
+    case PP_128x256:
+      if (!pp_ready<2, 4, 2, 2, MODE>()) return false;
+      RIGL_K_LAUNCH((k_igemm_pp<2, 4, 2, 2, MODE>), grid, blk, (PPGeom<2, 4, 2, 2>::SMEM), st, a);
+      return true;
+    case PP_256x128:
+      if (!pp_ready<4, 2, 2, 2, MODE>()) return false;
+      RIGL_K_LAUNCH((k_igemm_pp<4, 2, 2, 2, MODE>), grid, blk, (PPGeom<4, 2, 2, 2>::SMEM), st, a);
+      return true;
+    case PP_512x128:
+      if (!pp_ready<4, 2, 4, 2, MODE>()) return false;
+      RIGL_K_LAUNCH((k_igemm_pp<4, 2, 4, 2, MODE>), grid, blk, (PPGeom<4, 2, 4, 2>::SMEM), st, a);
+      return true;
+    default: return false;
+  }
+}
+

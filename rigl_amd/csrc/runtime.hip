@@ -1,5 +1,8 @@
 // Error channel, version, and the optional HIP-event profiler of the C ABI.
+#include <ctype.h>
 #include <mutex>
+#include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #include "common.hpp"
@@ -21,6 +24,31 @@ int fail(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+// ---- development knobs ------------------------------------------------------
+struct Knob { char key[32]; int value; bool set; };
+static std::mutex g_tune_mu;
+static std::vector<Knob> g_knobs;
+
+// A knob never set by rigl_tune_set reads the environment variable RIGL_<KEY IN UPPER CASE> once (so that
+// subprocess-per-setting test runners can select kernels the way they always did), else the caller's default.
+int tune_get(const char* key, int dflt) {
+  std::lock_guard<std::mutex> l(g_tune_mu);
+  for (const Knob& k : g_knobs)
+    if (strncmp(k.key, key, sizeof(k.key)) == 0) return k.set ? k.value : dflt;
+  Knob k;
+  memset(&k, 0, sizeof(k));
+  strncpy(k.key, key, sizeof(k.key) - 1);
+  char env[48] = "RIGL_";
+  size_t n = 5;
+  for (const char* c = key; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)toupper((unsigned char)*c);
+  env[n] = 0;
+  const char* e = getenv(env);
+  k.set = e != nullptr && *e != 0;
+  k.value = k.set ? atoi(e) : 0;
+  g_knobs.push_back(k);
+  return k.set ? k.value : dflt;
 }
 
 // ---- profiler ---------------------------------------------------------------
@@ -104,6 +132,22 @@ uint32_t rigl_crc32c(const void* data, size_t n, uint32_t crc) {
 }
 
 const char* rigl_last_error(void) { return rigl::g_err; }
+
+int rigl_tune_set(const char* key, int32_t value) {
+  if (!key || !*key || strlen(key) >= sizeof(rigl::Knob::key)) return rigl::fail(RIGL_EINVAL, "rigl_tune_set: bad key");
+  std::lock_guard<std::mutex> l(rigl::g_tune_mu);
+  for (rigl::Knob& k : rigl::g_knobs)
+    if (strcmp(k.key, key) == 0) { k.value = value; k.set = true; return RIGL_OK; }
+  rigl::Knob k;
+  memset(&k, 0, sizeof(k));
+  strncpy(k.key, key, sizeof(k.key) - 1);
+  k.value = value;
+  k.set = true;
+  rigl::g_knobs.push_back(k);
+  return RIGL_OK;
+}
+
+int32_t rigl_tune_get(const char* key, int32_t dflt) { return key ? rigl::tune_get(key, dflt) : dflt; }
 
 int rigl_prof_enable(int32_t on) {
   std::lock_guard<std::mutex> l(rigl::g_prof_mu);

@@ -795,6 +795,31 @@ def softmax_xent(logits, labels, label_smoothing=0.0, grad_scale=None, want_grad
 # ----------------------------------------------------------------------------
 # profiling
 # ----------------------------------------------------------------------------
+def tune_set(key, value):
+  """Process-wide kernel-selection knob (rigl_tune_set); descriptors cache plan-dependent sizes, so make new ones."""
+  check(_lib.load().rigl_tune_set(key.encode(), int(value)))
+
+
+def tune_get(key, default=-1):
+  return int(_lib.load().rigl_tune_get(key.encode(), int(default)))
+
+
+def mfma_peak_probe(device='cuda:0', blocks=2048, iters=2000, reps=5):
+  """Dense bf16 MFMA rate of this box in TFLOP/s (register-only MFMA chains, best of ``reps``)."""
+  lib = _lib.load()
+  sink = torch.zeros(blocks * 256, dtype=torch.float32, device=device)
+  best = 0.0
+  for r in range(reps + 1):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    check(lib.rigl_probe_mfma_bf16(blocks, iters, _ptr(sink), _stream()))
+    e.record()
+    e.synchronize()
+    if r:
+      best = max(best, blocks * 4 * iters * 8 * 32768.0 / (s.elapsed_time(e) * 1e-3) / 1e12)
+  return best
+
+
 def prof_enable(on=True):
   check(_lib.load().rigl_prof_enable(int(bool(on))))
 
