@@ -15,19 +15,26 @@
 //
 // A K-tile lives in LDS as four PIECES: A0 / A1 = the first / second half of every wave's rows, B0 / B1 = the first /
 // second half of every wave's columns ([row][64] bf16 = 128-byte rows, XOR-swizzled 16-byte chunks; the swizzle is
-// applied on the DMA's SOURCE side because `buffer_load ... lds` writes lane-linear).  A wave multiplies a K-tile in four
-// phases, one quadrant each: (A0,B0) (A0,B1) (A1,B1) (A1,B0); fragments are read once per K-tile (A half 2x, B halves
-// kept in registers).  Two K-tile stages; every phase re-fills one dead piece:
-//   tile t phase 0: B1(t+1)   phase 1: A1(t+1)   phase 2: A0(t+2)   phase 3: B0(t+2)
-// so a piece is issued >= 2 phases after its slot's last read (WAR across the one-barrier stagger of the two wave
-// groups) and lands 4 phases before it is read; the covering `s_waitcnt vmcnt(N)` sits at the end of the read segment
-// of the phase BEFORE the reading phase (every wave's wait precedes, by a barrier, every wave's read -- the stagger
-// makes "wait and read in the same phase" a race), N = the loads of the (at most four) younger pieces.
+// applied on the DMA's SOURCE side because `buffer_load ... lds` writes lane-linear).  A wave multiplies a K-tile
+// quadrant by quadrant, (A0,B0) (A0,B1) (A1,B1) (A1,B0), in PH phases (template):
+//   PH = 4  one quadrant per phase, two K-tile stages; every phase re-fills one dead piece:
+//           tile t phase 0: B1(t+1)   1: A1(t+1)   2: A0(t+2)   3: B0(t+2)
+//   PH = 2  two quadrants per phase (twice the MFMAs between barriers), two stages:
+//           tile t phase A (reads A0 B0 B1): A1(t+1)      phase B (reads A1): A0(t+2) B0(t+2) B1(t+2)
+//   PH = 1  the whole K-tile per phase (for the 64x64 wave tiles), three stages: tile t re-fills the stage of tile t-1
+//           with tile t+2.
+// A piece is issued >= 2 phases after its slot's last read (PH = 4), or in the phase right after it when the reading
+// segment ends with `s_waitcnt lgkmcnt(0)` BEFORE its barrier (PH = 2, 1) -- the two wave groups run one barrier apart,
+// so a read and a re-fill one barrier apart would race otherwise.  The covering `s_waitcnt vmcnt(N)` sits at the end of
+// the read segment of the phase BEFORE the reading phase (every wave's wait precedes, by a barrier, every wave's read --
+// the stagger makes "wait and read in the same phase" a race), N = the loads of the (at most four) younger pieces.
 #pragma once
 // (included inside namespace rigl::k1 of conv.hip)
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int PH>
 struct PPGeom {
+  static_assert(PH == 4 || PH == 2 || PH == 1, "phases per K-tile");
+  static constexpr int NST = PH == 1 ? 3 : 2;                      // K-tile stages in LDS
   static_assert(WM * WN == 8, "eight waves");
   static_assert(TM % 2 == 0 && TN % 2 == 0, "a wave tile splits into 2 x 2 quadrants");
   static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -41,15 +48,15 @@ struct PPGeom {
   static constexpr int EPI_WAVE = QM * 32 * EPI_ROWB;              // one half of a wave's rows at a time
   static constexpr int EPI_STATS = 8 * EPI_WAVE;                   // [8 waves][2][TN*32] floats behind the staging areas
   static constexpr int EPI_ALL = EPI_STATS + 8 * 2 * TN * 32 * 4;
-  static constexpr int SMEM = (2 * STAGE > EPI_ALL) ? 2 * STAGE : EPI_ALL;
+  static constexpr int SMEM = (NST * STAGE > EPI_ALL) ? NST * STAGE : EPI_ALL;
   static_assert(SMEM <= 160 * 1024, "LDS per CU");
 };
 
 struct PPCursor { int tap, cb, r, s; };
 
-template <int WM, int WN, int TM, int TN, int MODE /*0 fwd, 1 dgrad (stride 1)*/>
+template <int WM, int WN, int TM, int TN, int PH, int MODE /*0 fwd, 1 dgrad (stride 1)*/>
 __global__ __launch_bounds__(512) void k_igemm_pp(IgemmArgs P) {
-  using G = PPGeom<WM, WN, TM, TN>;
+  using G = PPGeom<WM, WN, TM, TN, PH>;
   constexpr int BM = G::BM, BN = G::BN, NA = G::NA, NB = G::NB, QM = G::QM, QN = G::QN;
   constexpr int STAGE = G::STAGE, AH_BYTES = G::AH_BYTES, BH_BYTES = G::BH_BYTES;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_pp[];
@@ -84,14 +91,15 @@ __global__ __launch_bounds__(512) void k_igemm_pp(IgemmArgs P) {
       const int rw = mm - t * P.RW, n = fdiv(t, P.fd_rh), rh = t - n * P.RH;
       const int c0 = MODE == 0 ? rh * P.sh - P.ph : rh + P.ph, c1 = MODE == 0 ? rw * P.sw - P.pw : rw + P.pw;
       a_base[h][j] = ((n * P.GH + c0) * P.GW + c1) * P.a_pix_stride + dchunk * 8;
+      // bit (r*KW + s) = tap (r, s) reads inside the image: rows r with 0 <= c0 +- r < GH, columns likewise
       uint32_t mk = 0u;
       if (ok) {
-        int tp = 0;
+        const int s_lo = MODE == 0 ? -c1 : c1 - P.GW + 1, s_hi = MODE == 0 ? P.GW - 1 - c1 : c1;
+        const int r_lo = MODE == 0 ? -c0 : c0 - P.GH + 1, r_hi = MODE == 0 ? P.GH - 1 - c0 : c0;
+        const int sl = s_lo > 0 ? s_lo : 0, sh_ = s_hi < P.KW - 1 ? s_hi : P.KW - 1;
+        const uint32_t cm = sh_ >= sl ? ((2u << sh_) - 1u) & ~((1u << sl) - 1u) : 0u;
         for (int r = 0; r < P.KH; ++r)
-          for (int s = 0; s < P.KW; ++s, ++tp) {
-            const int gh = MODE == 0 ? c0 + r : c0 - r, gw = MODE == 0 ? c1 + s : c1 - s;
-            if ((unsigned)gh < (unsigned)P.GH && (unsigned)gw < (unsigned)P.GW) mk |= 1u << tp;
-          }
+          if (r >= r_lo && r <= r_hi) mk |= cm << (r * P.KW);
       }
       a_mask[h][j] = mk;
     }
@@ -149,27 +157,26 @@ __global__ __launch_bounds__(512) void k_igemm_pp(IgemmArgs P) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  bf16x8 af[QM][4], b0[QN][4], b1[QN][4];
+  constexpr int AF = PH == 1 ? TM : QM;                // A fragments held at a time (PH = 1 holds both halves)
+  bf16x8 af[AF][4], b0[QN][4], b1[QN][4];
 
-#define PP_READ_A(h_, stage_)                                                                            \
+  // (ab_ = first af[] slot filled)
+#define PP_READ_A(h_, stage_, ab_)                                                                       \
   _Pragma("unroll") for (int i = 0; i < QM; ++i)                                                         \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                     \
-      af[i][ks] = *reinterpret_cast<const bf16x8*>(smem + (stage_) * STAGE + (h_) * AH_BYTES + a_row_off + i * 4096 + kof[ks]);
+      af[(ab_) + i][ks] = *reinterpret_cast<const bf16x8*>(smem + (stage_) * STAGE + (h_) * AH_BYTES + a_row_off + i * 4096 + kof[ks]);
 #define PP_READ_B(dst_, h_, stage_)                                                                      \
   _Pragma("unroll") for (int j = 0; j < QN; ++j)                                                         \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                     \
       dst_[j][ks] = *reinterpret_cast<const bf16x8*>(smem + (stage_) * STAGE + 2 * AH_BYTES + (h_) * BH_BYTES + b_row_off + j * 4096 + kof[ks]);
-  // quadrant (ha_, hb_): rows ha_*QM.., columns hb_*QN.. of the wave tile; D = W-fragment x X-fragment (transposed tile)
-#define PP_MFMA(ha_, hb_, bsrc_)                                                                         \
-  {                                                                                                      \
-    __builtin_amdgcn_s_setprio(1);                                                                       \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                     \
-      _Pragma("unroll") for (int i = 0; i < QM; ++i)                                                     \
-        _Pragma("unroll") for (int j = 0; j < QN; ++j)                                                   \
-          acc[(ha_) * QM + i][(hb_) * QN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                 \
-              bsrc_[j][ks], af[i][ks], acc[(ha_) * QM + i][(hb_) * QN + j], 0, 0, 0);                    \
-    __builtin_amdgcn_s_setprio(0);                                                                       \
-  }
+  // quadrant (ha_, hb_): rows ha_*QM.., columns hb_*QN.. of the wave tile; D = W-fragment x X-fragment (transposed tile);
+  // ab_ = af[] slot of the quadrant's first A fragment
+#define PP_QUAD(ha_, hb_, bsrc_, ab_)                                                                    \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                       \
+    _Pragma("unroll") for (int i = 0; i < QM; ++i)                                                       \
+      _Pragma("unroll") for (int j = 0; j < QN; ++j)                                                     \
+        acc[(ha_) * QM + i][(hb_) * QN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                   \
+            bsrc_[j][ks], af[(ab_) + i][ks], acc[(ha_) * QM + i][(hb_) * QN + j], 0, 0, 0);
 #define PP_BARRIER()                                                                                     \
   {                                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -178,63 +185,145 @@ __global__ __launch_bounds__(512) void k_igemm_pp(IgemmArgs P) {
     asm volatile("" ::: "memory");                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                   \
   }
-  // loads that may stay in flight behind a wait: k_ youngest pieces of the issue order ... A0 B0 B1 A1 A0 B0 B1 A1
+  // read segments that end with this wait retire their fragment reads BEFORE the barrier: the slot may be re-filled by
+  // the other wave group in the very next barrier interval
+#define PP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+  // loads that may stay in flight behind a wait = the youngest pieces of the issue order (any four consecutive pieces
+  // are two A and two B halves)
   constexpr int W4 = 2 * NA + 2 * NB, W2 = NA + NB, W1 = NA;
 
-  // ---- prologue: pieces A0(0) B0(0) B1(0) A1(0) A0(1) B0(1) --------------------------------------------------------
   PPCursor c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};     // tiles t + 1 and t + 2
-  PP_ISSUE_A(0, 0, c1); PP_ISSUE_B(0, 0, c1); PP_ISSUE_B(1, 0, c1); PP_ISSUE_A(1, 0, c1);
-  PP_NEXT(c1);
-  c2 = c1;
-  if (KT > 1) {
-    PP_ISSUE_A(0, 1, c1); PP_ISSUE_B(0, 1, c1);
-    PP_NEXT(c2);
-    wait_vmcnt<W4>();
-  } else {
-    wait_vmcnt<W2>();
-  }
-  PP_BARRIER();
-  if (grp == 1) PP_BARRIER();                        // the stagger: group 1 runs one barrier behind group 0
 
-  // one K-tile = four phases; S_ = its stage (compile-time), t_ its index
-#define PP_TILE(S_, t_)                                                                                  \
-  {                                                                                                      \
-    const bool n1_ = (t_) + 1 < KT, n2_ = (t_) + 2 < KT;                                                 \
-    /* phase 0: (A0, B0) */                                                                              \
-    PP_READ_A(0, S_); PP_READ_B(b0, 0, S_);                                                              \
-    if (n1_) { PP_ISSUE_B(1, (S_) ^ 1, c1); wait_vmcnt<W4>(); } else { wait_vmcnt<W1>(); }               \
-    PP_BARRIER();                                                                                        \
-    PP_MFMA(0, 0, b0);                                                                                   \
-    PP_BARRIER();                                                                                        \
-    /* phase 1: (A0, B1) */                                                                              \
-    PP_READ_B(b1, 1, S_);                                                                                \
-    if (n1_) { PP_ISSUE_A(1, (S_) ^ 1, c1); wait_vmcnt<W4>(); } else { wait_vmcnt<0>(); }                \
-    PP_BARRIER();                                                                                        \
-    PP_MFMA(0, 1, b1);                                                                                   \
-    PP_BARRIER();                                                                                        \
-    /* phase 2: (A1, B1) -- phase 3 reads nothing new, so no wait here */                                \
-    PP_READ_A(1, S_);                                                                                    \
-    if (n2_) { PP_ISSUE_A(0, S_, c2); }                                                                  \
-    PP_BARRIER();                                                                                        \
-    PP_MFMA(1, 1, b1);                                                                                   \
-    PP_BARRIER();                                                                                        \
-    /* phase 3: (A1, B0) */                                                                              \
-    if (n2_) { PP_ISSUE_B(0, S_, c2); wait_vmcnt<W4>(); } else if (n1_) { wait_vmcnt<W2>(); }            \
-    PP_BARRIER();                                                                                        \
-    PP_MFMA(1, 0, b0);                                                                                   \
-    PP_BARRIER();                                                                                        \
-    c1 = c2;                                                                                             \
-    PP_NEXT(c2);                                                                                         \
-  }
-  for (int t = 0; t < KT; t += 2) {
-    PP_TILE(0, t);
-    if (t + 1 < KT) PP_TILE(1, t + 1);
+  if constexpr (PH == 4) {
+    // ---- prologue: pieces A0(0) B0(0) B1(0) A1(0) A0(1) B0(1) ------------------------------------------------------
+    PP_ISSUE_A(0, 0, c1); PP_ISSUE_B(0, 0, c1); PP_ISSUE_B(1, 0, c1); PP_ISSUE_A(1, 0, c1);
+    PP_NEXT(c1);
+    c2 = c1;
+    if (KT > 1) {
+      PP_ISSUE_A(0, 1, c1); PP_ISSUE_B(0, 1, c1);
+      PP_NEXT(c2);
+      wait_vmcnt<W4>();
+    } else {
+      wait_vmcnt<W2>();
+    }
+    PP_BARRIER();
+    if (grp == 1) PP_BARRIER();                      // the stagger: group 1 runs one barrier behind group 0
+    // one K-tile = four phases; S_ = its stage (compile-time), t_ its index
+#define PP_TILE4(S_, t_)                                                                                 \
+    {                                                                                                    \
+      const bool n1_ = (t_) + 1 < KT, n2_ = (t_) + 2 < KT;                                               \
+      /* phase 0: (A0, B0) */                                                                            \
+      PP_READ_A(0, S_, 0); PP_READ_B(b0, 0, S_);                                                         \
+      if (n1_) { PP_ISSUE_B(1, (S_) ^ 1, c1); wait_vmcnt<W4>(); } else { wait_vmcnt<W1>(); }             \
+      PP_BARRIER();                                                                                      \
+      __builtin_amdgcn_s_setprio(1); PP_QUAD(0, 0, b0, 0); __builtin_amdgcn_s_setprio(0);               \
+      PP_BARRIER();                                                                                      \
+      /* phase 1: (A0, B1) */                                                                            \
+      PP_READ_B(b1, 1, S_);                                                                              \
+      if (n1_) { PP_ISSUE_A(1, (S_) ^ 1, c1); wait_vmcnt<W4>(); } else { wait_vmcnt<0>(); }              \
+      PP_BARRIER();                                                                                      \
+      __builtin_amdgcn_s_setprio(1); PP_QUAD(0, 1, b1, 0); __builtin_amdgcn_s_setprio(0);               \
+      PP_BARRIER();                                                                                      \
+      /* phase 2: (A1, B1) -- phase 3 reads nothing new, so no wait here */                              \
+      PP_READ_A(1, S_, 0);                                                                               \
+      if (n2_) { PP_ISSUE_A(0, S_, c2); }                                                                \
+      PP_BARRIER();                                                                                      \
+      __builtin_amdgcn_s_setprio(1); PP_QUAD(1, 1, b1, 0); __builtin_amdgcn_s_setprio(0);               \
+      PP_BARRIER();                                                                                      \
+      /* phase 3: (A1, B0) */                                                                            \
+      if (n2_) { PP_ISSUE_B(0, S_, c2); wait_vmcnt<W4>(); } else if (n1_) { wait_vmcnt<W2>(); }          \
+      PP_BARRIER();                                                                                      \
+      __builtin_amdgcn_s_setprio(1); PP_QUAD(1, 0, b0, 0); __builtin_amdgcn_s_setprio(0);               \
+      PP_BARRIER();                                                                                      \
+      c1 = c2;                                                                                           \
+      PP_NEXT(c2);                                                                                       \
+    }
+    for (int t = 0; t < KT; t += 2) {
+      PP_TILE4(0, t);
+      if (t + 1 < KT) PP_TILE4(1, t + 1);
+    }
+#undef PP_TILE4
+  } else if constexpr (PH == 2) {
+    // ---- prologue: A0 B0 B1 (0), A1(0), A0 B0 B1 (1) --------------------------------------------------------------
+    PP_ISSUE_A(0, 0, c1); PP_ISSUE_B(0, 0, c1); PP_ISSUE_B(1, 0, c1); PP_ISSUE_A(1, 0, c1);
+    PP_NEXT(c1);
+    c2 = c1;
+    if (KT > 1) {
+      PP_ISSUE_A(0, 1, c1); PP_ISSUE_B(0, 1, c1); PP_ISSUE_B(1, 1, c1);
+      PP_NEXT(c2);
+      wait_vmcnt<W4>();
+    } else {
+      wait_vmcnt<W1>();
+    }
+    PP_BARRIER();
+    if (grp == 1) PP_BARRIER();
+#define PP_TILE2(S_, t_)                                                                                 \
+    {                                                                                                    \
+      const bool n1_ = (t_) + 1 < KT, n2_ = (t_) + 2 < KT;                                               \
+      /* phase A: (A0, B0) (A0, B1); re-fill A1 of the other stage (read last phase) */                  \
+      PP_READ_A(0, S_, 0); PP_READ_B(b0, 0, S_); PP_READ_B(b1, 1, S_);                                   \
+      if (n1_) { PP_ISSUE_A(1, (S_) ^ 1, c1); wait_vmcnt<W4>(); } else { wait_vmcnt<0>(); }              \
+      PP_LGKM0();                                                                                        \
+      PP_BARRIER();                                                                                      \
+      __builtin_amdgcn_s_setprio(1); PP_QUAD(0, 0, b0, 0); PP_QUAD(0, 1, b1, 0); __builtin_amdgcn_s_setprio(0); \
+      PP_BARRIER();                                                                                      \
+      /* phase B: (A1, B1) (A1, B0); re-fill A0 B0 B1 of this stage (read last phase) */                 \
+      PP_READ_A(1, S_, 0);                                                                               \
+      if (n2_) { PP_ISSUE_A(0, S_, c2); PP_ISSUE_B(0, S_, c2); PP_ISSUE_B(1, S_, c2); wait_vmcnt<W4>(); } \
+      else if (n1_) { wait_vmcnt<W1>(); }                                                                \
+      PP_LGKM0();                                                                                        \
+      PP_BARRIER();                                                                                      \
+      __builtin_amdgcn_s_setprio(1); PP_QUAD(1, 1, b1, 0); PP_QUAD(1, 0, b0, 0); __builtin_amdgcn_s_setprio(0); \
+      PP_BARRIER();                                                                                      \
+      c1 = c2;                                                                                           \
+      PP_NEXT(c2);                                                                                       \
+    }
+    for (int t = 0; t < KT; t += 2) {
+      PP_TILE2(0, t);
+      if (t + 1 < KT) PP_TILE2(1, t + 1);
+    }
+#undef PP_TILE2
+  } else {
+    // ---- PH == 1, three stages: prologue tiles 0 and 1 --------------------------------------------------------------
+    PP_ISSUE_A(0, 0, c1); PP_ISSUE_B(0, 0, c1); PP_ISSUE_B(1, 0, c1); PP_ISSUE_A(1, 0, c1);
+    PP_NEXT(c1);
+    c2 = c1;
+    if (KT > 1) {
+      PP_ISSUE_A(0, 1, c1); PP_ISSUE_B(0, 1, c1); PP_ISSUE_B(1, 1, c1); PP_ISSUE_A(1, 1, c1);
+      PP_NEXT(c2);
+      wait_vmcnt<W4>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    PP_BARRIER();
+    if (grp == 1) PP_BARRIER();
+    // tile t: read everything, re-fill the stage tile t-1 used with tile t+2, wait for tile t+1
+#define PP_TILE1(S_, SN_, t_)                                                                            \
+    {                                                                                                    \
+      const bool n2_ = (t_) + 2 < KT;                                                                    \
+      PP_READ_A(0, S_, 0); PP_READ_A(1, S_, QM); PP_READ_B(b0, 0, S_); PP_READ_B(b1, 1, S_);             \
+      if (n2_) { PP_ISSUE_A(0, SN_, c2); PP_ISSUE_B(0, SN_, c2); PP_ISSUE_B(1, SN_, c2); PP_ISSUE_A(1, SN_, c2); wait_vmcnt<W4>(); } \
+      else { wait_vmcnt<0>(); }                                                                          \
+      PP_LGKM0();                                                                                        \
+      PP_BARRIER();                                                                                      \
+      __builtin_amdgcn_s_setprio(1);                                                                     \
+      PP_QUAD(0, 0, b0, 0); PP_QUAD(0, 1, b1, 0); PP_QUAD(1, 1, b1, QM); PP_QUAD(1, 0, b0, QM);          \
+      __builtin_amdgcn_s_setprio(0);                                                                     \
+      PP_BARRIER();                                                                                      \
+      PP_NEXT(c2);                                                                                       \
+    }
+    for (int t = 0; t < KT; t += 3) {
+      PP_TILE1(0, 2, t);
+      if (t + 1 < KT) PP_TILE1(1, 0, t + 1);
+      if (t + 2 < KT) PP_TILE1(2, 1, t + 2);
+    }
+#undef PP_TILE1
   }
   if (grp == 0) PP_BARRIER();                        // group 0 waits for group 1's last MFMA phase
-#undef PP_TILE
 #undef PP_READ_A
 #undef PP_READ_B
-#undef PP_MFMA
+#undef PP_QUAD
+#undef PP_LGKM0
 #undef PP_ISSUE_A
 #undef PP_ISSUE_B
 #undef PP_NEXT
@@ -336,12 +425,18 @@ struct PPPlan { int variant; unsigned grid; int bm, bn; };
 
 
 
-template <int WM, int WN, int TM, int TN, int MODE>
+template <int WM, int WN, int TM, int TN, int PH, int MODE>
 static bool pp_ready() {
-  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm_pp<WM, WN, TM, TN, MODE>),
+  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm_pp<WM, WN, TM, TN, PH, MODE>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                PPGeom<WM, WN, TM, TN>::SMEM) == hipSuccess;
+                                                PPGeom<WM, WN, TM, TN, PH>::SMEM) == hipSuccess;
   return ready;
+}
+template <int WM, int WN, int TM, int TN, int PH, int MODE>
+static bool pp_launch_one(dim3 grid, const IgemmArgs& a, hipStream_t st) {
+  if (!pp_ready<WM, WN, TM, TN, PH, MODE>()) return false;
+  RIGL_K_LAUNCH((k_igemm_pp<WM, WN, TM, TN, PH, MODE>), grid, dim3(512), (PPGeom<WM, WN, TM, TN, PH>::SMEM), st, a);
+  return true;
 }
 
 static inline void pp_dims(int variant, int& bm, int& bn) {
@@ -401,24 +496,19 @@ static bool launch_pp(const PPPlan& p, const IgemmArgs& a0, hipStream_t st) {
   IgemmArgs a = a0;
   a.fd_rw = make_fastdiv(a.RW); a.fd_rh = make_fastdiv(a.RH);
   a.tiles_n = a.N / p.bn;
-  const dim3 grid(p.grid), blk(512);
+  const dim3 grid(p.grid);
+  // phases per K-tile: the 128x64 wave tiles run 2 (16 MFMAs between barriers; "pp_ph" = 4 selects one quadrant per
+  // phase), the 64x64 wave tiles 1 with three stages ("pp_ph" = 4 selects the four-phase, two-stage form)
+  const int ph = tune_get("pp_ph", 0);
   switch (p.variant) {
     case PP_256x256:
-      if (!pp_ready<2, 4, 4, 2, MODE>()) return false;
-      RIGL_K_LAUNCH((k_igemm_pp<2, 4, 4, 2, MODE>), grid, blk, (PPGeom<2, 4, 4, 2>::SMEM), st, a);
-      return true;
+      return ph == 4 ? pp_launch_one<2, 4, 4, 2, 4, MODE>(grid, a, st) : pp_launch_one<2, 4, 4, 2, 2, MODE>(grid, a, st);
     case PP_128x256:
-      if (!pp_ready<2, 4, 2, 2, MODE>()) return false;
-      RIGL_K_LAUNCH((k_igemm_pp<2, 4, 2, 2, MODE>), grid, blk, (PPGeom<2, 4, 2, 2>::SMEM), st, a);
-      return true;
+      return ph == 4 ? pp_launch_one<2, 4, 2, 2, 4, MODE>(grid, a, st) : pp_launch_one<2, 4, 2, 2, 1, MODE>(grid, a, st);
     case PP_256x128:
-      if (!pp_ready<4, 2, 2, 2, MODE>()) return false;
-      RIGL_K_LAUNCH((k_igemm_pp<4, 2, 2, 2, MODE>), grid, blk, (PPGeom<4, 2, 2, 2>::SMEM), st, a);
-      return true;
+      return ph == 4 ? pp_launch_one<4, 2, 2, 2, 4, MODE>(grid, a, st) : pp_launch_one<4, 2, 2, 2, 1, MODE>(grid, a, st);
     case PP_512x128:
-      if (!pp_ready<4, 2, 4, 2, MODE>()) return false;
-      RIGL_K_LAUNCH((k_igemm_pp<4, 2, 4, 2, MODE>), grid, blk, (PPGeom<4, 2, 4, 2>::SMEM), st, a);
-      return true;
+      return ph == 4 ? pp_launch_one<4, 2, 4, 2, 4, MODE>(grid, a, st) : pp_launch_one<4, 2, 4, 2, 2, MODE>(grid, a, st);
     default: return false;
   }
 }

@@ -86,6 +86,7 @@ def main():
   ap.add_argument('--variants', type=int, nargs='+', default=[0, 1, 2, 3, 4])
   ap.add_argument('--layers', nargs='*', default=None)
   ap.add_argument('--passes', nargs='+', default=['fwd', 'dgrad'])
+  ap.add_argument('--ph', type=int, nargs='+', default=[0], help='pp_ph settings to sweep: 0 = built-in phases, 4 = four phases')
   ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'pp_sweep.json'))
   a = ap.parse_args()
   rep = dict(mfma_peak_tflops=ops.mfma_peak_probe(DEV), rows=[])
@@ -110,9 +111,10 @@ def main():
       ref = {}
       for ps in a.passes:
         line = '%-20s B%-4d %-5s' % (name, B, ps)
-        for v in a.variants:
+        for v, ph in [(v, ph) for v in a.variants for ph in (a.ph if v else [0])]:
           if v and not legal(v, ps, B, H, W, Cin, Cout, s, Ho, Wo):
             continue
+          ops.tune_set('pp_ph', ph)
           ops.tune_set('pp_fwd', v)
           ops.tune_set('pp_dgrad', v)
           d = ops.conv_desc(B, H, W, Cin, Cout, k, k, s, pt, pl, Ho, Wo)
@@ -140,14 +142,15 @@ def main():
                   bad += ' BADSTATS(%.3g)' % e
             ms = timeit(run, a.iters)
             tf = 2 * macs / (ms * 1e-3) / 1e12
-            rep['rows'].append(dict(layer=name, batch=B, kind=ps, variant=v, ms=ms, tflops=tf, bad=bad))
-            line += ' | %s %6.1f us %5.0f TF%s' % (NAMES[v], ms * 1e3, tf, bad)
+            rep['rows'].append(dict(layer=name, batch=B, kind=ps, variant=v, ph=ph, ms=ms, tflops=tf, bad=bad))
+            line += ' | %s%s %6.1f us %5.0f TF%s' % (NAMES[v], '/4ph' if ph == 4 else '', ms * 1e3, tf, bad)
           except Exception as ex:  # pylint: disable=broad-except
             line += ' | %s FAILED %s' % (NAMES[v], repr(ex)[:60])
         print(line, flush=True)
       del x, dy, w, add, hwio, ohwi, ref
   ops.tune_set('pp_fwd', -1)
   ops.tune_set('pp_dgrad', -1)
+  ops.tune_set('pp_ph', 0)
   os.makedirs(os.path.dirname(a.out), exist_ok=True)
   with open(a.out, 'w') as f:
     json.dump(rep, f, indent=1)
