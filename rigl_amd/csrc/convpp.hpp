@@ -470,20 +470,19 @@ static PPPlan plan_pp(const IgemmArgs& a) {
   const int forced = tune_get(MODE == 0 ? "pp_fwd" : "pp_dgrad", -1);
   int v = PP_NONE;
   if (forced >= 0) v = forced;
-  else {
-    // built-in rule: long reductions only (>= 8 K-tiles of 64); the tile by the column count and by how many row tiles
-    // the layer has for the 256 CUs (one workgroup per CU)
+  else if (MODE == 0) {
+    // Built-in rule (measured per layer at batch 128 and 512, tools/pp_sweep.py, profiles/r3/pp_sweep_*.txt): reductions
+    // of >= 8 K-tiles of 64; the 128x64-per-wave tiles (256x256 / 512x128) where they still give ~3/4 of the CUs a
+    // workgroup (one workgroup per CU), else the 64x64-per-wave tiles with half the rows.
     const int kt = a.KH * a.KW * (a.Cred / 64);
+    const int64_t fill = (int64_t)num_cus() * 3 / 4;
     if (kt >= 8) {
-      const int64_t cus = num_cus();
-      if (a.N % 256 == 0) {
-        const int64_t t256 = (int64_t)((a.M + 255) / 256) * (a.N / 256);
-        v = t256 >= cus ? PP_256x256 : PP_128x256;
-      } else if (a.N % 128 == 0) {
-        v = PP_256x128;
-      }
+      if (a.N % 256 == 0) v = (int64_t)((a.M + 255) / 256) * (a.N / 256) >= fill ? PP_256x256 : PP_128x256;
+      else if (a.N % 128 == 0) v = (int64_t)((a.M + 511) / 512) * (a.N / 128) >= fill ? PP_512x128 : PP_256x128;
     }
   }
+  // (dgrad: the shared backward launch -- dgrad tiles next to the split-K weight-gradient workgroups -- still beats a
+  //  stand-alone ping-pong dgrad plus a stand-alone wgrad on most layers, so there is no built-in dgrad rule yet)
   if (v == PP_NONE || !pp_legal<MODE>(a, v)) return p;
   pp_dims(v, p.bm, p.bn);
   p.variant = v;

@@ -2,10 +2,11 @@
 """K1 parity runner (GPU): every conv entry point of the C ABI against tests/convref.py's fp64 reference on the same
 bf16 operands, with the per-element bound  2^-8 |ref| + 1e-5 sum|a||b|  (fwd / dgrad)  and  1e-5 sum|a||b|  (wgrad).
 
-Run as a script so that the kernel-selection environment (RIGL_T196, RIGL_W9, RIGL_CONV_BIG, ...), which the library
-reads once per process, can be chosen per invocation:
+Run as a script so that the kernel-selection environment (RIGL_PP_FWD, RIGL_PP_DGRAD, RIGL_PP_PH, RIGL_CONV_BIG, ...),
+which the library reads once per process, can be chosen per invocation:
 
-  python tests/k1_check.py --set t196          # tile196 shapes (1x1 / 3x3, both column widths, K splits, ragged N)
+  python tests/k1_check.py --set small         # small 1x1 / 3x3 shapes (both column widths, ragged N, halo rows)
+  python tests/k1_check.py --set pp            # edge cases of the 8-wave ping-pong body (1..9 K-tiles, row tails, stride 2)
   python tests/k1_check.py --set resnet50 --batch 128     # the 23 distinct ResNet-50 layer shapes at the benchmarked batch
 
 Prints one line per case and a final JSON line {"ok": true, "cases": n, "worst": ratio}; exit code 1 on a mismatch.
@@ -26,7 +27,7 @@ from tests import convref  # noqa: E402
 DEV = 'cuda:0'
 
 # N, H, W, Cin, Cout, k, stride, pad_top, pad_left, Ho, Wo
-T196_CASES = [
+SMALL_CASES = [
     (4, 7, 7, 32, 128, 1, 1, 0, 0, 7, 7),         # 1x1, one K-tile (the peeled tail alone)
     (4, 7, 7, 64, 64, 1, 1, 0, 0, 7, 7),          # 1x1, two K-tiles, 64 columns (K split)
     (8, 7, 7, 96, 96, 1, 1, 0, 0, 7, 7),          # three K-tiles, ragged N (96 = 64 + 32)
@@ -39,6 +40,23 @@ T196_CASES = [
     (2, 14, 28, 64, 256, 3, 1, 1, 1, 14, 28),     # H != W, two column tiles
     (16, 7, 7, 512, 512, 3, 1, 1, 1, 7, 7),       # the late 3x3 of ResNet-50 (16 channel blocks)
     (4, 14, 14, 256, 256, 3, 1, 1, 1, 14, 14),    # the group-3 3x3
+]
+
+
+# Ping-pong body (convpp.hpp): prologue / tail branches by K-tile count, row tails, strides, column widths
+PP_CASES = [
+    (2, 14, 14, 64, 256, 1, 1, 0, 0, 14, 14),     # one K-tile, 392 rows (a ragged second 256-row tile)
+    (2, 14, 14, 128, 256, 1, 1, 0, 0, 14, 14),    # two K-tiles
+    (3, 14, 14, 192, 128, 1, 1, 0, 0, 14, 14),    # three K-tiles, 128 columns, 588 rows
+    (4, 7, 7, 320, 256, 1, 1, 0, 0, 7, 7),        # five K-tiles, 196 rows (only the 128-row tile is legal)
+    (2, 14, 14, 448, 512, 1, 1, 0, 0, 14, 14),    # seven K-tiles, two column tiles
+    (2, 14, 14, 64, 256, 3, 1, 1, 1, 14, 14),     # 3x3: nine K-tiles, image borders in every tile
+    (2, 28, 28, 64, 128, 3, 2, 1, 1, 14, 14),     # 3x3 stride 2 forward (fixed padding)
+    (2, 14, 14, 64, 256, 3, 2, 0, 0, 7, 7),       # 3x3 stride 2, TF SAME on an even size (pad 0 top/left, 1 bottom/right)
+    (1, 16, 20, 128, 384, 3, 1, 1, 1, 16, 20),    # H != W, 384 columns (128-wide tiles only)
+    (2, 9, 9, 64, 512, 3, 1, 1, 1, 9, 9),         # odd sizes, 162 rows
+    (3, 14, 14, 256, 256, 3, 1, 1, 1, 14, 14),    # 36 K-tiles: steady state of the ring
+    (2, 28, 28, 512, 256, 1, 2, 0, 0, 14, 14),    # 1x1 stride 2 forward
 ]
 
 
@@ -76,7 +94,20 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
   n = w.numel()
   hwio = torch.empty(n, dtype=torch.bfloat16, device=DEV)
   ohwi = torch.empty(n, dtype=torch.bfloat16, device=DEV)
-  ops.pack_weights(w.reshape(-1).contiguous(), None, k * k * Cin, Cout, hwio, ohwi)
+  # every second case packs through a 1-bit mask (80 % of the weights off, as in the benchmarked ERK layers): the bf16
+  # shadows must be exactly bf16(mask * w) in both layouts -- pack -> conv is pinned at these shapes, not only in situ
+  mask_bits = None
+  wflat = w.reshape(-1).contiguous()
+  if seed % 2 == 1:
+    m01 = (torch.rand(n, generator=g, device=DEV) < 0.2).float()
+    mask_bits = ops.mask_pack(m01)
+    expect = (wflat * m01).to(torch.bfloat16)
+  else:
+    expect = wflat.to(torch.bfloat16)
+  ops.pack_weights(wflat, mask_bits, k * k * Cin, Cout, hwio, ohwi)
+  assert torch.equal(hwio.view(torch.int16), expect.view(torch.int16)), 'pack: HWIO shadow != bf16(mask * w)'
+  assert torch.equal(ohwi.view(torch.int16).reshape(Cout, k * k * Cin),
+                     expect.view(torch.int16).reshape(k * k * Cin, Cout).t()), 'pack: OHWI shadow != transpose of the HWIO shadow'
   wm = hwio.float().reshape(k, k, Cin, Cout)
   d = ops.conv_desc(N, H, W, Cin, Cout, k, k, stride, pt, pl, Ho, Wo)
   has_dx = Cin % 8 == 0
@@ -98,7 +129,7 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
       assert float((s[0] - yf.sum(0)).abs().max()) <= tol0, 'statistics: sum y'
       q = (yf * yf).sum(0)
       assert float(((s[1] - q).abs() / (q.abs() + 1e-6)).max()) <= 2e-6, 'statistics: sum y^2'
-      rows = 128 if part.shape[0] == (yf.shape[0] + 127) // 128 else 196      # igemm: 128-row tiles; tile196: 196
+      rows = 128                                     # one partial per 128 output rows, whatever the tile
       assert part.shape[0] == (yf.shape[0] + rows - 1) // rows
       t = min(part.shape[0] - 1, 1)
       blk = yf[t * rows:(t + 1) * rows]
@@ -132,11 +163,11 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
 
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument('--set', default='t196', choices=['t196', 'resnet50'])
+  ap.add_argument('--set', default='small', choices=['small', 'pp', 'resnet50'])
   ap.add_argument('--batch', type=int, default=128)
   ap.add_argument('--only', type=int, default=-1)
   a = ap.parse_args()
-  cases = T196_CASES if a.set == 't196' else resnet50_shapes(a.batch)
+  cases = SMALL_CASES if a.set == 'small' else (PP_CASES if a.set == 'pp' else resnet50_shapes(a.batch))
   worst, n = 0.0, 0
   for i, c in enumerate(cases):
     if a.only >= 0 and i != a.only:

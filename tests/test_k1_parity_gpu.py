@@ -26,23 +26,39 @@ def _run(args, env=None, timeout=1500):
   return out
 
 
+PP_SETTINGS = [
+    {},                                                                          # the built-in selection rules
+    {'RIGL_PP_FWD': '1', 'RIGL_PP_DGRAD': '1'},                                  # 256x256 wherever legal (two phases per K-tile)
+    {'RIGL_PP_FWD': '2', 'RIGL_PP_DGRAD': '2'},                                  # 128x256 (one phase, three stages)
+    {'RIGL_PP_FWD': '3', 'RIGL_PP_DGRAD': '3'},                                  # 256x128
+    {'RIGL_PP_FWD': '4', 'RIGL_PP_DGRAD': '4'},                                  # 512x128
+    {'RIGL_PP_FWD': '1', 'RIGL_PP_DGRAD': '2', 'RIGL_PP_PH': '4'},               # the four-phase schedule of both wave tiles
+    {'RIGL_PP_FWD': '0', 'RIGL_PP_DGRAD': '0'},                                  # the igemm body everywhere
+]
+
+
 @pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
-@pytest.mark.parametrize('env', [
-    {'RIGL_T196': '2', 'RIGL_C3': '2', 'RIGL_W9': '1'},     # every new kernel wherever its shape is legal (fwd, dgrad, wgrad)
-    {'RIGL_T196': '1', 'RIGL_C3': '1'},                     # the forward-only selection rules
-    {},                                                     # the defaults
-])
-def test_tile196_shapes(env):
-  out = _run(['--set', 't196'], env)
+@pytest.mark.parametrize('env', PP_SETTINGS)
+def test_small_shapes(env):
+  out = _run(['--set', 'small'], env)
   assert out['cases'] == 12
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
-@pytest.mark.parametrize('env', [{}, {'RIGL_T196': '2', 'RIGL_C3': '2'}])
+@pytest.mark.parametrize('env', PP_SETTINGS[:6])
+def test_pingpong_edge_shapes(env):
+  """1 .. 36 K-tiles (every prologue / tail branch of the ring), ragged row tiles, stride-2 forwards, TF-SAME asymmetric
+  padding, 128- / 256-wide column tiles -- each ping-pong tile forced wherever it is legal, against the fp64 reference."""
+  out = _run(['--set', 'pp'], env)
+  assert out['cases'] == 12
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
+@pytest.mark.parametrize('env', PP_SETTINGS[:3] + PP_SETTINGS[4:5])
 def test_resnet50_layer_shapes_at_batch_128(env):
   """All distinct ResNet-50 conv shapes at the benchmarked per-GPU batch: fwd, fwd + statistics,
-  dgrad, dgrad + addend, wgrad and the one-call backward, under the default kernel selection and with the tile196 / 3x3
-  slab kernels forced wherever legal -- so the 256x128 forward tile, the parity-class strided dgrad, tile196, the slab
-  kernel and the shared-launch split plans are each pinned directly against the fp64 reference at the benchmarked sizes."""
+  dgrad, dgrad + addend, wgrad and the one-call backward, under the default kernel selection (the ping-pong body on the
+  long-reduction forwards) and with each ping-pong tile forced wherever legal, forward and dgrad -- so every kernel that
+  can run in the step is pinned directly against the fp64 reference at the benchmarked sizes."""
   out = _run(['--set', 'resnet50', '--batch', '128'], env, timeout=3000)
   assert out['cases'] == 23
