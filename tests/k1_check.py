@@ -101,7 +101,7 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
   if seed % 2 == 1:
     m01 = (torch.rand(n, generator=g, device=DEV) < 0.2).float()
     mask_bits = ops.mask_pack(m01)
-    expect = (wflat * m01).to(torch.bfloat16)
+    expect = torch.where(m01 > 0, wflat, torch.zeros_like(wflat)).to(torch.bfloat16)   # (+0 where masked, not -0)
   else:
     expect = wflat.to(torch.bfloat16)
   ops.pack_weights(wflat, mask_bits, k * k * Cin, Cout, hwio, ohwi)
