@@ -740,6 +740,7 @@ struct WgradArgs {
   int x_pix_stride;    // elements between consecutive pixels of X (== Cin except on the tiny-Cin path)
   int fold;            // > 0 (k_wgrad_tr only): the KH taps are folded into the channel axis, `fold` channels per
                        // tap -- channel c of the GEMM is tap c / fold, input channel c % fold (KW == 1, Cin = taps*fold)
+  FastDiv fd_wo, fd_ho;   // (ping-pong body only) launch-time divisors of the output-pixel decomposition
 };
 
 template <int TM, int TN>
@@ -1397,7 +1398,6 @@ static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, int bk, b
 struct IgemmPlan { bool wide_n, dma, w4, cls, big; int bk; unsigned grid; };
 
 static int num_cus();
-#include "convpp.hpp"
 // The 512-thread kernel needs 72 KB of dynamic LDS: opt in once; if the runtime refuses, the plan never picks it.
 template <int MODE>
 static bool big_tile_ready() {
@@ -1504,6 +1504,8 @@ static int check_desc(const RiglConvDesc* d, const char* who) {
 static inline bool small_cin(const RiglConvDesc* d) { return (d->cin % 8) != 0 && d->cin > 4; }
 static inline int kpad(const RiglConvDesc* d) { return (d->kh * d->kw * d->cin + 31) / 32 * 32; }
 
+#include "convpp.hpp"
+
 struct WgradPlan { int tm, tn, tiles_ci, tiles_co, splits; int64_t slab; };
 // DMA ring depth of the tr kernel: 3 stages for the 128x128 tile (48 KB -> 3 workgroups/CU),
 // 4 for the smaller tiles (measured per layer; RIGL_WGRAD_STAGES=3|4 forces one).
@@ -1599,7 +1601,12 @@ size_t rigl_conv2d_workspace_bytes(const RiglConvDesc* d, int32_t which) {
   }
   if (which == 2) {
     WgradPlan p = plan_wgrad((int)M, d->cin, d->cout, d->kh * d->kw);
-    return p.splits > 1 ? align_up((size_t)p.splits * p.slab * 4, 256) : 0;
+    size_t need = p.splits > 1 ? align_up((size_t)p.splits * p.slab * 4, 256) : 0;
+    if (pp_wgrad_legal(d)) {                // the ping-pong weight gradient has its own split plans; the buffer serves any
+      const size_t npp = align_up((size_t)pp_wgrad_max_splits(d) * p.slab * 4, 256);
+      if (npp > need) need = npp;
+    }
+    return need;
   }
   return 0;
 }
@@ -1763,6 +1770,17 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   const size_t need = rigl_conv2d_workspace_bytes(d, 2);
   if (need && (!workspace || workspace_bytes < need)) return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
   ProfFamily prof(PROF_CONV_WGRAD);
+  if (!tiny_cin(d) && !small_cin(d) && pp_wgrad_legal(d) && tune_get("pp_wgrad", -1) > 0 && pp_wgrad_ready()) {
+    const PPBwdPlan pw = plan_wgrad_pp(d, 0u, 0);
+    const WgradArgs aw = pp_wgrad_args(d, x, dy, pw, dw, workspace);
+    RIGL_K_LAUNCH((k_wgrad_pp<2>), dim3(pw.nw), dim3(512), (PPGeom<2, 4, 4, 2, 2>::SMEM), st, aw);
+    if (pw.splits > 1) {
+      ReduceArgs ra = {static_cast<const float*>(workspace), dw, pw.slab, pw.slab, pw.splits};
+      launch_wgrad_reduce(ra, st);
+    }
+    RIGL_CHECK_LAUNCH("rigl_masked_conv2d_wgrad");
+    return RIGL_OK;
+  }
   WgradArgs a = {};
   a.DY = dy; a.M = d->n * d->ho * d->wo; a.Cout = d->cout;
   a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
@@ -1890,6 +1908,43 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
   if (dx && (d->cin % 8) == 0 && (d->cout % 8) == 0 && !bn) {
     const IgemmArgs ap = dgrad_args(d, dy, w_hwio, addend, dx);
     dgrad_pp = plan_pp<1>(ap).variant != 0;
+  }
+  // The shared launch on the 8-wave ping-pong bodies ("pp_bwd"): layers whose weight gradient has 256-channel tiles and
+  // whose dgrad is a stride-1 long reduction.
+  const int pp_bwd = tune_get("pp_bwd", -1);
+  if (pp_bwd > 0 && dx && x && dy && w_hwio && dw && !bn && !tiny_cin(d) && !small_cin(d) && pp_wgrad_legal(d)) {
+    IgemmArgs ad = dgrad_args(d, dy, w_hwio, addend, dx);
+    const int dvar = tune_get("pp_dgrad", -1) >= 0 ? PP_NONE : pp_bwd_dgrad_variant(ad);   // (a forced stand-alone dgrad tile wins)
+    if (dvar != PP_NONE && pp_legal<1>(ad, dvar)) {
+      PPPlan pd = {dvar, 0u, 0, 0};
+      pp_dims(dvar, pd.bm, pd.bn);
+      pd.grid = (unsigned)(((ad.M + pd.bm - 1) / pd.bm) * (ad.N / pd.bn));
+      const int kt_d = d->kh * d->kw * (d->cout / 64) / (dvar == PP_128x256 ? 2 : 1);   // in 256x256-tile K-tile units
+      const PPBwdPlan pw = plan_wgrad_pp(d, pd.grid, kt_d);
+      const size_t need = rigl_conv2d_workspace_bytes(d, 2);
+      if (need && (!workspace || workspace_bytes < need))
+        return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
+      if (have_flush) { ProfFamily pf(PROF_CONV_BWD); launch_pending_reduce(flush, st); }
+      ProfFamily prof(PROF_CONV_BWD);
+      const WgradArgs aw = pp_wgrad_args(d, x, dy, pw, dw, workspace);
+      ad.fd_rw = make_fastdiv(ad.RW); ad.fd_rh = make_fastdiv(ad.RH);
+      ad.tiles_n = ad.N / pd.bn;
+      const bool ok = dvar == PP_128x256 ? pp_bwd_launch_one<2, 4, 2, 2, 1>(ad, aw, pw.nd, pw.nw, pw.wgrad_first, st)
+                                         : pp_bwd_launch_one<2, 4, 4, 2, 2>(ad, aw, pw.nd, pw.nw, pw.wgrad_first, st);
+      if (ok) {
+        if (pw.splits > 1) {
+          if (defer) {
+            defer->slabs = static_cast<const float*>(workspace); defer->dw = dw; defer->n_out = pw.slab;
+            defer->slab_elems = pw.slab; defer->splits = pw.splits;
+          } else {
+            ReduceArgs ra = {static_cast<const float*>(workspace), dw, pw.slab, pw.slab, pw.splits};
+            launch_wgrad_reduce(ra, st);
+          }
+        }
+        RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");
+        return RIGL_OK;
+      }
+    }
   }
   if (fuse && !dgrad_pp && dx && x && dy && w_hwio && dw && !tiny_cin(d) && !small_cin(d) && (d->cin % 8) == 0 && (d->cout % 8) == 0 &&
       wgrad_use_tr() && conv_dma_stages() == 3) {

@@ -52,21 +52,31 @@ struct PPGeom {
   static_assert(SMEM <= 160 * 1024, "LDS per CU");
 };
 
+#define PP_BARRIER()                                                                                     \
+  {                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    asm volatile("" ::: "memory");                                                                       \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    asm volatile("" ::: "memory");                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  }
+// read segments that end with this wait retire their fragment reads BEFORE the barrier: the slot may be re-filled by
+// the other wave group in the very next barrier interval
+#define PP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
 struct PPCursor { int tap, cb, r, s; };
 
 template <int WM, int WN, int TM, int TN, int PH, int MODE /*0 fwd, 1 dgrad (stride 1)*/>
-__global__ __launch_bounds__(512) void k_igemm_pp(IgemmArgs P) {
+__device__ __forceinline__ void pp_igemm_body(const IgemmArgs& P, unsigned char* const smem, uint32_t bid, uint32_t nblk) {
   using G = PPGeom<WM, WN, TM, TN, PH>;
   constexpr int BM = G::BM, BN = G::BN, NA = G::NA, NB = G::NB, QM = G::QM, QN = G::QN;
   constexpr int STAGE = G::STAGE, AH_BYTES = G::AH_BYTES, BH_BYTES = G::BH_BYTES;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_pp[];
-  unsigned char* const smem = smem_pp;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int grp = wave >> 2;                 // waves w and w + 4 share a SIMD: one of each group per SIMD
-  const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t tile = xcd_remap(bid, nblk);
   const int tile_m = (int)(tile / (uint32_t)P.tiles_n);
   const int n0 = (int)(tile % (uint32_t)P.tiles_n) * BN;
   const int m0 = tile_m * BM;
@@ -119,6 +129,8 @@ __global__ __launch_bounds__(512) void k_igemm_pp(IgemmArgs P) {
   const int KT = taps * kcb;
   const int a_row_step = (MODE == 0 ? P.GW : -P.GW) * P.a_pix_stride, a_col_step = (MODE == 0 ? 1 : -1) * P.a_pix_stride;
 
+#define PP_CURSOR_T PPCursor
+#define PP_CURSOR_ZERO(c_) { (c_).tap = 0; (c_).cb = 0; (c_).r = 0; (c_).s = 0; }
 #define PP_NEXT(c_) { if (++(c_).cb == kcb) { (c_).cb = 0; ++(c_).tap; if (++(c_).s == P.KW) { (c_).s = 0; ++(c_).r; } } }
 #define PP_ISSUE_A(h_, stage_, c_)                                                                       \
   {                                                                                                      \
@@ -177,156 +189,19 @@ __global__ __launch_bounds__(512) void k_igemm_pp(IgemmArgs P) {
       _Pragma("unroll") for (int j = 0; j < QN; ++j)                                                     \
         acc[(ha_) * QM + i][(hb_) * QN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                   \
             bsrc_[j][ks], af[(ab_) + i][ks], acc[(ha_) * QM + i][(hb_) * QN + j], 0, 0, 0);
-#define PP_BARRIER()                                                                                     \
-  {                                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    asm volatile("" ::: "memory");                                                                       \
-    __builtin_amdgcn_s_barrier();                                                                        \
-    asm volatile("" ::: "memory");                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-  }
-  // read segments that end with this wait retire their fragment reads BEFORE the barrier: the slot may be re-filled by
-  // the other wave group in the very next barrier interval
-#define PP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
   // loads that may stay in flight behind a wait = the youngest pieces of the issue order (any four consecutive pieces
   // are two A and two B halves)
   constexpr int W4 = 2 * NA + 2 * NB, W2 = NA + NB, W1 = NA;
 
-  PPCursor c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};     // tiles t + 1 and t + 2
-
-  if constexpr (PH == 4) {
-    // ---- prologue: pieces A0(0) B0(0) B1(0) A1(0) A0(1) B0(1) ------------------------------------------------------
-    PP_ISSUE_A(0, 0, c1); PP_ISSUE_B(0, 0, c1); PP_ISSUE_B(1, 0, c1); PP_ISSUE_A(1, 0, c1);
-    PP_NEXT(c1);
-    c2 = c1;
-    if (KT > 1) {
-      PP_ISSUE_A(0, 1, c1); PP_ISSUE_B(0, 1, c1);
-      PP_NEXT(c2);
-      wait_vmcnt<W4>();
-    } else {
-      wait_vmcnt<W2>();
-    }
-    PP_BARRIER();
-    if (grp == 1) PP_BARRIER();                      // the stagger: group 1 runs one barrier behind group 0
-    // one K-tile = four phases; S_ = its stage (compile-time), t_ its index
-#define PP_TILE4(S_, t_)                                                                                 \
-    {                                                                                                    \
-      const bool n1_ = (t_) + 1 < KT, n2_ = (t_) + 2 < KT;                                               \
-      /* phase 0: (A0, B0) */                                                                            \
-      PP_READ_A(0, S_, 0); PP_READ_B(b0, 0, S_);                                                         \
-      if (n1_) { PP_ISSUE_B(1, (S_) ^ 1, c1); wait_vmcnt<W4>(); } else { wait_vmcnt<W1>(); }             \
-      PP_BARRIER();                                                                                      \
-      __builtin_amdgcn_s_setprio(1); PP_QUAD(0, 0, b0, 0); __builtin_amdgcn_s_setprio(0);               \
-      PP_BARRIER();                                                                                      \
-      /* phase 1: (A0, B1) */                                                                            \
-      PP_READ_B(b1, 1, S_);                                                                              \
-      if (n1_) { PP_ISSUE_A(1, (S_) ^ 1, c1); wait_vmcnt<W4>(); } else { wait_vmcnt<0>(); }              \
-      PP_BARRIER();                                                                                      \
-      __builtin_amdgcn_s_setprio(1); PP_QUAD(0, 1, b1, 0); __builtin_amdgcn_s_setprio(0);               \
-      PP_BARRIER();                                                                                      \
-      /* phase 2: (A1, B1) -- phase 3 reads nothing new, so no wait here */                              \
-      PP_READ_A(1, S_, 0);                                                                               \
-      if (n2_) { PP_ISSUE_A(0, S_, c2); }                                                                \
-      PP_BARRIER();                                                                                      \
-      __builtin_amdgcn_s_setprio(1); PP_QUAD(1, 1, b1, 0); __builtin_amdgcn_s_setprio(0);               \
-      PP_BARRIER();                                                                                      \
-      /* phase 3: (A1, B0) */                                                                            \
-      if (n2_) { PP_ISSUE_B(0, S_, c2); wait_vmcnt<W4>(); } else if (n1_) { wait_vmcnt<W2>(); }          \
-      PP_BARRIER();                                                                                      \
-      __builtin_amdgcn_s_setprio(1); PP_QUAD(1, 0, b0, 0); __builtin_amdgcn_s_setprio(0);               \
-      PP_BARRIER();                                                                                      \
-      c1 = c2;                                                                                           \
-      PP_NEXT(c2);                                                                                       \
-    }
-    for (int t = 0; t < KT; t += 2) {
-      PP_TILE4(0, t);
-      if (t + 1 < KT) PP_TILE4(1, t + 1);
-    }
-#undef PP_TILE4
-  } else if constexpr (PH == 2) {
-    // ---- prologue: A0 B0 B1 (0), A1(0), A0 B0 B1 (1) --------------------------------------------------------------
-    PP_ISSUE_A(0, 0, c1); PP_ISSUE_B(0, 0, c1); PP_ISSUE_B(1, 0, c1); PP_ISSUE_A(1, 0, c1);
-    PP_NEXT(c1);
-    c2 = c1;
-    if (KT > 1) {
-      PP_ISSUE_A(0, 1, c1); PP_ISSUE_B(0, 1, c1); PP_ISSUE_B(1, 1, c1);
-      PP_NEXT(c2);
-      wait_vmcnt<W4>();
-    } else {
-      wait_vmcnt<W1>();
-    }
-    PP_BARRIER();
-    if (grp == 1) PP_BARRIER();
-#define PP_TILE2(S_, t_)                                                                                 \
-    {                                                                                                    \
-      const bool n1_ = (t_) + 1 < KT, n2_ = (t_) + 2 < KT;                                               \
-      /* phase A: (A0, B0) (A0, B1); re-fill A1 of the other stage (read last phase) */                  \
-      PP_READ_A(0, S_, 0); PP_READ_B(b0, 0, S_); PP_READ_B(b1, 1, S_);                                   \
-      if (n1_) { PP_ISSUE_A(1, (S_) ^ 1, c1); wait_vmcnt<W4>(); } else { wait_vmcnt<0>(); }              \
-      PP_LGKM0();                                                                                        \
-      PP_BARRIER();                                                                                      \
-      __builtin_amdgcn_s_setprio(1); PP_QUAD(0, 0, b0, 0); PP_QUAD(0, 1, b1, 0); __builtin_amdgcn_s_setprio(0); \
-      PP_BARRIER();                                                                                      \
-      /* phase B: (A1, B1) (A1, B0); re-fill A0 B0 B1 of this stage (read last phase) */                 \
-      PP_READ_A(1, S_, 0);                                                                               \
-      if (n2_) { PP_ISSUE_A(0, S_, c2); PP_ISSUE_B(0, S_, c2); PP_ISSUE_B(1, S_, c2); wait_vmcnt<W4>(); } \
-      else if (n1_) { wait_vmcnt<W1>(); }                                                                \
-      PP_LGKM0();                                                                                        \
-      PP_BARRIER();                                                                                      \
-      __builtin_amdgcn_s_setprio(1); PP_QUAD(1, 1, b1, 0); PP_QUAD(1, 0, b0, 0); __builtin_amdgcn_s_setprio(0); \
-      PP_BARRIER();                                                                                      \
-      c1 = c2;                                                                                           \
-      PP_NEXT(c2);                                                                                       \
-    }
-    for (int t = 0; t < KT; t += 2) {
-      PP_TILE2(0, t);
-      if (t + 1 < KT) PP_TILE2(1, t + 1);
-    }
-#undef PP_TILE2
-  } else {
-    // ---- PH == 1, three stages: prologue tiles 0 and 1 --------------------------------------------------------------
-    PP_ISSUE_A(0, 0, c1); PP_ISSUE_B(0, 0, c1); PP_ISSUE_B(1, 0, c1); PP_ISSUE_A(1, 0, c1);
-    PP_NEXT(c1);
-    c2 = c1;
-    if (KT > 1) {
-      PP_ISSUE_A(0, 1, c1); PP_ISSUE_B(0, 1, c1); PP_ISSUE_B(1, 1, c1); PP_ISSUE_A(1, 1, c1);
-      PP_NEXT(c2);
-      wait_vmcnt<W4>();
-    } else {
-      wait_vmcnt<0>();
-    }
-    PP_BARRIER();
-    if (grp == 1) PP_BARRIER();
-    // tile t: read everything, re-fill the stage tile t-1 used with tile t+2, wait for tile t+1
-#define PP_TILE1(S_, SN_, t_)                                                                            \
-    {                                                                                                    \
-      const bool n2_ = (t_) + 2 < KT;                                                                    \
-      PP_READ_A(0, S_, 0); PP_READ_A(1, S_, QM); PP_READ_B(b0, 0, S_); PP_READ_B(b1, 1, S_);             \
-      if (n2_) { PP_ISSUE_A(0, SN_, c2); PP_ISSUE_B(0, SN_, c2); PP_ISSUE_B(1, SN_, c2); PP_ISSUE_A(1, SN_, c2); wait_vmcnt<W4>(); } \
-      else { wait_vmcnt<0>(); }                                                                          \
-      PP_LGKM0();                                                                                        \
-      PP_BARRIER();                                                                                      \
-      __builtin_amdgcn_s_setprio(1);                                                                     \
-      PP_QUAD(0, 0, b0, 0); PP_QUAD(0, 1, b1, 0); PP_QUAD(1, 1, b1, QM); PP_QUAD(1, 0, b0, QM);          \
-      __builtin_amdgcn_s_setprio(0);                                                                     \
-      PP_BARRIER();                                                                                      \
-      PP_NEXT(c2);                                                                                       \
-    }
-    for (int t = 0; t < KT; t += 3) {
-      PP_TILE1(0, 2, t);
-      if (t + 1 < KT) PP_TILE1(1, 0, t + 1);
-      if (t + 2 < KT) PP_TILE1(2, 1, t + 2);
-    }
-#undef PP_TILE1
-  }
-  if (grp == 0) PP_BARRIER();                        // group 0 waits for group 1's last MFMA phase
+#include "convpp_loop.inc"
 #undef PP_READ_A
 #undef PP_READ_B
 #undef PP_QUAD
-#undef PP_LGKM0
 #undef PP_ISSUE_A
 #undef PP_ISSUE_B
 #undef PP_NEXT
+#undef PP_CURSOR_T
+#undef PP_CURSOR_ZERO
 
   // ---- epilogue ------------------------------------------------------------------------------------------------------
   // Every wave stages its own tile (half of its rows at a time) in a private LDS area and stores full 128-byte row
@@ -414,7 +289,177 @@ __global__ __launch_bounds__(512) void k_igemm_pp(IgemmArgs P) {
       if (unit * 128 < P.M) P.STATS[unit * 2 * P.N + (int64_t)k * P.N + n0 + col] = s;
     }
   }
-#undef PP_BARRIER
+}
+
+template <int WM, int WN, int TM, int TN, int PH, int MODE>
+__global__ __launch_bounds__(512) void k_igemm_pp(IgemmArgs P) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_pp[];
+  pp_igemm_body<WM, WN, TM, TN, PH, MODE>(P, smem_pp, blockIdx.x, gridDim.x);
+}
+
+// ---- weight gradient on the same skeleton ---------------------------------------------------------------------------------
+// dW[tap][ci][co] = sum over output pixels p of X[pixel(p, tap)][ci] * dY[p][co]  (dense fp32, sparse_optimizers_base.py:478-485
+// through autodiff): rows = 256 input channels, columns = 256 output channels of one filter tap, reduction = a range of
+// output pixels (split-K: the workgroup writes its partial tile into slab `split`, rigl::k1::launch_wgrad_reduce sums the
+// slabs in a fixed order).  Both operands are reduction(pixel)-major in memory, so the LDS pieces are [64 pixels][128
+// channels] images exactly as the DMA writes them and the fragments come out of ds_read_b64_tr_b16 (the k_wgrad_tr recipe:
+// lane j of a 16-lane group supplies the address of 4 channels of pixel j/4 and receives channel j for 4 pixels); 64-byte
+// quads of a pixel row are XORed with (pixel & 3) on the DMA's source side so the 4 pixel rows of a 32-lane pass sit in 4
+// different bank groups.  Piece A_h = channels {wave row 0, 1} x 64-channel half h of X, piece B_h = {wave column 0..3}
+// x 32-channel half h of dY.
+struct PPWCursor { int kt; int pa[2], pb[2]; };
+
+template <int PH>
+__device__ __forceinline__ void pp_wgrad_body(const WgradArgs& P, unsigned char* const smem, uint32_t bid, uint32_t nblk) {
+  constexpr int WN = 4, TM = 4, TN = 2;
+  using G = PPGeom<2, 4, 4, 2, PH>;
+  constexpr int NA = G::NA, NB = G::NB, QM = G::QM, QN = G::QN;
+  constexpr int STAGE = G::STAGE, AH_BYTES = G::AH_BYTES, BH_BYTES = G::BH_BYTES;
+  static_assert(NA == 2 && NB == 2 && QM == 2 && QN == 1, "256 x 256 tile, 64-pixel K-tiles");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int grp = wave >> 2;
+  uint32_t b = xcd_remap(bid, nblk);
+  const int tco = (int)(b % (uint32_t)P.tiles_co); b /= (uint32_t)P.tiles_co;
+  const int tci = (int)(b % (uint32_t)P.tiles_ci); b /= (uint32_t)P.tiles_ci;
+  const int taps = P.KH * P.KW;
+  const int tap = (int)(b % (uint32_t)taps), split = (int)(b / (uint32_t)taps);
+  const int r = tap / P.KW, s = tap - r * P.KW;
+  const int ci0 = tci * 256, co0 = tco * 256;
+  const int KT_all = (P.M + 63) >> 6;
+  const int kt_begin = (int)((int64_t)KT_all * split / P.splits);
+  const int KT = (int)((int64_t)KT_all * (split + 1) / P.splits) - kt_begin;
+
+  // DMA lanes: instruction jj of wave w fills pixel rows 4 * (jj*8 + w) .. +3 of a piece; lane l: pixel +(l >> 4), 16-byte
+  // slot l & 15, fetching channel chunk slot ^ ((pixel & 3) << 2)
+  const int px_lane = 4 * wave + (lane >> 4);                       // + 32 * jj
+  const int chunk = (lane & 15) ^ (((lane >> 4) & 3) << 2);
+  int chan_a[2], chan_b[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    chan_a[h] = ci0 + (chunk >> 3) * 128 + h * 64 + (chunk & 7) * 8;
+    chan_b[h] = co0 + (chunk >> 2) * 64 + h * 32 + (chunk & 3) * 8;
+  }
+  const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.X, P.x_bytes), rsrcB = make_rsrc(P.DY, P.dy_bytes);
+  const int hi0 = r - P.ph, wi0 = s - P.pw;
+
+#define PP_CURSOR_T PPWCursor
+#define PP_WCOMPUTE(c_)                                                                                  \
+  {                                                                                                      \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                   \
+      const int p_ = ((kt_begin + (c_).kt) << 6) + 32 * jj + px_lane;                                    \
+      const bool ok_ = p_ < P.M;                                                                         \
+      const int pp_ = ok_ ? p_ : 0;                                                                      \
+      const int t_ = fdiv(pp_, P.fd_wo);                                                                 \
+      const int wo_ = pp_ - t_ * P.Wo, n_ = fdiv(t_, P.fd_ho), ho_ = t_ - n_ * P.Ho;                     \
+      const int hi_ = ho_ * P.sh + hi0, wi_ = wo_ * P.sw + wi0;                                          \
+      const bool oka_ = ok_ && (unsigned)hi_ < (unsigned)P.H && (unsigned)wi_ < (unsigned)P.W;          \
+      (c_).pa[jj] = oka_ ? ((n_ * P.H + hi_) * P.W + wi_) * P.x_pix_stride : -1;                         \
+      (c_).pb[jj] = ok_ ? p_ * P.Cout : -1;                                                              \
+    }                                                                                                    \
+  }
+#define PP_CURSOR_ZERO(c_) { (c_).kt = 0; PP_WCOMPUTE(c_); }
+#define PP_NEXT(c_) { ++(c_).kt; PP_WCOMPUTE(c_); }
+#define PP_ISSUE_A(h_, stage_, c_)                                                                       \
+  {                                                                                                      \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                   \
+      const int off_ = (c_).pa[jj] >= 0 ? (int)((uint32_t)((c_).pa[jj] + chan_a[h_]) * 2u) : (int)OOB;   \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                          \
+          rsrcA, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + (h_) * AH_BYTES + (jj * 8 + wave) * 1024), \
+          16, off_, 0, 0, 0);                                                                            \
+    }                                                                                                    \
+  }
+#define PP_ISSUE_B(h_, stage_, c_)                                                                       \
+  {                                                                                                      \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                   \
+      const int off_ = (c_).pb[jj] >= 0 ? (int)((uint32_t)((c_).pb[jj] + chan_b[h_]) * 2u) : (int)OOB;   \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                          \
+          rsrcB, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + 2 * AH_BYTES + (h_) * BH_BYTES + (jj * 8 + wave) * 1024), \
+          16, off_, 0, 0, 0);                                                                            \
+    }                                                                                                    \
+  }
+
+  // transposing fragment reads: a 32-channel x 16-pixel operand fragment = two ds_read_b64_tr_b16 (pixels +0..3, +4..7 of
+  // the lane's 8); lane (g, j): pixel row 8 * (g >> 1) + (j >> 2), 16-byte chunk 2 * (g & 1) + ((j >> 1) & 1) of the
+  // fragment's four, bytes (j & 1) * 8; the row's quad swizzle (pixel & 3 = (j >> 2) & 3) moves the fragment's quad
+  const int g = lane >> 4, j16 = lane & 15, rs = (j16 >> 2) & 3;
+  const int tr_row = (8 * (g >> 1) + (j16 >> 2)) * 256, tr_low = ((2 * (g & 1) + ((j16 >> 1) & 1)) << 4) + (j16 & 1) * 8;
+  int a_tr[QM];
+#pragma unroll
+  for (int i = 0; i < QM; ++i) a_tr[i] = tr_row + ((((wm * 2 + i) ^ rs) * 4) << 4) + tr_low;
+  const int b_tr = tr_row + (((wn ^ rs) * 4) << 4) + tr_low;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
+  constexpr int AF = PH == 1 ? TM : QM;
+  bf16x8 af[AF][4], b0[QN][4], b1[QN][4];
+
+#define PP_READ_A(h_, stage_, ab_)                                                                       \
+  _Pragma("unroll") for (int i = 0; i < QM; ++i)                                                         \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                     \
+      af[(ab_) + i][ks] = lds_read_tr_pair(smem + (stage_) * STAGE + (h_) * AH_BYTES + a_tr[i] + ks * 4096,        \
+                                           smem + (stage_) * STAGE + (h_) * AH_BYTES + a_tr[i] + ks * 4096 + 1024);
+#define PP_READ_B(dst_, h_, stage_)                                                                      \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                       \
+    dst_[0][ks] = lds_read_tr_pair(smem + (stage_) * STAGE + 2 * AH_BYTES + (h_) * BH_BYTES + b_tr + ks * 4096,    \
+                                   smem + (stage_) * STAGE + 2 * AH_BYTES + (h_) * BH_BYTES + b_tr + ks * 4096 + 1024);
+  // D[ci][co]: the X fragment is the MFMA's first operand
+#define PP_QUAD(ha_, hb_, bsrc_, ab_)                                                                    \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                       \
+    _Pragma("unroll") for (int i = 0; i < QM; ++i)                                                       \
+      acc[(ha_) * QM + i][(hb_)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                              \
+          af[(ab_) + i][ks], bsrc_[0][ks], acc[(ha_) * QM + i][(hb_)], 0, 0, 0);
+  constexpr int W4 = 2 * NA + 2 * NB, W2 = NA + NB, W1 = NA;
+  (void)W2;
+#include "convpp_loop.inc"
+#undef PP_READ_A
+#undef PP_READ_B
+#undef PP_QUAD
+#undef PP_ISSUE_A
+#undef PP_ISSUE_B
+#undef PP_NEXT
+#undef PP_CURSOR_T
+#undef PP_CURSOR_ZERO
+#undef PP_WCOMPUTE
+
+  // partial tile -> slab `split` (or dW itself when the layer is not split): D row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+  // -> ci, column = lane & 31 -> co; 32 lanes store 128 contiguous bytes
+  float* const out = P.OUT + (int64_t)split * P.slab_elems + (int64_t)tap * P.Cin * P.Cout;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = ci0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int co = co0 + wn * 64 + jj * 32 + (lane & 31);
+        out[(int64_t)ci * P.Cout + co] = acc[i][jj][e];
+      }
+}
+
+template <int PH>
+__global__ __launch_bounds__(512) void k_wgrad_pp(WgradArgs P) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_pp[];
+  pp_wgrad_body<PH>(P, smem_pp, blockIdx.x, gridDim.x);
+}
+
+// One launch per layer backward: the split-K weight-gradient workgroups and the dgrad tiles of a layer share one grid -- two independent GEMMs that each leave CUs idle at batch 128 share the chip (the k_bwd_fused idea
+// on the 8-wave bodies).  dX is bit-identical to k_igemm_pp<..., 1> launched alone.
+template <int WMD, int WND, int TMD, int TND, int PHD>
+__global__ __launch_bounds__(512) void k_bwd_pp(IgemmArgs PD, WgradArgs PW, uint32_t nd, uint32_t nw, uint32_t wgrad_first) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_pp[];
+  // longest jobs first: whichever body has the longer reduction per workgroup takes the low block indices
+  const uint32_t b = blockIdx.x;
+  const bool is_w = wgrad_first ? b < nw : b >= nd;
+  if (is_w) pp_wgrad_body<2>(PW, smem_pp, wgrad_first ? b : b - nd, nw);
+  else pp_igemm_body<WMD, WND, TMD, TND, PHD, 1>(PD, smem_pp, wgrad_first ? b - nw : b, nd);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -464,6 +509,16 @@ static bool pp_legal(const IgemmArgs& a, int variant) {
   return true;
 }
 
+// Which ping-pong tile the shared backward launch gives this layer's dgrad (PP_NONE: the layer's backward stays on the
+// igemm / tr bodies).  `a` = the dgrad GEMM (N = cin, Cred = cout, gathered tensor = dY).
+static int pp_bwd_dgrad_variant(const IgemmArgs& a) {
+  const int pp_bwd = tune_get("pp_bwd", -1);
+  if (pp_bwd <= 0) return PP_NONE;
+  const int64_t m_out = (int64_t)(a.M / (a.RH * a.RW)) * a.GH * a.GW;
+  if (a.N % 256 || a.Cred % 256 || m_out < 256 || a.KH * a.KW > 32 || a.BNX) return PP_NONE;
+  return pp_bwd == 2 ? PP_128x256 : PP_256x256;
+}
+
 template <int MODE>
 static PPPlan plan_pp(const IgemmArgs& a) {
   PPPlan p = {PP_NONE, 0u, 0, 0};
@@ -481,8 +536,9 @@ static PPPlan plan_pp(const IgemmArgs& a) {
       else if (a.N % 128 == 0) v = (int64_t)((a.M + 511) / 512) * (a.N / 128) >= fill ? PP_512x128 : PP_256x128;
     }
   }
-  // (dgrad: the shared backward launch -- dgrad tiles next to the split-K weight-gradient workgroups -- still beats a
-  //  stand-alone ping-pong dgrad plus a stand-alone wgrad on most layers, so there is no built-in dgrad rule yet)
+  // dgrad: a layer's dX comes from ONE kernel whichever entry point computes it, so the stand-alone dgrad follows the
+  // shared backward launch's choice ("pp_bwd", below): the ping-pong dgrad where that launch runs on the 8-wave bodies.
+  else v = pp_bwd_dgrad_variant(a);
   if (v == PP_NONE || !pp_legal<MODE>(a, v)) return p;
   pp_dims(v, p.bm, p.bn);
   p.variant = v;
@@ -512,3 +568,83 @@ static bool launch_pp(const PPPlan& p, const IgemmArgs& a0, hipStream_t st) {
   }
 }
 
+// ---- backward on the ping-pong bodies -------------------------------------------------------------------------------------
+// Knobs: "pp_wgrad" (stand-alone weight gradient: -1 rule, 0 never, 1 wherever legal), "pp_bwd" (the shared launch:
+// -1 rule, 0 never, 1 dgrad on 256x256 tiles, 2 dgrad on 128x256 tiles).
+struct PPBwdPlan {
+  bool use;
+  PPPlan pd;            // the dgrad half (variant 0: weight gradient only)
+  int tiles_ci, tiles_co, splits;
+  int64_t slab;         // elements of one partial slab = the whole dW
+  unsigned nd, nw;
+  bool wgrad_first;
+};
+
+static inline bool pp_wgrad_legal(const RiglConvDesc* d) {
+  const int64_t M = (int64_t)d->n * d->ho * d->wo;
+  return d->cin % 256 == 0 && d->cout % 256 == 0 && M >= 256 && d->kh * d->kw <= 32;
+}
+// Upper bound of the split count of any ping-pong weight-gradient plan (the workspace is sized for it): at least 256
+// pixels per split, at most two rounds of workgroups, at most 64 MB of slabs.
+static inline int pp_wgrad_max_splits(const RiglConvDesc* d) {
+  const int64_t M = (int64_t)d->n * d->ho * d->wo, kt_all = (M + 63) / 64;
+  const int64_t base = (int64_t)d->kh * d->kw * (d->cin / 256) * (d->cout / 256);
+  const int64_t dw_bytes = (int64_t)d->kh * d->kw * d->cin * d->cout * 4;
+  int64_t s = kt_all / 4;
+  const int64_t by_slots = (2 * (int64_t)num_cus() + base - 1) / base, by_bytes = (64ll << 20) / dw_bytes;
+  if (s > by_slots) s = by_slots;
+  if (s > by_bytes) s = by_bytes;
+  return (int)(s < 1 ? 1 : s);
+}
+
+// nd = dgrad workgroups that share the launch (0: stand-alone weight gradient)
+static PPBwdPlan plan_wgrad_pp(const RiglConvDesc* d, unsigned nd, int kt_d) {
+  PPBwdPlan p = {};
+  p.tiles_ci = d->cin / 256; p.tiles_co = d->cout / 256;
+  p.slab = (int64_t)d->kh * d->kw * d->cin * d->cout;
+  const int64_t M = (int64_t)d->n * d->ho * d->wo, kt_all = (M + 63) / 64;
+  const int64_t base = (int64_t)d->kh * d->kw * p.tiles_ci * p.tiles_co, cus = num_cus();
+  // whole rounds of one workgroup per CU, with room for at least `base` (and a quarter of a round of) weight-gradient
+  // workgroups behind the dgrad tiles
+  const int64_t room = base > cus / 4 ? base : cus / 4;
+  const int64_t slots = ((int64_t)nd + room + cus - 1) / cus * cus;
+  int64_t s = (slots - (int64_t)nd) / base;
+  const int smax = pp_wgrad_max_splits(d);
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  p.splits = (int)s;
+  p.nd = nd; p.nw = (unsigned)(base * s);
+  p.wgrad_first = (int)(kt_all / s) >= kt_d;          // longest jobs first
+  p.use = true;
+  return p;
+}
+
+static WgradArgs pp_wgrad_args(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const PPBwdPlan& p, float* dw,
+                               void* workspace) {
+  WgradArgs a = {};
+  a.X = x; a.DY = dy; a.M = d->n * d->ho * d->wo; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw;
+  a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
+  a.tiles_ci = p.tiles_ci; a.tiles_co = p.tiles_co; a.splits = p.splits; a.slab_elems = p.slab;
+  a.x_bytes = (uint32_t)((size_t)d->n * d->h * d->w * d->cin * 2);
+  a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
+  a.x_pix_stride = d->cin;
+  a.fd_wo = make_fastdiv(d->wo); a.fd_ho = make_fastdiv(d->ho);
+  a.OUT = p.splits > 1 ? static_cast<float*>(workspace) : dw;
+  return a;
+}
+
+static bool pp_wgrad_ready() {
+  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_pp<2>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                PPGeom<2, 4, 4, 2, 2>::SMEM) == hipSuccess;
+  return ready;
+}
+template <int WMD, int WND, int TMD, int TND, int PHD>
+static bool pp_bwd_launch_one(const IgemmArgs& ad, const WgradArgs& aw, unsigned nd, unsigned nw, bool wgrad_first, hipStream_t st) {
+  constexpr int SM_D = PPGeom<WMD, WND, TMD, TND, PHD>::SMEM, SM_W = PPGeom<2, 4, 4, 2, 2>::SMEM, SM = SM_D > SM_W ? SM_D : SM_W;
+  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_pp<WMD, WND, TMD, TND, PHD>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, SM) == hipSuccess;
+  if (!ready) return false;
+  RIGL_K_LAUNCH((k_bwd_pp<WMD, WND, TMD, TND, PHD>), dim3(nd + nw), dim3(512), SM, st, ad, aw, nd, nw, (uint32_t)(wgrad_first ? 1u : 0u));
+  return true;
+}

@@ -67,6 +67,61 @@ def compare(a, b):
   return n / af.numel(), rel
 
 
+def bwd_rows(a, rep, name, B, H, W, Cin, Cout, k, s, pt, pl, Ho, Wo, macs, x, dy, hwio, add):
+  """The one-call backward (pp_bwd 0 / 1 / 2) and the stand-alone weight gradient (pp_wgrad 0 / 1): dW against the
+  igemm / tr kernels' (fp32 reassociation: relative to max |dW|), dX bit-equal to the stand-alone dgrad of the same
+  setting, run-to-run bit determinism of dW; then the timings (backward time includes the split-K reduce launch)."""
+  n = k * k * Cin * Cout
+  has_dx = Cin % 8 == 0
+  for ps, key, vals in (('bwd', 'pp_bwd', (0, 1, 2)), ('wgrad', 'pp_wgrad', (0, 1))):
+    if ps not in a.passes:
+      continue
+    line = '%-20s B%-4d %-5s' % (name, B, ps)
+    ref_dw = None
+    for v in vals:
+      ops.tune_set('pp_fwd', 0); ops.tune_set('pp_dgrad', -1); ops.tune_set('pp_bwd', 0); ops.tune_set('pp_wgrad', 0)
+      ops.tune_set(key, v)
+      d = ops.conv_desc(B, H, W, Cin, Cout, k, k, s, pt, pl, Ho, Wo)
+      try:
+        dw = torch.empty(n, dtype=torch.float32, device=DEV)
+        if ps == 'bwd':
+          dx = ops.conv_bwd(d, x, dy, hwio, dw, need_dx=has_dx, addend=add if has_dx else None)
+          ops.flush_pending_wgrad()
+          run = lambda: (ops.conv_bwd(d, x, dy, hwio, dw, need_dx=has_dx, addend=add if has_dx else None), ops.flush_pending_wgrad())
+        else:
+          ops.conv_wgrad(d, x, dy, dw)
+          dx = None
+          run = lambda: ops.conv_wgrad(d, x, dy, dw)
+        torch.cuda.synchronize()
+        bad = ''
+        if ref_dw is None:
+          ref_dw = dw.clone()
+        else:
+          e = (dw - ref_dw).abs().max().item() / (ref_dw.abs().max().item() + 1e-12)
+          if not e < 2e-5:
+            bad += ' BADDW(%.3g)' % e
+        if dx is not None:
+          dx2 = ops.conv_dgrad(d, dy, hwio, addend=add)
+          if not torch.equal(dx.view(torch.int16), dx2.view(torch.int16)):
+            bad += ' BADDX(%d)' % int((dx.float() != dx2.float()).sum())
+        dw2 = torch.empty_like(dw)
+        if ps == 'bwd':
+          ops.conv_bwd(d, x, dy, hwio, dw2, need_dx=has_dx, addend=add if has_dx else None)
+          ops.flush_pending_wgrad()
+        else:
+          ops.conv_wgrad(d, x, dy, dw2)
+        if not torch.equal(dw.view(torch.int32), dw2.view(torch.int32)):
+          bad += ' NONDET'
+        ms = timeit(run, a.iters)
+        tf = (4 if ps == 'bwd' and has_dx else 2) * macs / (ms * 1e-3) / 1e12
+        rep['rows'].append(dict(layer=name, batch=B, kind=ps, variant=v, ms=ms, tflops=tf, bad=bad))
+        line += ' | %s=%d %6.1f us %5.0f TF%s' % (key, v, ms * 1e3, tf, bad)
+      except Exception as ex:  # pylint: disable=broad-except
+        line += ' | %s=%d FAILED %s' % (key, v, repr(ex)[:80])
+    print(line, flush=True)
+  ops.tune_set('pp_bwd', -1); ops.tune_set('pp_wgrad', -1); ops.tune_set('pp_fwd', -1)
+
+
 DIMS = {1: (256, 256), 2: (128, 256), 3: (256, 128), 4: (512, 128)}
 
 
@@ -109,7 +164,9 @@ def main():
       ops.pack_weights(w.reshape(-1).contiguous(), None, k * k * Cin, Cout, hwio, ohwi)
       pt = pl = p
       ref = {}
-      for ps in a.passes:
+      if 'bwd' in a.passes or 'wgrad' in a.passes:
+        bwd_rows(a, rep, name, B, H, W, Cin, Cout, k, s, pt, pl, Ho, Wo, macs, x, dy, hwio, add)
+      for ps in [q for q in a.passes if q in ('fwd', 'dgrad')]:
         line = '%-20s B%-4d %-5s' % (name, B, ps)
         for v, ph in [(v, ph) for v in a.variants for ph in (a.ph if v else [0])]:
           if v and not legal(v, ps, B, H, W, Cin, Cout, s, Ho, Wo):
