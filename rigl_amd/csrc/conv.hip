@@ -1911,8 +1911,7 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
   }
   // The shared launch on the 8-wave ping-pong bodies ("pp_bwd"): layers whose weight gradient has 256-channel tiles and
   // whose dgrad is a stride-1 long reduction.
-  const int pp_bwd = tune_get("pp_bwd", -1);
-  if (pp_bwd > 0 && dx && x && dy && w_hwio && dw && !bn && !tiny_cin(d) && !small_cin(d) && pp_wgrad_legal(d)) {
+  if (tune_get("pp_bwd", -1) != 0 && dx && x && dy && w_hwio && dw && !bn && !tiny_cin(d) && !small_cin(d) && pp_wgrad_legal(d)) {
     IgemmArgs ad = dgrad_args(d, dy, w_hwio, addend, dx);
     const int dvar = tune_get("pp_dgrad", -1) >= 0 ? PP_NONE : pp_bwd_dgrad_variant(ad);   // (a forced stand-alone dgrad tile wins)
     if (dvar != PP_NONE && pp_legal<1>(ad, dvar)) {

@@ -513,10 +513,16 @@ static bool pp_legal(const IgemmArgs& a, int variant) {
 // igemm / tr bodies).  `a` = the dgrad GEMM (N = cin, Cred = cout, gathered tensor = dY).
 static int pp_bwd_dgrad_variant(const IgemmArgs& a) {
   const int pp_bwd = tune_get("pp_bwd", -1);
-  if (pp_bwd <= 0) return PP_NONE;
+  if (pp_bwd == 0) return PP_NONE;
   const int64_t m_out = (int64_t)(a.M / (a.RH * a.RW)) * a.GH * a.GW;
-  if (a.N % 256 || a.Cred % 256 || m_out < 256 || a.KH * a.KW > 32 || a.BNX) return PP_NONE;
-  return pp_bwd == 2 ? PP_128x256 : PP_256x256;
+  if (a.N % 256 || a.Cred % 256 || m_out < 256 || a.KH * a.KW > 32 || a.BNX || a.sh != 1 || a.sw != 1) return PP_NONE;
+  if (pp_bwd > 0) return pp_bwd == 2 ? PP_128x256 : PP_256x256;
+  // built-in rule (tools/pp_sweep.py --passes bwd, batch 128): dgrad reductions of >= 8 K-tiles; 256x256 dgrad tiles
+  // where they give at least ~1/3 of the CUs a tile, the 128-row tiles below that
+  const int kt_d = a.KH * a.KW * (a.Cred / 64);
+  if (kt_d < tune_get("pp_bwd_min_kt", 8)) return PP_NONE;
+  const int64_t nd256 = (int64_t)((a.M + 255) / 256) * (a.N / 256);
+  return nd256 >= 90 ? PP_256x256 : PP_128x256;
 }
 
 template <int MODE>
@@ -585,13 +591,14 @@ static inline bool pp_wgrad_legal(const RiglConvDesc* d) {
   return d->cin % 256 == 0 && d->cout % 256 == 0 && M >= 256 && d->kh * d->kw <= 32;
 }
 // Upper bound of the split count of any ping-pong weight-gradient plan (the workspace is sized for it): at least 256
-// pixels per split, at most two rounds of workgroups, at most 64 MB of slabs.
+// pixels per split, at most two rounds of workgroups, at most 40 MB of slabs.
 static inline int pp_wgrad_max_splits(const RiglConvDesc* d) {
   const int64_t M = (int64_t)d->n * d->ho * d->wo, kt_all = (M + 63) / 64;
   const int64_t base = (int64_t)d->kh * d->kw * (d->cin / 256) * (d->cout / 256);
   const int64_t dw_bytes = (int64_t)d->kh * d->kw * d->cin * d->cout * 4;
   int64_t s = kt_all / 4;
-  const int64_t by_slots = (2 * (int64_t)num_cus() + base - 1) / base, by_bytes = (64ll << 20) / dw_bytes;
+  // (every split is one more fp32 copy of dW written and read back: "pp_slab_mb" caps their total)
+  const int64_t by_slots = (2 * (int64_t)num_cus() + base - 1) / base, by_bytes = ((int64_t)tune_get("pp_slab_mb", 40) << 20) / dw_bytes;
   if (s > by_slots) s = by_slots;
   if (s > by_bytes) s = by_bytes;
   return (int)(s < 1 ? 1 : s);

@@ -143,7 +143,11 @@ def main():
   ap.add_argument('--passes', nargs='+', default=['fwd', 'dgrad'])
   ap.add_argument('--ph', type=int, nargs='+', default=[0], help='pp_ph settings to sweep: 0 = built-in phases, 4 = four phases')
   ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'pp_sweep.json'))
+  ap.add_argument('--knob', nargs='*', default=[], help='extra knobs for the whole run, key=value')
   a = ap.parse_args()
+  for kv in a.knob:
+    k_, v_ = kv.split('=')
+    ops.tune_set(k_, int(v_))
   rep = dict(mfma_peak_tflops=ops.mfma_peak_probe(DEV), rows=[])
   print('MFMA bf16 dense rate of this box: %.0f TFLOP/s' % rep['mfma_peak_tflops'], flush=True)
   for B in a.batch:
