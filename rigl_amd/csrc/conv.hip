@@ -1602,10 +1602,8 @@ size_t rigl_conv2d_workspace_bytes(const RiglConvDesc* d, int32_t which) {
   if (which == 2) {
     WgradPlan p = plan_wgrad((int)M, d->cin, d->cout, d->kh * d->kw);
     size_t need = p.splits > 1 ? align_up((size_t)p.splits * p.slab * 4, 256) : 0;
-    if (pp_wgrad_legal(d)) {                // the ping-pong weight gradient has its own split plans; the buffer serves any
-      const size_t npp = align_up((size_t)pp_wgrad_max_splits(d) * p.slab * 4, 256);
-      if (npp > need) need = npp;
-    }
+    const size_t npp = align_up(pp_wgrad_workspace(d), 256);   // the ping-pong weight gradients have their own split plans
+    if (npp > need) need = npp;
     return need;
   }
   return 0;
@@ -1770,16 +1768,17 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   const size_t need = rigl_conv2d_workspace_bytes(d, 2);
   if (need && (!workspace || workspace_bytes < need)) return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
   ProfFamily prof(PROF_CONV_WGRAD);
-  if (!tiny_cin(d) && !small_cin(d) && pp_wgrad_legal(d) && tune_get("pp_wgrad", -1) > 0 && pp_wgrad_ready()) {
-    const PPBwdPlan pw = plan_wgrad_pp(d, 0u, 0);
+  if (tune_get("pp_wgrad", -1) > 0 && pp_wgrad_kind(d) >= 0) {
+    const PPBwdPlan pw = plan_wgrad_pp(d, pp_wgrad_kind(d), 0u, 0);
     const WgradArgs aw = pp_wgrad_args(d, x, dy, pw, dw, workspace);
-    RIGL_K_LAUNCH((k_wgrad_pp<2>), dim3(pw.nw), dim3(512), (PPGeom<2, 4, 4, 2, 2>::SMEM), st, aw);
-    if (pw.splits > 1) {
-      ReduceArgs ra = {static_cast<const float*>(workspace), dw, pw.slab, pw.slab, pw.splits};
-      launch_wgrad_reduce(ra, st);
+    if (pp_wgrad_launch(pw, aw, st)) {
+      if (pw.splits > 1) {
+        ReduceArgs ra = {static_cast<const float*>(workspace), dw, pw.slab, pw.slab, pw.splits};
+        launch_wgrad_reduce(ra, st);
+      }
+      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_wgrad");
+      return RIGL_OK;
     }
-    RIGL_CHECK_LAUNCH("rigl_masked_conv2d_wgrad");
-    return RIGL_OK;
   }
   WgradArgs a = {};
   a.DY = dy; a.M = d->n * d->ho * d->wo; a.Cout = d->cout;
@@ -1911,15 +1910,15 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
   }
   // The shared launch on the 8-wave ping-pong bodies ("pp_bwd"): layers whose weight gradient has 256-channel tiles and
   // whose dgrad is a stride-1 long reduction.
-  if (tune_get("pp_bwd", -1) != 0 && dx && x && dy && w_hwio && dw && !bn && !tiny_cin(d) && !small_cin(d) && pp_wgrad_legal(d)) {
+  if (tune_get("pp_bwd", -1) != 0 && dx && x && dy && w_hwio && dw && !bn && pp_wgrad_kind(d) >= 0) {
     IgemmArgs ad = dgrad_args(d, dy, w_hwio, addend, dx);
     const int dvar = tune_get("pp_dgrad", -1) >= 0 ? PP_NONE : pp_bwd_dgrad_variant(ad);   // (a forced stand-alone dgrad tile wins)
     if (dvar != PP_NONE && pp_legal<1>(ad, dvar)) {
-      PPPlan pd = {dvar, 0u, 0, 0};
-      pp_dims(dvar, pd.bm, pd.bn);
-      pd.grid = (unsigned)(((ad.M + pd.bm - 1) / pd.bm) * (ad.N / pd.bn));
-      const int kt_d = d->kh * d->kw * (d->cout / 64) / (dvar == PP_128x256 ? 2 : 1);   // in 256x256-tile K-tile units
-      const PPBwdPlan pw = plan_wgrad_pp(d, pd.grid, kt_d);
+      int bm, bn;
+      pp_dims(dvar, bm, bn);
+      const unsigned nd = (unsigned)(((ad.M + bm - 1) / bm) * (ad.N / bn));
+      const int kt_d = (int)((int64_t)d->kh * d->kw * (d->cout / 64) * bm * bn / (256 * 256));   // in 256x256-tile K-tile units
+      const PPBwdPlan pw = plan_wgrad_pp(d, pp_wgrad_kind(d), nd, kt_d);
       const size_t need = rigl_conv2d_workspace_bytes(d, 2);
       if (need && (!workspace || workspace_bytes < need))
         return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
@@ -1927,10 +1926,8 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
       ProfFamily prof(PROF_CONV_BWD);
       const WgradArgs aw = pp_wgrad_args(d, x, dy, pw, dw, workspace);
       ad.fd_rw = make_fastdiv(ad.RW); ad.fd_rh = make_fastdiv(ad.RH);
-      ad.tiles_n = ad.N / pd.bn;
-      const bool ok = dvar == PP_128x256 ? pp_bwd_launch_one<2, 4, 2, 2, 1>(ad, aw, pw.nd, pw.nw, pw.wgrad_first, st)
-                                         : pp_bwd_launch_one<2, 4, 4, 2, 2>(ad, aw, pw.nd, pw.nw, pw.wgrad_first, st);
-      if (ok) {
+      ad.tiles_n = ad.N / bn;
+      if (pp_bwd_launch(dvar, pw.wk, ad, aw, pw, st)) {
         if (pw.splits > 1) {
           if (defer) {
             defer->slabs = static_cast<const float*>(workspace); defer->dw = dw; defer->n_out = pw.slab;

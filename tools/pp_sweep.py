@@ -73,13 +73,17 @@ def bwd_rows(a, rep, name, B, H, W, Cin, Cout, k, s, pt, pl, Ho, Wo, macs, x, dy
   setting, run-to-run bit determinism of dW; then the timings (backward time includes the split-K reduce launch)."""
   n = k * k * Cin * Cout
   has_dx = Cin % 8 == 0
-  for ps, key, vals in (('bwd', 'pp_bwd', (0, 1, 2)), ('wgrad', 'pp_wgrad', (0, 1))):
+  for ps, key, vals in (('bwd', 'pp_bwd', ((0, 0), (1, 0), (2, 0), (1, 1), (2, 1))), ('wgrad', 'pp_wgrad', ((0, 0), (1, 0), (1, 1)))):
     if ps not in a.passes:
       continue
     line = '%-20s B%-4d %-5s' % (name, B, ps)
     ref_dw = None
-    for v in vals:
+    for v, wk in vals:
+      t = 128 if wk else 256
+      if v and (Cin % t or Cout % t):
+        continue
       ops.tune_set('pp_fwd', 0); ops.tune_set('pp_dgrad', -1); ops.tune_set('pp_bwd', 0); ops.tune_set('pp_wgrad', 0)
+      ops.tune_set('pp_wk', wk)
       ops.tune_set(key, v)
       d = ops.conv_desc(B, H, W, Cin, Cout, k, k, s, pt, pl, Ho, Wo)
       try:
@@ -114,12 +118,12 @@ def bwd_rows(a, rep, name, B, H, W, Cin, Cout, k, s, pt, pl, Ho, Wo, macs, x, dy
           bad += ' NONDET'
         ms = timeit(run, a.iters)
         tf = (4 if ps == 'bwd' and has_dx else 2) * macs / (ms * 1e-3) / 1e12
-        rep['rows'].append(dict(layer=name, batch=B, kind=ps, variant=v, ms=ms, tflops=tf, bad=bad))
-        line += ' | %s=%d %6.1f us %5.0f TF%s' % (key, v, ms * 1e3, tf, bad)
+        rep['rows'].append(dict(layer=name, batch=B, kind=ps, variant=v, wk=wk, ms=ms, tflops=tf, bad=bad))
+        line += ' | %s=%d%s %6.1f us %5.0f TF%s' % (key, v, '/wk' if wk else '', ms * 1e3, tf, bad)
       except Exception as ex:  # pylint: disable=broad-except
         line += ' | %s=%d FAILED %s' % (key, v, repr(ex)[:80])
     print(line, flush=True)
-  ops.tune_set('pp_bwd', -1); ops.tune_set('pp_wgrad', -1); ops.tune_set('pp_fwd', -1)
+  ops.tune_set('pp_bwd', -1); ops.tune_set('pp_wgrad', -1); ops.tune_set('pp_fwd', -1); ops.tune_set('pp_wk', -1)
 
 
 DIMS = {1: (256, 256), 2: (128, 256), 3: (256, 128), 4: (512, 128)}
