@@ -429,19 +429,32 @@ __device__ __forceinline__ void pp_wgrad_body(const WgradArgs& P, unsigned char*
 #undef PP_CURSOR_ZERO
 #undef PP_WCOMPUTE
 
-  // partial tile -> slab `split` (or dW itself when the layer is not split): D row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-  // -> ci, column = lane & 31 -> co; 32 lanes store 128 contiguous bytes
+  // partial tile -> slab `split` (or dW itself when the layer is not split).  D row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+  // -> ci, column = lane & 31 -> co: stored straight from the accumulators that is 128 four-byte stores per lane, and those
+  // stores -- not the MFMAs -- ended the workgroup (256 KB per workgroup, every workgroup of a round at the same moment).
+  // Staged through a private LDS area per wave, half of its rows at a time ([64 rows][64 floats]), a lane stores 16
+  // contiguous bytes and a wave instruction four whole 256-byte row segments.
   float* const out = P.OUT + (int64_t)split * P.slab_elems + (int64_t)tap * P.Cin * P.Cout;
+  constexpr int SROW = 64;        // (256-byte rows: the 16-lane groups of ds_read_b128 land on distinct bank quarters without padding)
+  float* const stg = reinterpret_cast<float*>(smem) + wave * 64 * SROW;
+  static_assert(8 * 64 * SROW * 4 <= 2 * STAGE, "epilogue staging fits the K-tile stages");
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int jj = 0; jj < TN; ++jj)
+    for (int i = 0; i < QM; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int ci = ci0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const int co = co0 + wn * 64 + jj * 32 + (lane & 31);
-        out[(int64_t)ci * P.Cout + co] = acc[i][jj][e];
-      }
+      for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          stg[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * SROW + jj * 32 + (lane & 31)] = acc[h * QM + i][jj][e];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(stg + row * SROW + c4);
+      const int ci = ci0 + wm * 128 + h * 64 + row, co = co0 + wn * 64 + c4;
+      *reinterpret_cast<float4*>(out + (int64_t)ci * P.Cout + co) = v;
+    }
+  }
 }
 
 template <int PH>
