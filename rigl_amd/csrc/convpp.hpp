@@ -681,7 +681,7 @@ static int pp_bwd_dgrad_variant(const IgemmArgs& a) {
   // the weight gradient that would share the launch must exist: 128-channel tiles need the K-grouped body
   const int wkf = tune_get("pp_wk", -1);
   const bool c256 = a.N % 256 == 0 && a.Cred % 256 == 0;
-  if (wkf == 0 && !c256) return PP_NONE;
+  if (wkf != 1 && !c256) return PP_NONE;
   const bool wide = a.N % 256 == 0;
   const int big = wide ? PP_256x256 : PP_512x128, small = wide ? PP_128x256 : PP_256x128;
   if (pp_bwd > 0) return pp_bwd == 2 ? small : big;
@@ -764,8 +764,9 @@ static inline bool pp_wgrad_legal(const RiglConvDesc* d, int wk) {
 static inline int pp_wgrad_kind(const RiglConvDesc* d) {
   const int forced = tune_get("pp_wk", -1);
   if (forced >= 0) return pp_wgrad_legal(d, forced) ? forced : -1;
-  if (pp_wgrad_legal(d, 1)) return 1;
-  return -1;
+  // rule: the 256x256 tiles (measured at batch 128: the K-grouped body saves slab bytes but loses more in MFMA rate --
+  // ResNet-50 step 12.60 vs 12.35 ms)
+  return pp_wgrad_legal(d, 0) ? 0 : -1;
 }
 // Upper bound of the split count of any ping-pong weight-gradient plan (the workspace is sized for it): at least ~256
 // pixels per split, at most two rounds of workgroups, at most "pp_slab_mb" (40) MB of slabs -- every split is one more
