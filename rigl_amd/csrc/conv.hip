@@ -1922,12 +1922,21 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
       const size_t need = rigl_conv2d_workspace_bytes(d, 2);
       if (need && (!workspace || workspace_bytes < need))
         return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
-      if (have_flush) { ProfFamily pf(PROF_CONV_BWD); launch_pending_reduce(flush, st); }
+      if (have_flush && need && flush->slabs == static_cast<const float*>(workspace))
+        return fail(RIGL_EINVAL, "rigl_masked_conv2d_bwd: the pending reduce still reads this workspace");
       ProfFamily prof(PROF_CONV_BWD);
       const WgradArgs aw = pp_wgrad_args(d, x, dy, pw, dw, workspace);
       ad.fd_rw = make_fastdiv(ad.RW); ad.fd_rh = make_fastdiv(ad.RH);
       ad.tiles_n = ad.N / bn;
-      if (pp_bwd_launch(dvar, pw.wk, ad, aw, pw, st)) {
+      // the layer before left its split-K reduce for this launch: a third segment that runs in the launch's tail
+      ReduceArgs pr = {nullptr, nullptr, 0, 0, 0};
+      unsigned nr = 0;
+      if (have_flush) {
+        pr.slabs = flush->slabs; pr.dw = flush->dw; pr.n_out = flush->n_out; pr.slab_elems = flush->slab_elems; pr.splits = flush->splits;
+        const int64_t pairs = ceil_div64(ceil_div64(flush->n_out, 64), 2);
+        nr = (unsigned)(pairs < (int64_t)num_cus() ? pairs : (int64_t)num_cus());
+      }
+      if (pp_bwd_launch(dvar, pw.wk, ad, aw, pw, pr, nr, st)) {
         if (pw.splits > 1) {
           if (defer) {
             defer->slabs = static_cast<const float*>(workspace); defer->dw = dw; defer->n_out = pw.slab;

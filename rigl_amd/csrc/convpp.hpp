@@ -610,11 +610,65 @@ constexpr int PPK_SMEM = 3 * 2 * 96 * 256;
 
 // One launch per layer backward: the split-K weight-gradient workgroups and the dgrad tiles of a layer share one grid -- two independent GEMMs that each leave CUs idle at batch 128 share the chip (the k_bwd_fused idea
 // on the 8-wave bodies).  dX is bit-identical to k_igemm_pp<..., 1> launched alone.
+// The split-K reduce of the layer BEFORE (rigl_masked_conv2d_bwd_deferred) as a third segment of 512-thread workgroups:
+// the two halves of a workgroup each run wgrad_reduce_body's 256-thread arithmetic on their own 64-output group (same
+// summation order as k_wgrad_reduce: bit-identical dW), barriers shared.
+__device__ __forceinline__ void pp_reduce_body(const ReduceArgs& R, unsigned char* smem, uint32_t bid, uint32_t nblk) {
+  const int half = threadIdx.x >> 8, t = threadIdx.x & 255;
+  float4 (*part)[16] = reinterpret_cast<float4 (*)[16]>(smem + half * 16 * 16 * sizeof(float4));
+  const int col = t & 15, grp = t >> 4;
+  const int64_t n_groups = (R.n_out + 63) / 64;
+  const bool vec = (R.slab_elems & 3) == 0;
+  const float* __restrict__ slabs = R.slabs;
+  float* __restrict__ dw = R.dw;
+  const int64_t iters = (n_groups + 2 * (int64_t)nblk - 1) / (2 * (int64_t)nblk);
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t gidx = (it * nblk + bid) * 2 + half;
+    const bool live = gidx < n_groups;
+    const int64_t i0 = gidx * 64 + col * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+      if (vec && i0 + 3 < R.slab_elems) {
+#pragma unroll 4
+        for (int s2 = grp; s2 < R.splits; s2 += 16) {
+          const float4 v = *reinterpret_cast<const float4*>(slabs + (int64_t)s2 * R.slab_elems + i0);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+      } else {
+        for (int s2 = grp; s2 < R.splits; s2 += 16) {
+          const float* p = slabs + (int64_t)s2 * R.slab_elems;
+          if (i0 + 0 < R.slab_elems) acc.x += p[i0 + 0];
+          if (i0 + 1 < R.slab_elems) acc.y += p[i0 + 1];
+          if (i0 + 2 < R.slab_elems) acc.z += p[i0 + 2];
+          if (i0 + 3 < R.slab_elems) acc.w += p[i0 + 3];
+        }
+      }
+    }
+    part[grp][col] = acc;
+    __syncthreads();
+    if (live && grp == 0) {
+      float4 r = part[0][col];
+#pragma unroll
+      for (int g2 = 1; g2 < 16; ++g2) {
+        const float4 v = part[g2][col];
+        r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+      }
+      if (i0 + 0 < R.n_out) dw[i0 + 0] = r.x;
+      if (i0 + 1 < R.n_out) dw[i0 + 1] = r.y;
+      if (i0 + 2 < R.n_out) dw[i0 + 2] = r.z;
+      if (i0 + 3 < R.n_out) dw[i0 + 3] = r.w;
+    }
+    __syncthreads();
+  }
+}
+
 template <int WMD, int WND, int TMD, int TND, int PHD, int WK /*0: 256x256 tiles, 1: K-grouped 128x128 tiles*/>
-__global__ __launch_bounds__(512) void k_bwd_pp(IgemmArgs PD, WgradArgs PW, uint32_t nd, uint32_t nw, uint32_t wgrad_first) {
+__global__ __launch_bounds__(512) void k_bwd_pp(IgemmArgs PD, WgradArgs PW, ReduceArgs PR, uint32_t nd, uint32_t nw, uint32_t wgrad_first) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_pp[];
-  // longest jobs first: whichever body has the longer reduction per workgroup takes the low block indices
+  // longest jobs first: whichever body has the longer reduction per workgroup takes the low block indices; the reduce
+  // workgroups of the previous layer (if any) come last and run in the launch's tail
   const uint32_t b = blockIdx.x;
+  if (b >= nd + nw) { pp_reduce_body(PR, smem_pp, b - nd - nw, gridDim.x - nd - nw); return; }
   const bool is_w = wgrad_first ? b < nw : b >= nd;
   if (is_w) {
     if constexpr (WK == 1) pp_wgrad_k_body(PW, smem_pp, wgrad_first ? b : b - nd, nw);
@@ -849,28 +903,30 @@ static bool pp_wgrad_launch(const PPBwdPlan& p, const WgradArgs& aw, hipStream_t
   return true;
 }
 template <int WMD, int WND, int TMD, int TND, int PHD, int WK>
-static bool pp_bwd_launch_one(const IgemmArgs& ad, const WgradArgs& aw, unsigned nd, unsigned nw, bool wgrad_first, hipStream_t st) {
+static bool pp_bwd_launch_one(const IgemmArgs& ad, const WgradArgs& aw, const ReduceArgs& pr, unsigned nr, unsigned nd, unsigned nw,
+                              bool wgrad_first, hipStream_t st) {
   constexpr int SM_D = PPGeom<WMD, WND, TMD, TND, PHD>::SMEM, SM_W = WK ? PPK_SMEM : PPGeom<2, 4, 4, 2, 2>::SMEM, SM = SM_D > SM_W ? SM_D : SM_W;
   static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_pp<WMD, WND, TMD, TND, PHD, WK>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM) == hipSuccess;
   if (!ready) return false;
-  RIGL_K_LAUNCH((k_bwd_pp<WMD, WND, TMD, TND, PHD, WK>), dim3(nd + nw), dim3(512), SM, st, ad, aw, nd, nw, (uint32_t)(wgrad_first ? 1u : 0u));
+  RIGL_K_LAUNCH((k_bwd_pp<WMD, WND, TMD, TND, PHD, WK>), dim3(nd + nw + nr), dim3(512), SM, st, ad, aw, pr, nd, nw, (uint32_t)(wgrad_first ? 1u : 0u));
   return true;
 }
 // dvar = the dgrad tile, wk = the weight-gradient body
-static bool pp_bwd_launch(int dvar, int wk, const IgemmArgs& ad, const WgradArgs& aw, const PPBwdPlan& pw, hipStream_t st) {
+static bool pp_bwd_launch(int dvar, int wk, const IgemmArgs& ad, const WgradArgs& aw, const PPBwdPlan& pw, const ReduceArgs& pr, unsigned nr,
+                          hipStream_t st) {
   if (wk) {
     switch (dvar) {
-      case PP_256x256: return pp_bwd_launch_one<2, 4, 4, 2, 2, 1>(ad, aw, pw.nd, pw.nw, pw.wgrad_first, st);
-      case PP_128x256: return pp_bwd_launch_one<2, 4, 2, 2, 1, 1>(ad, aw, pw.nd, pw.nw, pw.wgrad_first, st);
-      case PP_256x128: return pp_bwd_launch_one<4, 2, 2, 2, 1, 1>(ad, aw, pw.nd, pw.nw, pw.wgrad_first, st);
-      case PP_512x128: return pp_bwd_launch_one<4, 2, 4, 2, 2, 1>(ad, aw, pw.nd, pw.nw, pw.wgrad_first, st);
+      case PP_256x256: return pp_bwd_launch_one<2, 4, 4, 2, 2, 1>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
+      case PP_128x256: return pp_bwd_launch_one<2, 4, 2, 2, 1, 1>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
+      case PP_256x128: return pp_bwd_launch_one<4, 2, 2, 2, 1, 1>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
+      case PP_512x128: return pp_bwd_launch_one<4, 2, 4, 2, 2, 1>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
       default: return false;
     }
   }
   switch (dvar) {
-    case PP_256x256: return pp_bwd_launch_one<2, 4, 4, 2, 2, 0>(ad, aw, pw.nd, pw.nw, pw.wgrad_first, st);
-    case PP_128x256: return pp_bwd_launch_one<2, 4, 2, 2, 1, 0>(ad, aw, pw.nd, pw.nw, pw.wgrad_first, st);
+    case PP_256x256: return pp_bwd_launch_one<2, 4, 4, 2, 2, 0>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
+    case PP_128x256: return pp_bwd_launch_one<2, 4, 2, 2, 1, 0>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
     default: return false;
   }
 }
