@@ -120,7 +120,35 @@ def _claim_stdout():
   return real
 
 
+def _self_launch(argv, gpus):
+  """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): replace this process by
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` -- one rank per GPU, rank 0
+  prints the one JSON line on the inherited stdout.  RIGL_BENCH_DRY_LAUNCH=1 prints the command instead (tests)."""
+  import socket
+  port = os.environ.get('MASTER_PORT')
+  if not port:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+      sk.bind(('127.0.0.1', 0))
+      port = str(sk.getsockname()[1])
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus),
+         '--master-addr', '127.0.0.1', '--master-port', port, os.path.abspath(__file__)] + list(argv)
+  if os.environ.get('RIGL_BENCH_DRY_LAUNCH', '0') == '1':
+    print(json.dumps({'launch': cmd}))
+    sys.stdout.flush()
+    return
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  sys.stdout.flush()
+  os.execv(sys.executable, cmd)
+
+
 def main():
+  # (argument errors and --help print before stdout is claimed)
+  pre = argparse.ArgumentParser(add_help=False)
+  pre.add_argument('--gpus', type=int, default=1)
+  known, _ = pre.parse_known_args()
+  if known.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    _self_launch(sys.argv[1:], known.gpus)
+    return
   real_stdout = _claim_stdout()
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -165,7 +193,9 @@ def main():
       dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
     else:
       dist.init_process_group(backend, rank=rank, world_size=world)
-  assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+  if world != args.gpus:
+    raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus N` bare, or under '
+                     'torch.distributed.run --nproc-per-node N)' % (args.gpus, world))
 
   from rigl_amd import ops, sparse_optimizers, train, variables
   from rigl_amd.dist import GradSync

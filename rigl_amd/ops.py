@@ -16,6 +16,7 @@ from rigl_amd._lib import (ConvDesc, PackLayer, PruneRegrowLayer,
                            PruneRegrowParams, RiglError, check)
 
 _workspaces = {}
+_retired_workspaces = []
 
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
@@ -73,14 +74,25 @@ def join_side_stream(device):
     torch.cuda.current_stream(device).wait_stream(st)
 
 
+# Bumped whenever a scratch buffer is (re)allocated: a captured HIP graph holds the OLD buffer's address, so
+# train.GraphedStep drops its graphs when the generation it captured under is no longer current.
+WORKSPACE_GENERATION = 0
+
+
 def workspace(nbytes, device, tag=''):
   """Grow-only scratch buffer per device and user (stream-ordered reuse)."""
+  global WORKSPACE_GENERATION
   key = (torch.device(device).index or 0, tag)
   ws = _workspaces.get(key)
   if ws is None or ws.numel() < nbytes:
+    old = ws
     ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8,
                      device=device)
     _workspaces[key] = ws
+    WORKSPACE_GENERATION += 1
+    if old is not None:
+      # keep the outgrown buffer alive: graphs captured before the growth may still replay once before they notice
+      _retired_workspaces.append(old)
   return ws
 
 

@@ -602,7 +602,15 @@ class SparseSnipOptimizer(PruningGetterMixin, train.Optimizer):
         # dense, so g = dL/d(mask*W) + weight_decay * W -- the l2 term the update kernel otherwise folds in
         # (``rigl_masked_sgd_momentum``) belongs in the score (the reference's loss includes the regulariser,
         # imagenet_train_eval.py:578-584)
+        # Under data parallelism the gradient arena holds the SUM over replicas (the 1 / world of the mean lives in the
+        # update kernel's grad_scale), while every replica's loss carries the regulariser once: scale the summed data
+        # gradient back to the mean before adding wd * W, or the l2 term would weigh 1 / world of what it does on one
+        # GPU and the SNIP masks would depend on the number of GPUs.
         g_var = l.weights.grad
+        sync = getattr(self._optimizer, '_grad_sync', None)
+        scale = float(getattr(sync, 'grad_scale', 1.0)) if sync is not None else 1.0
+        if scale != 1.0:
+          g_var = g_var * scale
         if l.weights.weight_decay:
           g_var = g_var + float(l.weights.weight_decay) * l.weights.data
         score = (g_var * l.weights.data).abs().contiguous().view(-1)

@@ -227,6 +227,9 @@ class GraphedStep:
     self._eager_only = (sync is not None and getattr(sync, 'enabled', False)) or not torch.cuda.is_available()
     self.replays = 0
     self.eager_steps = 0
+    self._ws_gen = ops.WORKSPACE_GENERATION
+    self._misses = 0
+    self._warmup_steps = warmup
 
   def _is_update(self):
     o = self._opt
@@ -244,8 +247,20 @@ class GraphedStep:
     if self._eager_only or self._is_update():
       return self._eager()
     key = _lr_value(self._inner._lr, self._gs)                   # pylint: disable=protected-access
+    if self._ws_gen != ops.WORKSPACE_GENERATION:
+      # an eager step (a mask update, typically) outgrew a scratch buffer after the capture: the graphs point at the old
+      # one -- drop them and capture again (the old buffers stay allocated, so nothing was overwritten meanwhile)
+      self._graphs.clear()
+      self._ws_gen = ops.WORKSPACE_GENERATION
     ent = self._graphs.get(key)
     if ent is None:
+      self._misses += 1
+      if self._misses > 8 + self._warmup_steps:
+        #  many steps in a row without one replay: the learning rate changes every step (warm-up, cosine), so a
+        # graph keyed on its value is never reused -- stop capturing and run plain eager steps on the current stream
+        self._eager_only = True
+        self._graphs.clear()
+        return self._eager()
       if self._warmup > 0:                                         # allocator / workspace caches / descriptors settle first
         self._warmup -= 1
         return self._eager()
@@ -263,9 +278,13 @@ class GraphedStep:
         loss = self._loss_fn()
         self._opt.minimize(loss, self._gs)                         # capture enqueues nothing; undo its host side effect:
       self._gs.value = step1
+      if len(self._graphs) >= 16:
+        self._graphs.pop(next(iter(self._graphs)))                 # bound the cache (piecewise-constant schedules have few values)
       self._graphs[key] = (graph, loss)
+      self._ws_gen = ops.WORKSPACE_GENERATION
       return out
     graph, loss = ent
+    self._misses = 0
     graph.replay()
     self._gs.value += 1
     self._inner.graph.shadows_dirty = True                         # the replayed update rewrote the weights

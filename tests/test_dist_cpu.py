@@ -162,3 +162,24 @@ def test_bucket_size_default_and_knob(monkeypatch):
   monkeypatch.setenv('RIGL_DP_BUCKET_MB', '8')
   assert GradSync(g, enabled=False).bucket_elems == (8 << 20) // 4
   assert GradSync(g, bucket_bytes=4000, enabled=False).bucket_elems == 1000
+
+
+def test_bench_self_launch_command():
+  """bench.py --gpus N without a launcher re-executes itself under torch.distributed.run (one rank per GPU, 127.0.0.1
+  rendezvous, same arguments); with WORLD_SIZE set it is a rank and does not."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, RIGL_BENCH_DRY_LAUNCH='1')
+  for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+    env.pop(k, None)
+  out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4', '--steps', '7', '--warmup', '2'],
+                       env=env, capture_output=True, text=True, timeout=300)
+  assert out.returncode == 0, out.stderr[-2000:]
+  cmd = json.loads(out.stdout.strip().splitlines()[-1])['launch']
+  assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nnodes=1' in cmd
+  assert cmd[cmd.index('--nproc-per-node') + 1] == '4' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+  assert int(cmd[cmd.index('--master-port') + 1]) > 0
+  i = cmd.index(os.path.join(root, 'bench.py'))
+  assert cmd[i + 1:] == ['--gpus', '4', '--steps', '7', '--warmup', '2']

@@ -31,6 +31,23 @@ def test_two_ranks_on_one_gpu_keep_identical_masks():
 
 
 @pytest.mark.gpu
+def test_bench_launches_itself_for_more_than_one_gpu():
+  """`python bench.py --gpus 2` with no launcher around it (the form the driver uses): bench.py re-executes itself under
+  torch.distributed.run and rank 0 prints the one JSON line (missing #1)."""
+  env = dict(os.environ, RIGL_BENCH_ONE_DEVICE='1', RIGL_BENCH_BACKEND='gloo')
+  for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+    env.pop(k, None)
+  cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '0', '--batch', '8',
+         '--no-cpu-baseline']
+  out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stderr[-2000:]
+  lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1 and out.stdout.strip().splitlines() == lines
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['config']['masks_identical_across_ranks'] is True
+
+
+@pytest.mark.gpu
 def test_bench_contract_single_gpu():
   """The JSON line the driver parses: contract keys, the roofline and cpu_baseline objects."""
   cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '1', '--prof-every', '2']

@@ -206,6 +206,28 @@ def test_snip_score_includes_the_l2_gradient():
   assert not np.array_equal(np.sort(np.argsort(-plain.reshape(-1), kind='stable')[:keep]), np.flatnonzero(m.reshape(-1)))
 
 
+def test_snip_masks_do_not_depend_on_the_number_of_replicas():
+  """Under data parallelism the arena holds the SUM of the replicas' data gradients and 1 / world rides in grad_scale: the
+  SNIP score must scale the sum back before adding wd * W.  Two identical replicas are emulated by doubling the
+  loss (= the summed gradient) and a GradSync stand-in with grad_scale 1/2; the masks must be those of the one-GPU run."""
+  l2 = 50.0
+  opt, loss_fn, _, mask, weights, gs = _setup_oneshot('snip', 0.5, 6, 5, l2=l2)
+  assert opt.minimize(loss_fn(), gs)
+  m1 = mask.numpy().copy()
+
+  class _Sync:                       # what SparseSnipOptimizer and train.Optimizer read of a rigl_amd.dist.GradSync
+    enabled, world, grad_scale = True, 2, 0.5
+
+    def all_reduce(self, graph):     # the "sum over replicas" already happened (doubled loss)
+      del graph
+
+  opt2, loss_fn2, _, mask2, weights2, gs2 = _setup_oneshot('snip', 0.5, 6, 5, l2=l2)
+  np.testing.assert_array_equal(weights2.numpy(), weights.numpy())          # same seed, same initial weights
+  opt2._optimizer._grad_sync = _Sync()                                      # pylint: disable=protected-access
+  assert opt2.minimize(2.0 * loss_fn2(), gs2)
+  np.testing.assert_array_equal(mask2.numpy(), m1)
+
+
 def test_dnw_masked_kernels_get_no_l2_gradient():
   """DNW differentiates w.r.t. the masked_weights tensors (sparse_optimizers.py:375-386): the regulariser on the raw
   variables does not reach them, so the update is w -= lr * dense_grad exactly, whatever the l2 scale."""
