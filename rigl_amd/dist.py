@@ -101,8 +101,16 @@ class GradSync:
         t = getattr(mod, name, None)
         if torch.is_tensor(t):
           dist.broadcast(t, src=src, group=self.group)
+    # per-layer initial values kept for grow_init='initial_dist' are part of the state a grown weight can take
+    for v in g.trainable_variables():
+      t = getattr(v, 'initial_value', None)
+      if torch.is_tensor(t) and t.is_cuda:
+        dist.broadcast(t, src=src, group=self.group)
     g.shadows_dirty = True
     self._state_synced = True
+    # NOTE: this is a collective.  It runs at the first refresh_shadows() of a data-parallel run, i.e. the
+    # first forward -- every rank must run that forward (call sync_initial_state() explicitly at the top of the training
+    # loop when some ranks evaluate first).  Optimizer slots are created zero on every rank, so they need no broadcast.
 
   def _kernel_end(self):
     from rigl_amd import variables as V  # pylint: disable=import-outside-toplevel
