@@ -1,0 +1,284 @@
+"""Chained in-situ parity along whole networks.
+
+tests/test_network_grad_gpu.py compares the END of a 22-layer backward pass with stock ops and has to allow 15 %: two
+correct bf16 implementations differ by half-ulps in every activation gradient and batch norm amplifies those.  Here the
+errors cannot compound: a stock-op reference of the network (fp64 arithmetic, a bf16 rounding wherever the HIP path stores
+a bf16 tensor) runs ONCE and records, for every conv and every batch-norm node, the tensors that node consumed and the
+gradient that arrived at its output; then each HIP kernel is fed THE REFERENCE'S tensors and held to the per-kernel bound
+
+  conv fwd / dgrad   |got - ref| <= 2^-8 |ref| + 1e-5 sum|a||b|     (bf16 output rounding + fp32 accumulation)
+  conv wgrad         |got - ref| <= 1e-5 sum|a||b|
+  batch norm y, dx   |got - ref| <= 2^-8 |ref| + 1e-5 (sum of the magnitudes of the terms of the element's formula)
+  batch norm dgamma  |got - ref| <= 1e-5 sum |dz xhat|,   dbeta: 1e-5 sum |dz|      (fp32-accumulation bounds)
+
+so a wrong scale confined to a few low-energy channels of one layer -- invisible in a 15 % band -- fails its own node.
+Networks: the 22-layer WideResNet of BASELINE config 2 (16 / 32 / 64 channels: the igemm bodies) and a stack of two
+ResNet-50 group-3 bottleneck blocks at 14x14 (256 / 1024 channels: the ping-pong forward, the shared ping-pong backward
+launch and its 256x256 weight-gradient tiles).  The checker (stock ops in fp64, tests/convref.py) is test infrastructure.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+import torch.nn.functional as F  # noqa: E402
+
+from tests import convref  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+EPS = 1e-5
+
+
+class _RoundBF16(torch.autograd.Function):
+  """bf16 rounding of a tensor in the forward AND of its gradient in the backward pass (values stay fp64)."""
+
+  @staticmethod
+  def forward(ctx, x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+  @staticmethod
+  def backward(ctx, g):
+    return g.to(torch.bfloat16).to(g.dtype)
+
+
+rnd = _RoundBF16.apply
+
+
+class Recorder:
+  """Stock-op network pieces in fp64 (NCHW) that remember what each node saw."""
+
+  def __init__(self):
+    self.convs, self.bns = [], []
+
+  def conv(self, name, x, w_hwio_f32, k, stride, pads):
+    """pads = (top, left, bottom, right).  Returns the bf16-rounded output."""
+    xi = (x * 1.0)                                   # this consumer's own copy: its .grad is THIS conv's dX alone
+    xi.retain_grad()
+    w = w_hwio_f32.to(torch.bfloat16).double().clone().requires_grad_(True)     # the shadow the kernels read
+    pt, pl, pb, pr = pads
+    y_raw = F.conv2d(F.pad(xi, (pl, pr, pt, pb)), w.permute(3, 2, 0, 1), stride=stride)
+    y_raw.retain_grad()                              # its .grad is the bf16-rounded gradient the conv's backward consumes
+    self.convs.append(dict(name=name, x=xi, w=w, w32=w_hwio_f32, y=y_raw, k=k, stride=stride, pads=pads))
+    return rnd(y_raw)
+
+  def bn(self, name, x, gamma, beta, relu, residual=None):
+    xi = (x * 1.0)
+    xi.retain_grad()
+    ri = None
+    if residual is not None:
+      ri = residual * 1.0
+      ri.retain_grad()
+    g64 = gamma.double().clone().requires_grad_(True)
+    b64 = beta.double().clone().requires_grad_(True)
+    y = F.batch_norm(xi, None, None, g64, b64, True, 0.1, EPS)
+    if ri is not None:
+      y = y + ri
+    if relu:
+      y = F.relu(y)
+    y.retain_grad()
+    self.bns.append(dict(name=name, x=xi, res=ri, gamma=gamma, beta=beta, g64=g64, b64=b64, y=y, relu=relu))
+    return rnd(y)
+
+
+def _nhwc_bf16(t):
+  return t.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+
+
+def check_conv_node(nd):
+  """The HIP forward / dgrad / wgrad of one conv on the reference's tensors against tests/convref.py."""
+  from rigl_amd import ops
+  x = _nhwc_bf16(nd['x'])
+  dy = _nhwc_bf16(nd['y'].grad)
+  assert torch.equal(dy.double(), nd['y'].grad.detach().permute(0, 2, 3, 1)), 'the recorded gradient is not bf16-valued'
+  N, H, W, Cin = x.shape
+  _, Ho, Wo, Cout = dy.shape
+  k, s = nd['k'], nd['stride']
+  pt, pl = nd['pads'][0], nd['pads'][1]
+  n = k * k * Cin * Cout
+  hwio = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+  ohwi = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+  ops.pack_weights(nd['w32'].reshape(-1).contiguous(), None, k * k * Cin, Cout, hwio, ohwi)
+  wm = hwio.float().reshape(k, k, Cin, Cout)
+  assert torch.equal(wm.double(), nd['w'].detach()), 'packed shadow != the reference weights'
+  d = ops.conv_desc(N, H, W, Cin, Cout, k, k, s, pt, pl, Ho, Wo)
+  has_dx = Cin % 8 == 0
+  want = ('y', 'dx', 'dw') if has_dx else ('y', 'dw')
+  ref = convref.conv_fp64(x, wm, dy, s, pt, pl, Ho, Wo, want)
+  ab = convref.conv_fp64(x.abs(), wm.abs(), dy.abs(), s, pt, pl, Ho, Wo, want)
+  # (the matrix-product reference must agree with the stock-op graph it is standing in for)
+  assert float((ref['y'] - nd['y'].detach().permute(0, 2, 3, 1)).abs().max()) <= 1e-9 * float(ab['y'].max() + 1e-30)
+  worst = 0.0
+  if Cout % 8 == 0:
+    y = ops.conv_fwd(d, x, ohwi)
+    worst = max(worst, convref.check_close(nd['name'] + ' fwd', y, ref['y'], ab['y'], 1e-5, 2.0 ** -8))
+    dw = torch.empty(n, dtype=torch.float32, device=DEV)
+    dx = ops.conv_bwd(d, x, dy, hwio, dw, need_dx=has_dx)
+    ops.flush_pending_wgrad()
+    worst = max(worst, convref.check_close(nd['name'] + ' wgrad', dw.reshape(k, k, Cin, Cout), ref['dw'], ab['dw'], 1e-5))
+    if has_dx:
+      worst = max(worst, convref.check_close(nd['name'] + ' dgrad', dx, ref['dx'], ab['dx'], 1e-5, 2.0 ** -8))
+      gx = nd['x'].grad.detach().permute(0, 2, 3, 1)
+      assert float((ref['dx'] - gx).abs().max()) <= 1e-9 * float(ab['dx'].max() + 1e-30)
+  return worst
+
+
+def check_bn_node(nd):
+  """The HIP batch norm (+ residual)(+ ReLU) forward and backward on the reference's tensors."""
+  from rigl_amd import ops
+  x = _nhwc_bf16(nd['x'])
+  res = _nhwc_bf16(nd['res']) if nd['res'] is not None else None
+  C = x.shape[-1]
+  M = x.numel() // C
+  gamma, beta = nd['gamma'].float().contiguous(), nd['beta'].float().contiguous()
+  rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+  relu = nd['relu']
+  out = ops.bn_fwd(x, gamma, beta, rm, rv, 0.1, EPS, relu, residual=res, want_relu_bits=relu and res is not None)
+  y_hip, saved = out[0], out[1]
+  bits = out[2] if len(out) > 2 else None
+  # fp64 reference of the same formulas on the same bf16 inputs
+  xd = x.double().reshape(M, C)
+  mean = xd.mean(0)
+  var = (xd * xd).mean(0) - mean * mean
+  invstd = 1.0 / torch.sqrt(var.clamp_min(0) + EPS)
+  xhat = (xd - mean) * invstd
+  g64, b64 = gamma.double(), beta.double()
+  pre = xhat * g64 + b64
+  mag = xhat.abs() * g64.abs() + b64.abs()
+  if res is not None:
+    rd = res.double().reshape(M, C)
+    pre = pre + rd
+    mag = mag + rd.abs()
+  y_ref = pre.clamp_min(0) if relu else pre
+  assert float((y_ref.reshape(x.shape) - nd['y'].detach().permute(0, 2, 3, 1)).abs().max()) <= 1e-9 * float(mag.max())
+  worst = convref.check_close(nd['name'] + ' y', y_hip.reshape(M, C), y_ref, mag, 1e-5, 2.0 ** -8)
+  # saved statistics: mean within 1e-6 of the data scale, invstd relatively
+  sm, si = saved[0].double(), saved[1].double()
+  assert float(((sm - mean).abs() / (xd.abs().mean(0) + 1e-12)).max()) <= 1e-5, nd['name'] + ' saved mean'
+  assert float(((si - invstd).abs() / invstd).max()) <= 1e-5, nd['name'] + ' saved invstd'
+  # backward: the gradient that arrived at the node's output in the reference; the ReLU mask is the REFERENCE's
+  dy = _nhwc_bf16(nd['y'].grad)
+  dyd = dy.double().reshape(M, C)
+  on = (y_ref > 0) if relu else torch.ones_like(y_ref, dtype=torch.bool)
+  dz = torch.where(on, dyd, torch.zeros_like(dyd))
+  dbeta = dz.sum(0)
+  dgamma = (dz * xhat).sum(0)
+  a = g64 * invstd
+  dx_ref = a * (dz - dbeta / M - xhat * dgamma / M)
+  dx_mag = a.abs() * (dz.abs() + dbeta.abs() / M + xhat.abs() * dgamma.abs() / M)
+  y_mask = y_ref.reshape(x.shape).to(torch.bfloat16) if relu else None          # bf16(y) > 0  <=>  y > 0 (no flush to zero)
+  if relu:
+    assert bool(((y_mask.double() > 0) == on.reshape(x.shape)).all())
+  dg = torch.empty(C, dtype=torch.float32, device=DEV)
+  db = torch.empty(C, dtype=torch.float32, device=DEV)
+  dx_hip, dres = ops.bn_bwd(x, y_mask, dy, gamma, saved, relu, dg, db, want_dres=res is not None)
+  del bits
+  worst = max(worst, convref.check_close(nd['name'] + ' dbeta', db, dbeta, dz.abs().sum(0), 1e-5))
+  worst = max(worst, convref.check_close(nd['name'] + ' dgamma', dg, dgamma, (dz * xhat).abs().sum(0), 1e-5))
+  worst = max(worst, convref.check_close(nd['name'] + ' dx', dx_hip.reshape(M, C), dx_ref, dx_mag, 1e-5, 2.0 ** -8))
+  if res is not None:
+    assert torch.equal(dres.reshape(M, C).double(), dz), nd['name'] + ': the residual gradient is the masked gradient, exactly'
+  # ... and the recorded graph agrees with these formulas (the reference's own backward)
+  assert float((nd['g64'].grad - dgamma).abs().max()) <= 1e-9 * float((dz * xhat).abs().sum(0).max() + 1e-30)
+  gx = nd['x'].grad.detach().permute(0, 2, 3, 1).reshape(M, C)
+  assert float((gx - dx_ref).abs().max()) <= 1e-9 * float(dx_mag.max() + 1e-30)
+  return worst
+
+
+def _same_pads(h, w, k, stride):
+  """TF 'SAME': the extra pixel goes to the bottom / right."""
+  if k == 1:
+    return (0, 0, 0, 0)
+  th = max((-(-h // stride) - 1) * stride + k - h, 0)
+  tw = max((-(-w // stride) - 1) * stride + k - w, 0)
+  return (th // 2, tw // 2, th - th // 2, tw - tw // 2)
+
+
+def test_wrn22_every_conv_and_batch_norm_node_on_the_reference_tensors():
+  from rigl_amd import sparse_utils, variables as V
+  from rigl_amd.workloads import wide_resnet
+  g = V.reset_default_graph(DEV)
+  model = wide_resnet.WideResNet(g, depth=22, width=1)
+  np.random.seed(0)
+  sparse_utils.get_mask_init_fn(g.get_masks(), 'erdos_renyi_kernel', 0.8, {})()
+  gen = torch.Generator(device=DEV).manual_seed(3)
+  for mod in g.modules.values():
+    if hasattr(mod, 'gamma'):
+      mod.gamma.data.copy_(1.0 + 0.2 * torch.randn(mod.channels, generator=gen, device=DEV))
+      mod.beta.data.copy_(0.1 * torch.randn(mod.channels, generator=gen, device=DEV))
+  x_nhwc, labels = wide_resnet.synthetic_batch(128, DEV)
+  rec = Recorder()
+
+  def w_of(layer):
+    w = layer.weights.data.float()
+    if layer.mask is not None:
+      w = w * layer.mask.data.float().reshape(w.shape)
+    return w.contiguous()
+
+  def conv(layer, x, k):
+    s = layer.strides[0]
+    pads = _same_pads(x.shape[2], x.shape[3], k, s) if k == 3 else (0, 0, 0, 0)
+    return rec.conv(layer.scope, x, w_of(layer), k, s, pads)
+
+  def bn_relu(bn, name, x):
+    return rec.bn(name, x, bn.gamma.data, bn.beta.data, True)
+
+  net = conv(model.stem, x_nhwc.double().permute(0, 3, 1, 2), 3)
+  for i, b in enumerate(model.blocks):
+    skip = net
+    net = bn_relu(b['bn_a'], 'block%d/bn_a' % i, net)
+    if 'skip' in b:
+      skip = conv(b['skip'], net, 1)
+    net = conv(b['conv1'], net, 3)
+    net = bn_relu(b['bn_b'], 'block%d/bn_b' % i, net)
+    net = conv(b['conv2'], net, 3)
+    net = rnd(net + skip)
+  net = bn_relu(model.final_bn, 'final_bn', net)
+  feat = rnd(net.mean(dim=(2, 3)))
+  wl = w_of(model.logits).to(torch.bfloat16).double()
+  logits = rnd(feat @ wl + model.logits.bias.data.double())
+  F.cross_entropy(logits, labels).backward()
+  assert len(rec.convs) == 21 and len(rec.bns) == 19
+  worst = 0.0
+  for nd in rec.convs:
+    worst = max(worst, check_conv_node(nd))
+  for nd in rec.bns:
+    worst = max(worst, check_bn_node(nd))
+  print('wrn22 chained: %d conv + %d batch-norm nodes, worst error / bound %.3f' % (len(rec.convs), len(rec.bns), worst))
+  assert worst <= 1.0
+
+
+def test_resnet50_group3_bottlenecks_every_node_on_the_reference_tensors():
+  """Two group-3 bottleneck blocks (1x1 1024->256, 3x3 256->256, 1x1 256->1024, identity shortcut; resnet_model.py:456-501)
+  at 14x14, batch 64: the shapes whose forward runs on the 128x256 ping-pong tile and whose backward runs the shared
+  ping-pong launch (256x256 dgrad tiles next to the 256x256 weight-gradient tiles, split-K slabs + reduce)."""
+  gen = torch.Generator(device=DEV).manual_seed(11)
+  B, HW = 64, 14
+  rec = Recorder()
+
+  def rand_w(k, cin, cout):
+    w = torch.randn(k, k, cin, cout, generator=gen, device=DEV) * (2.0 / (k * k * cin)) ** 0.5
+    m = (torch.rand(k, k, cin, cout, generator=gen, device=DEV) < 0.2).float()       # 80 % sparse, like the ERK layers
+    return (w * m).contiguous()
+
+  def bn_params(c):
+    return (1.0 + 0.2 * torch.randn(c, generator=gen, device=DEV)), 0.1 * torch.randn(c, generator=gen, device=DEV)
+
+  x0 = torch.randn(B, 1024, HW, HW, generator=gen, device=DEV).to(torch.bfloat16).double()
+  net = F.relu(x0).requires_grad_(True)
+  for blk in range(2):
+    shortcut = net
+    t = rec.conv('b%d/c1' % blk, net, rand_w(1, 1024, 256), 1, 1, (0, 0, 0, 0))
+    t = rec.bn('b%d/bn1' % blk, t, *bn_params(256), True)
+    t = rec.conv('b%d/c2' % blk, t, rand_w(3, 256, 256), 3, 1, (1, 1, 1, 1))
+    t = rec.bn('b%d/bn2' % blk, t, *bn_params(256), True)
+    t = rec.conv('b%d/c3' % blk, t, rand_w(1, 256, 1024), 1, 1, (0, 0, 0, 0))
+    net = rec.bn('b%d/bn3' % blk, t, *bn_params(1024), True, residual=shortcut)
+  r = torch.randn(net.shape, generator=gen, device=DEV).double()
+  (net * r).sum().backward()
+  worst = 0.0
+  for nd in rec.convs:
+    worst = max(worst, check_conv_node(nd))
+  for nd in rec.bns:
+    worst = max(worst, check_bn_node(nd))
+  print('resnet50 group-3 chained: %d conv + %d batch-norm nodes, worst error / bound %.3f' % (len(rec.convs), len(rec.bns), worst))
+  assert worst <= 1.0
