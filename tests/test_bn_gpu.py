@@ -145,6 +145,17 @@ def test_bn_bwd_reductions_in_the_dgrad_epilogue(case):
   keep their bits; the batch norm's dgamma / dbeta agree with an fp64 reduction to fp32-accumulation accuracy
   (1e-5 x the sum of the absolute terms) for BOTH paths, and its dx to one bf16 ulp of the unfused result."""
   from rigl_amd import ops
+  # the reduction epilogue lives in the igemm dgrad body (opt-in RIGL_BN_FUSE_BWD=1): keep these layers' backward off the
+  # ping-pong launch, whose dgrad has none (rigl_conv2d_dgrad_stats_parts returns 0 there and the model does not fuse)
+  ops.tune_set('pp_bwd', 0)
+  try:
+    _bn_bwd_reductions_case(case)
+  finally:
+    ops.tune_set('pp_bwd', -1)
+
+
+def _bn_bwd_reductions_case(case):
+  from rigl_amd import ops
   N, H, W, Cin, Cout, k, stride, relu, has_res, has_add = case
   g = torch.Generator(device=DEV).manual_seed(sum(int(v) for v in case))
   pad = (k - 1) // 2

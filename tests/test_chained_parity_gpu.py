@@ -53,7 +53,8 @@ class Recorder:
   def conv(self, name, x, w_hwio_f32, k, stride, pads):
     """pads = (top, left, bottom, right).  Returns the bf16-rounded output."""
     xi = (x * 1.0)                                   # this consumer's own copy: its .grad is THIS conv's dX alone
-    xi.retain_grad()
+    if xi.requires_grad:                             # (the network input has no gradient)
+      xi.retain_grad()
     w = w_hwio_f32.to(torch.bfloat16).double().clone().requires_grad_(True)     # the shadow the kernels read
     pt, pl, pb, pr = pads
     y_raw = F.conv2d(F.pad(xi, (pl, pr, pt, pb)), w.permute(3, 2, 0, 1), stride=stride)
