@@ -132,6 +132,26 @@ int rigl_prune_regrow(const RiglPruneRegrowLayer* layers /* host */,
                       void* workspace /* device */, size_t workspace_bytes,
                       rigl_stream_t stream);
 
+/* The same update on ONE tensor, with its two selections read back (north
+ * star: "masks and top-k indices bit-exact"; SURVEY.md 8(b) sketch
+ * `out_topk_idx`): out_mask1_bits = the kept set mask1, out_mask2_bits = the
+ * grown set mask2 (bitmaps, either may be NULL) and -- both or neither --
+ * out_idx1 / out_idx2 [n] int32: the indices in tf.nn.top_k order of the drop
+ * score resp. the lifted grow score (sparse_optimizers_base.py:293, :311),
+ * i.e. larger score first, equal scores by lower index; the first n_keep
+ * (out_counts[2]) resp. n_prune (out_counts[1]) entries are the selected ones,
+ * the entries behind them are the rest of the tensor in the same order.  The
+ * tensor is updated exactly as by rigl_prune_regrow.  A test / inspection
+ * entry point: one stable 33-bit radix sort of the whole tensor per list.   */
+size_t rigl_prune_regrow_selections_workspace_bytes(int64_t n);
+int rigl_prune_regrow_selections(const RiglPruneRegrowLayer* layer /* host */,
+                                 const RiglPruneRegrowParams* params,
+                                 uint32_t* out_mask1_bits, uint32_t* out_mask2_bits,
+                                 int32_t* out_idx1, int32_t* out_idx2,
+                                 int32_t* out_counts /* device, 8, nullable */,
+                                 void* workspace, size_t workspace_bytes,
+                                 rigl_stream_t stream);
+
 /* One-shot "keep the k best" mask (SNIP / DNW, sparse_optimizers.py:287-317,
  * :430-460): mask = the n_keep entries of score with the largest value, ties
  * by lower index.  Uses the same selection kernels as rigl_prune_regrow.    */

@@ -91,6 +91,9 @@ SIGNATURES = {
     'rigl_prune_regrow': (C.c_int, [C.POINTER(PruneRegrowLayer), _I32,
                                     C.POINTER(PruneRegrowParams), _P, _P, _SZ,
                                     _P]),
+    'rigl_prune_regrow_selections_workspace_bytes': (_SZ, [_I64]),
+    'rigl_prune_regrow_selections': (C.c_int, [C.POINTER(PruneRegrowLayer), C.POINTER(PruneRegrowParams), _P, _P, _P, _P, _P,
+                                               _P, _SZ, _P]),
     'rigl_topk_mask': (C.c_int, [_P, _I64, _I64, _P, _P, _SZ, _P]),
     'rigl_topk_mask_batched': (C.c_int, [C.POINTER(TopkLayer), _I32, _P, _SZ, _P]),
     'rigl_masked_sgd_momentum': (C.c_int, [_I64, _P, _P, _P, _P, _F, _F, _F, _F,

@@ -739,10 +739,10 @@ static int pp_bwd_dgrad_variant(const IgemmArgs& a) {
   const bool wide = a.N % 256 == 0;
   const int big = wide ? PP_256x256 : PP_512x128, small = wide ? PP_128x256 : PP_256x128;
   if (pp_bwd > 0) return pp_bwd == 2 ? small : big;
-  // built-in rule (tools/pp_sweep.py --passes bwd, batch 128): dgrad reductions of >= 8 K-tiles; the 128x64-per-wave
+  // built-in rule (tools/pp_sweep.py --passes bwd, batch 128): dgrad reductions of >= 16 K-tiles; the 128x64-per-wave
   // dgrad tiles where they give at least ~1/3 of the CUs a tile, the 64x64-per-wave tiles below that
   const int kt_d = a.KH * a.KW * (a.Cred / 64);
-  if (kt_d < tune_get("pp_bwd_min_kt", 8)) return PP_NONE;
+  if (kt_d < tune_get("pp_bwd_min_kt", 16)) return PP_NONE;     // (8-tile reductions measured neutral to slightly slower)
   const int64_t nbig = wide ? (int64_t)((a.M + 255) / 256) * (a.N / 256) : (int64_t)((a.M + 511) / 512) * (a.N / 128);
   return nbig >= 90 ? big : small;
 }

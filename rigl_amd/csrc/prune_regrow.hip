@@ -14,6 +14,10 @@
 // assemble the 1-bit/weight bitmap, LDS histograms, no MFMA.
 #include <vector>
 
+#include <string.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "common.hpp"
 
 // Bit-exact parity with the reference arithmetic: every fp32 product / sum is
@@ -724,6 +728,68 @@ __global__ __launch_bounds__(BLOCK) void k_apply2(const LayerDev* __restrict__ L
   }
 }
 
+// The two selections of an update, read back (rigl_prune_regrow_selections; one layer): mask1 (the kept set, already a
+// bitmap), mask2 (the grown set, computed exactly as k_apply2 does) and, per element, a 33-bit sort key
+// (selected << 32) | score key -- a STABLE descending radix sort of those with the element index as payload is
+// tf.nn.top_k's order (larger score first, equal scores by lower index: sparse_optimizers_base.py:293-318), selected
+// entries first.  Runs between the grow selection and k_apply2, i.e. on the OLD mask and weights.
+struct ExportDev {
+  uint32_t* m1;
+  uint32_t* m2;
+  unsigned long long* keys1;
+  unsigned long long* keys2;
+  int32_t* idx;
+};
+__global__ __launch_bounds__(BLOCK) void k_export(const LayerDev* __restrict__ Ls, const LayerState* __restrict__ St,
+                                                  const uint32_t* __restrict__ tie_cnt, const uint32_t* __restrict__ tie_off,
+                                                  ExportDev ex) {
+  __shared__ uint32_t sh[BLOCK];
+  const LayerDev L = Ls[0];
+  const LayerState& S = St[0];
+  const SelState sel = S.g;
+  const uint32_t cl = blockIdx.x;
+  uint32_t key1[SEGS][4], key2[SEGS][4], tie_nib[SEGS], rank_base[SEGS], m1[SEGS];
+  Pos q[SEGS];
+#pragma unroll
+  for (int j = 0; j < SEGS; ++j) {
+    q[j] = quad_pos(L.n, cl, j);
+    tie_nib[j] = 0u;
+    m1[j] = 0u;
+    if (q[j].nvalid) {
+      m1[j] = load_nibble(L.mask1, q[j]);
+      const uint32_t nib = L.sdrop ? 0u : load_nibble(L.mask, q[j]);
+      drop_keys(L, q[j], nib, key1[j]);
+      grow_scores(L, q[j], key2[j]);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        if ((m1[j] >> v) & 1u) key2[j][v] = S.lifted_key;
+        tie_nib[j] |= ((v < q[j].nvalid && key2[j][v] == sel.T) ? 1u : 0u) << v;
+      }
+    }
+  }
+  const uint32_t c_ties = sel.mode == 0u ? tie_cnt[blockIdx.x] : 0u;
+  const uint32_t c_off = sel.mode == 0u ? tie_off[blockIdx.x] : 0u;
+  tie_rank_bases(tie_nib, c_off, c_ties, sel.r, sh, rank_base);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < SEGS; ++j) {
+    const uint32_t in2 = q[j].nvalid ? select_nibble(key2[j], q[j].nvalid, sel, rank_base[j]) : 0u;
+    if (ex.m1) store_nibble(ex.m1, q[j], m1[j]);
+    if (ex.m2) store_nibble(ex.m2, q[j], in2);
+    if (ex.keys1) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        if (v < q[j].nvalid) {
+          const int64_t e = q[j].e0 + v;
+          ex.keys1[e] = ((unsigned long long)((m1[j] >> v) & 1u) << 32) | key1[j][v];
+          ex.keys2[e] = ((unsigned long long)((in2 >> v) & 1u) << 32) | key2[j][v];
+          ex.idx[e] = (int32_t)e;
+        }
+      }
+    }
+  }
+}
+
 __global__ void k_counts(const LayerState* __restrict__ St, int n_layers, int32_t* __restrict__ out) {
   int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= n_layers) return;
@@ -783,7 +849,7 @@ static Layout make_layout(const int64_t* n_per_layer, int n_layers) {
 
 static int run(const RiglPruneRegrowLayer* layers, int n_layers, const int64_t* fixed_k, const Params& prm,
                bool with_grow, uint32_t* const* mask1_override, int32_t* out_counts, void* ws, size_t ws_bytes,
-               hipStream_t stream) {
+               hipStream_t stream, const ExportDev* ex = nullptr) {
   if (n_layers <= 0) return RIGL_OK;
   std::vector<int64_t> ns(n_layers);
   for (int i = 0; i < n_layers; ++i) {
@@ -870,6 +936,7 @@ static int run(const RiglPruneRegrowLayer* layers, int n_layers, const int64_t* 
   hipLaunchKernelGGL((k_scan<1, 2>), dim3(n_layers), dim3(BLOCK), 0, stream, dL, dS, prm);
   hipLaunchKernelGGL(k_tiecount<1>, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers, tie_cnt);
   hipLaunchKernelGGL(k_tiescan, dim3(n_layers), dim3(BLOCK), 0, stream, dL, tie_cnt, tie_off);
+  if (ex) hipLaunchKernelGGL(k_export, dim3(C), dim3(BLOCK), 0, stream, dL, dS, tie_cnt, tie_off, *ex);
   hipLaunchKernelGGL(k_apply2, dim3(C), dim3(BLOCK), 0, stream, dL, dS, n_layers, tie_cnt, tie_off, prm);
   if (out_counts)
     hipLaunchKernelGGL(k_counts, dim3((n_layers + 63) / 64), dim3(64), 0, stream, dS, n_layers, out_counts);
@@ -904,6 +971,61 @@ int rigl_prune_regrow(const RiglPruneRegrowLayer* layers, int32_t n_layers, cons
   p.reinit_when_same = params->reinit_when_same;
   return rigl::k2::run(layers, n_layers, nullptr, p, true, nullptr, out_counts, workspace, workspace_bytes,
                        rigl::as_stream(stream));
+}
+
+// ---- the two selections, read back -------------------------------------------------------------------------------------
+static size_t sel_sort_temp_bytes(int64_t n) {
+  size_t t = 0;
+  (void)rocprim::radix_sort_pairs_desc(nullptr, t, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int32_t*)nullptr,
+                                       (int32_t*)nullptr, (size_t)n, 0, 33, (hipStream_t)0);
+  return t;
+}
+struct SelLayout { size_t k2ws, keys1, keys2, keys_out, idx, temp, total; };
+static SelLayout sel_layout(int64_t n) {
+  SelLayout l;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += rigl::align_up(bytes, 256); return o; };
+  l.k2ws = take(rigl::k2::make_layout(&n, 1).total);
+  l.keys1 = take((size_t)n * 8); l.keys2 = take((size_t)n * 8); l.keys_out = take((size_t)n * 8);
+  l.idx = take((size_t)n * 4);
+  l.temp = take(sel_sort_temp_bytes(n));
+  l.total = off;
+  return l;
+}
+
+size_t rigl_prune_regrow_selections_workspace_bytes(int64_t n) { return n > 0 ? sel_layout(n).total : 0; }
+
+int rigl_prune_regrow_selections(const RiglPruneRegrowLayer* layer, const RiglPruneRegrowParams* params,
+                                 uint32_t* out_mask1_bits, uint32_t* out_mask2_bits, int32_t* out_idx1, int32_t* out_idx2,
+                                 int32_t* out_counts, void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+  if (!layer || !params) return rigl::fail(RIGL_EINVAL, "rigl_prune_regrow_selections: NULL layer/params");
+  if (layer->n <= 0 || layer->n >= (int64_t(1) << 31)) return rigl::fail(RIGL_EINVAL, "rigl_prune_regrow_selections: n out of range");
+  if ((out_idx1 == nullptr) != (out_idx2 == nullptr)) return rigl::fail(RIGL_EINVAL, "rigl_prune_regrow_selections: give both index lists or neither");
+  if (!(params->drop_fraction >= 0.f) || params->drop_fraction > 1.f || params->grow_init_mode < 0 || params->grow_init_mode > 3)
+    return rigl::fail(RIGL_EINVAL, "rigl_prune_regrow_selections: bad params");
+  const SelLayout lo = sel_layout(layer->n);
+  if (!workspace || workspace_bytes < lo.total)
+    return rigl::fail(RIGL_EWORKSPACE, "rigl_prune_regrow_selections: workspace %zu < required %zu", workspace_bytes, lo.total);
+  char* base = static_cast<char*>(workspace);
+  hipStream_t st = rigl::as_stream(stream);
+  rigl::k2::ExportDev ex = {out_mask1_bits, out_mask2_bits, nullptr, nullptr, nullptr};
+  if (out_idx1) {
+    ex.keys1 = reinterpret_cast<unsigned long long*>(base + lo.keys1);
+    ex.keys2 = reinterpret_cast<unsigned long long*>(base + lo.keys2);
+    ex.idx = reinterpret_cast<int32_t*>(base + lo.idx);
+  }
+  rigl::k2::Params p;
+  p.drop_fraction = params->drop_fraction; p.grow_init_mode = params->grow_init_mode; p.grow_init_div = params->grow_init_div;
+  p.momentum_reset_mode = params->momentum_reset_mode; p.initial_acc_scale = params->initial_acc_scale;
+  p.reinit_when_same = params->reinit_when_same;
+  int rc = rigl::k2::run(layer, 1, nullptr, p, true, nullptr, out_counts, base + lo.k2ws, lo.total - lo.k2ws, st, &ex);
+  if (rc || !out_idx1) return rc;
+  // stable descending sort of (selected, key): selected entries first, larger score first, equal scores by lower index
+  size_t tb = sel_sort_temp_bytes(layer->n);
+  unsigned long long* ko = reinterpret_cast<unsigned long long*>(base + lo.keys_out);
+  RIGL_HIP(rocprim::radix_sort_pairs_desc(base + lo.temp, tb, ex.keys1, ko, ex.idx, out_idx1, (size_t)layer->n, 0, 33, st));
+  RIGL_HIP(rocprim::radix_sort_pairs_desc(base + lo.temp, tb, ex.keys2, ko, ex.idx, out_idx2, (size_t)layer->n, 0, 33, st));
+  return RIGL_OK;
 }
 
 int rigl_topk_mask_batched(const RiglTopkLayer* layers, int32_t n_layers, void* workspace, size_t workspace_bytes,

@@ -177,6 +177,42 @@ def prune_regrow(layers, drop_fraction, grow_init_mode=_lib.GROW_ZEROS,
   return counts
 
 
+def prune_regrow_selections(layer, drop_fraction, grow_init_mode=_lib.GROW_ZEROS, grow_init_div=1.0,
+                            momentum_reset_mode=_lib.MOMRESET_GRAD, initial_acc_scale=0.0, reinit_when_same=False,
+                            want_indices=True):
+  """``prune_regrow`` on ONE layer (same dict), with the two selections read back (rigl_prune_regrow_selections): returns
+  dict(counts int32[8], mask1_bits, mask2_bits (int32 bitmaps) and -- with ``want_indices`` -- idx1, idx2 int32[n]: the
+  tensor's indices in tf.nn.top_k order of the drop / lifted grow score; the first counts[2] (n_keep) resp. counts[1]
+  (n_prune) entries are the selected ones)."""
+  lib = _lib.load()
+  w = layer.get('w')
+  ref = w if w is not None else layer['score_drop']
+  n, dev = ref.numel(), ref.device
+  arr = PruneRegrowLayer()
+  arr.n = n
+  arr.w = w.data_ptr() if w is not None else None
+  for key in ('momentum', 'dense_grad', 'drop_noise', 'score_drop', 'score_grow', 'grow_values'):
+    t = layer.get(key)
+    _req(t, torch.float32, key, allow_none=True)
+    setattr(arr, key, t.data_ptr() if t is not None else None)
+  _req(layer['mask_bits'], torch.int32, 'mask_bits')
+  arr.mask_bits = layer['mask_bits'].data_ptr()
+  prm = PruneRegrowParams(float(drop_fraction), int(grow_init_mode), float(grow_init_div), int(momentum_reset_mode),
+                          float(initial_acc_scale), int(bool(reinit_when_same)))
+  words = n_mask_words(n)
+  out = dict(counts=torch.zeros(_lib.COUNTS_PER_LAYER, dtype=torch.int32, device=dev),
+             mask1_bits=torch.zeros(words, dtype=torch.int32, device=dev),
+             mask2_bits=torch.zeros(words, dtype=torch.int32, device=dev))
+  if want_indices:
+    out['idx1'] = torch.empty(n, dtype=torch.int32, device=dev)
+    out['idx2'] = torch.empty(n, dtype=torch.int32, device=dev)
+  ws = workspace(lib.rigl_prune_regrow_selections_workspace_bytes(n), dev, 'k2sel')
+  check(lib.rigl_prune_regrow_selections(C.byref(arr), C.byref(prm), _ptr(out['mask1_bits']), _ptr(out['mask2_bits']),
+                                         _ptr(out.get('idx1')), _ptr(out.get('idx2')), _ptr(out['counts']), _ptr(ws),
+                                         ws.numel(), _stream()))
+  return out
+
+
 def topk_mask(score, n_keep, out=None):
   """Bitmap of the n_keep largest scores (ties: lower flat index first)."""
   _req(score, torch.float32, 'score')

@@ -71,6 +71,68 @@ def test_golden_reference_cases_one_by_one():
     assert counts[7] == counts[0]    # number of connections conserved
 
 
+def _check_selections(ops, name, mask, w, g, frac, noise, mom, grow_init, acc_scale):
+  """mask1, mask2 and the ordered top-k index lists of one update against the oracle's (sparse_optimizers_base.py:293-318)."""
+  from rigl_amd import _lib
+  n = mask.size
+  tw, tg = _t(w), _t(g)
+  tm = _t(mom) if mom is not None else None
+  tn = _t(noise) if noise is not None else None
+  bits = ops.mask_pack(_t(mask))
+  mode, div = _lib.GROW_ZEROS, 1.0
+  if grow_init.startswith('grad_scale'):
+    mode, div = _lib.GROW_GRAD_SCALE, O.extract_number(grow_init)
+  elif grow_init.startswith('grad_sign'):
+    mode, div = _lib.GROW_GRAD_SIGN, O.extract_number(grow_init)
+  out = ops.prune_regrow_selections(dict(w=tw, momentum=tm, mask_bits=bits, dense_grad=tg, drop_noise=tn), frac,
+                                    grow_init_mode=mode, grow_init_div=div, initial_acc_scale=acc_scale)
+  ref = O.rigl_mask_update(mask.reshape(-1), w.reshape(-1), g.reshape(-1), frac, noise=None if noise is None else noise.reshape(-1),
+                           momentum=None if mom is None else mom.reshape(-1), grow_init=grow_init, initial_acc_scale=acc_scale)
+  counts = out['counts'].cpu().numpy()
+  assert counts[2] == ref['n_keep'] and counts[1] == ref['n_prune'], (name, counts, ref['n_keep'], ref['n_prune'])
+  _diff(name + ' mask1', ops.mask_unpack(out['mask1_bits'], (n,)).cpu().numpy(), ref['mask1'])
+  _diff(name + ' mask2', ops.mask_unpack(out['mask2_bits'], (n,)).cpu().numpy(), ref['mask2'])
+  # the whole ordered lists (selected entries first, then the rest of the tensor in the same order) = the reference's top_k
+  np.testing.assert_array_equal(out['idx1'].cpu().numpy(), np.asarray(ref['idx1'], dtype=np.int32), err_msg=name + ' idx1')
+  np.testing.assert_array_equal(out['idx2'].cpu().numpy()[:ref['n_prune']], np.asarray(ref['idx2'], dtype=np.int32)[:ref['n_prune']],
+                                err_msg=name + ' idx2 (selected part)')
+  # ... and the update itself is the plain call's
+  _diff(name + ' new mask', ops.mask_unpack(bits, (n,)).cpu().numpy(), ref['mask'].reshape(-1))
+  _diff(name + ' new weights', tw.cpu().numpy(), ref['weights'].reshape(-1))
+  return ref
+
+
+def test_selections_and_topk_indices_on_the_golden_cases():
+  """North star: "masks and top-k indices must be bit-exact" -- mask1 / mask2 and the ordered index lists of
+  rigl_prune_regrow_selections on every reference-generated update case (missing #3)."""
+  from rigl_amd import ops
+  z = np.load(os.path.join(G, 'update_cases.npz'))
+  names = sorted({k.split('__')[0] for k in z.files if not k.startswith('generic_')})
+  for n in names:
+    g = lambda k: z['%s__%s' % (n, k)] if '%s__%s' % (n, k) in z.files else None
+    ref = _check_selections(ops, n, g('mask'), g('w'), g('g'), float(g('frac')), g('noise'), g('mom'), str(g('grow_init')),
+                            float(g('acc_scale')))
+    _diff(n + ' golden mask', ref['mask'].reshape(-1), g('new_mask').astype(np.float32))     # the oracle is the golden's twin
+
+
+def test_selections_with_heavy_ties_and_a_large_layer():
+  from rigl_amd import ops
+  rs = np.random.RandomState(5)
+  # heavy ties: weights and gradients drawn from a handful of values, so both thresholds cut through long runs of equals
+  n = 70001
+  mask = (rs.rand(n) < 0.3).astype(np.float32)
+  w = rs.choice([-0.5, -0.25, 0.25, 0.5, 1.0], size=n).astype(np.float32)
+  g = rs.choice([0.0, 0.125, -0.125, 0.75], size=n).astype(np.float32)
+  _check_selections(ops, 'ties', mask, w, g, 0.3, None, None, 'zeros', 0.0)
+  # a ResNet-50 3x3 layer (2.36 M weights) at ERK-0.8 density with noise
+  n = 3 * 3 * 512 * 512
+  mask = (rs.rand(n) < 0.2).astype(np.float32)
+  w = (rs.randn(n) * 0.05).astype(np.float32)
+  g = (rs.randn(n) * 1e-3).astype(np.float32)
+  noise = (rs.randn(n) * 1e-4).astype(np.float32)
+  _check_selections(ops, 'big', mask, w, g, 0.27, noise, (rs.randn(n) * 1e-2).astype(np.float32), 'zeros', 0.0)
+
+
 def test_golden_reference_cases_batched_single_call():
   """All golden layers in ONE rigl_prune_regrow call (segmented launches)."""
   from rigl_amd import ops
