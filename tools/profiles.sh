@@ -1,8 +1,10 @@
 #!/bin/bash
-# Round-2 profile set, all from one box and one build: outputs under gpurun_out/r2prof (copied to profiles/r2 afterwards).
+# The profile set of a round, all from one box and one build:  tools/profiles.sh <tag>  (e.g. r3) writes
+# gpurun_out/<tag>prof/, which is then copied to profiles/<tag>/ and committed.  Replaces the per-round run scripts.
 set -u
+TAG=${1:-r3}
 R="$(cd "$(dirname "$0")/.." && pwd)"
-O=$R/gpurun_out/r2prof; mkdir -p $O
+O=$R/gpurun_out/${TAG}prof; mkdir -p $O
 cd $R
 timeout 600 python bench.py > $O/bench_n1.json 2>$O/bench_err.txt; echo "bench rc=$?" | tee $O/log.txt
 for w in resnet50_erk99 mobilenet_v1 wrn22; do
@@ -10,6 +12,10 @@ for w in resnet50_erk99 mobilenet_v1 wrn22; do
 done
 timeout 300 python bench.py --workload wrn22 --graph --no-cpu-baseline > $O/bench_wrn22_graph.json 2>>$O/bench_err.txt; echo "wrn22 graph rc=$?" | tee -a $O/log.txt
 timeout 600 python tools/bench_kernels.py > $O/bench_kernels_per_layer.txt 2>&1; echo "bench_kernels rc=$?" | tee -a $O/log.txt
+timeout 600 python tools/pp_sweep.py --batch 128 --iters 20 --out $O/pp_sweep_b128.json > $O/pp_sweep_b128.txt 2>&1; echo "pp_sweep 128 rc=$?" | tee -a $O/log.txt
+timeout 600 python tools/pp_sweep.py --batch 512 --iters 10 --layers g3_c2_3x3_256 g3_c1_1024_256 g3_c3_256_1024 g4_c2_3x3_512 g2_c2_3x3_128 --out $O/pp_sweep_b512.json > $O/pp_sweep_b512.txt 2>&1; echo "pp_sweep 512 rc=$?" | tee -a $O/log.txt
+timeout 600 python tools/pp_sweep.py --batch 128 --iters 10 --passes bwd wgrad --out $O/pp_sweep_bwd_b128.json > $O/pp_sweep_bwd_b128.txt 2>&1; echo "pp_sweep bwd rc=$?" | tee -a $O/log.txt
+for i in 1 2 3; do timeout 300 python bench.py --no-cpu-baseline >> $O/bench_n1_runs.jsonl 2>>$O/bench_err.txt; done; echo "bench x3 rc=$?" | tee -a $O/log.txt
 timeout 300 python tools/k2_time.py > $O/k2_time.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 30 --warmup 10 --no-cpu-baseline > $O/prof_run.txt 2>&1; echo "rocprof rc=$?" | tee -a $O/log.txt
@@ -30,5 +36,6 @@ python $R/tools/k2_profile.py --summarise $(find $O/k2prof -name "*kernel_stats.
 rm -rf $O/k2prof
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mbprof -o mb -- python $R/bench.py --workload mobilenet_v1 --steps 20 --warmup 5 --no-cpu-baseline --no-prof > $O/mb_run.txt 2>&1
 cp $(find $O/mbprof -name "*kernel_stats.csv" | head -1) $O/mobilenet_kernel_stats.csv; rm -rf $O/mbprof
+timeout 900 python -m pytest tests -q -m gpu > $O/gpu_tests_final.txt 2>&1; echo "pytest gpu rc=$?" | tee -a $O/log.txt; tail -3 $O/gpu_tests_final.txt | tee -a $O/log.txt
 tail -3 $O/pmc_sq_k1.txt | tee -a $O/log.txt; tail -3 $O/k2_kernels.txt | tee -a $O/log.txt; tail -4 $O/bench_kernels_per_layer.txt | tee -a $O/log.txt
 ls -la $O | tee -a $O/log.txt
