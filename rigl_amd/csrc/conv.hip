@@ -1916,8 +1916,11 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
     if (dvar != PP_NONE && pp_legal<1>(ad, dvar)) {
       int bm, bn;
       pp_dims(dvar, bm, bn);
-      const unsigned nd = (unsigned)(((ad.M + bm - 1) / bm) * (ad.N / bn));
-      const int kt_d = (int)((int64_t)d->kh * d->kw * (d->cout / 64) * bm * bn / (256 * 256));   // in 256x256-tile K-tile units
+      const bool strided = pp_strided(ad);
+      const int tiles_m = strided ? pp_fill_classes(ad, bm) : (ad.M + bm - 1) / bm;
+      const unsigned nd = (unsigned)(tiles_m * (ad.N / bn));
+      // dgrad workgroup length in 256x256-tile K-tile units (a parity class visits about taps / (sh * sw) of the taps)
+      const int kt_d = (int)((int64_t)d->kh * d->kw * (d->cout / 64) * bm * bn / (256 * 256) / (d->stride_h * d->stride_w));
       const PPBwdPlan pw = plan_wgrad_pp(d, pp_wgrad_kind(d), nd, kt_d);
       const size_t need = rigl_conv2d_workspace_bytes(d, 2);
       if (need && (!workspace || workspace_bytes < need))
@@ -1936,7 +1939,7 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
         const int64_t pairs = ceil_div64(ceil_div64(flush->n_out, 64), 2);
         nr = (unsigned)(pairs < (int64_t)num_cus() ? pairs : (int64_t)num_cus());
       }
-      if (pp_bwd_launch(dvar, pw.wk, ad, aw, pw, pr, nr, st)) {
+      if (pp_bwd_launch(dvar, pw.wk, strided, ad, aw, pw, pr, nr, st)) {
         if (pw.splits > 1) {
           if (defer) {
             defer->slabs = static_cast<const float*>(workspace); defer->dw = dw; defer->n_out = pw.slab;

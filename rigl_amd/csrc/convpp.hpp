@@ -66,8 +66,13 @@ struct PPGeom {
 
 struct PPCursor { int tap, cb, r, s; };
 
-template <int WM, int WN, int TM, int TN, int PH, int MODE /*0 fwd, 1 dgrad (stride 1)*/>
+// CLS (dgrad of a strided conv): rows are enumerated per stride-parity class (h % sh, w % sw) exactly as igemm_body does --
+// a tile never mixes classes, so it only visits the filter taps that can reach its pixels (3x3 / 2: 4, 2, 2 or 1 taps;
+// 1x1 / 2: three classes have none and just write zeros), and inside a class the gathered dY pixel moves by -1 per
+// visited tap, like a stride-1 dgrad.
+template <int WM, int WN, int TM, int TN, int PH, int MODE /*0 fwd, 1 dgrad*/, bool CLS = false>
 __device__ __forceinline__ void pp_igemm_body(const IgemmArgs& P, unsigned char* const smem, uint32_t bid, uint32_t nblk) {
+  static_assert(!CLS || MODE == 1, "parity classes are a dgrad notion");
   using G = PPGeom<WM, WN, TM, TN, PH>;
   constexpr int BM = G::BM, BN = G::BN, NA = G::NA, NB = G::NB, QM = G::QM, QN = G::QN;
   constexpr int STAGE = G::STAGE, AH_BYTES = G::AH_BYTES, BH_BYTES = G::BH_BYTES;
@@ -79,12 +84,52 @@ __device__ __forceinline__ void pp_igemm_body(const IgemmArgs& P, unsigned char*
   const uint32_t tile = xcd_remap(bid, nblk);
   const int tile_m = (int)(tile / (uint32_t)P.tiles_n);
   const int n0 = (int)(tile % (uint32_t)P.tiles_n) * BN;
-  const int m0 = tile_m * BM;
+  int m0 = tile_m * BM;
+  int c_ph = 0, c_pw = 0, c_cnt = P.M, c_hc = 1, c_wc = 1;
+  FastDiv c_fwc = {0u, 0u}, c_fhc = {0u, 0u};
+  if (CLS) {
+    // classes interleaved round-robin over tile_m (the XCD remap hands each XCD a contiguous range of tile_m and the
+    // classes differ in work), the left-over tiles class by class -- the igemm_body map, on this body's tile height
+    int c, local;
+    const int il = P.cls_interleave * P.cls_n;
+    if (tile_m < il) {
+      c = P.cls_ids[tile_m % P.cls_n]; local = tile_m / P.cls_n;
+    } else {
+      int rest = tile_m - il;
+      c = 0; local = 0;
+      for (int k = 0; k < 4; ++k) {
+        const int tc = P.cls_tile_begin[k + 1] - P.cls_tile_begin[k];
+        const int have = P.cls_cnt[k] > 0 ? (tc > P.cls_interleave ? tc - P.cls_interleave : 0) : tc;
+        if (rest < have) { c = k; local = (P.cls_cnt[k] > 0 ? P.cls_interleave : 0) + rest; break; }
+        rest -= have;
+      }
+    }
+    m0 = local * BM;
+    c_ph = c / P.sw; c_pw = c % P.sw;
+    c_cnt = P.cls_cnt[c]; c_hc = P.cls_hc[c]; c_wc = P.cls_wc[c];
+    c_fwc = P.fd_cwc[c]; c_fhc = P.fd_chc[c];
+  }
+  // visited taps: (r0 + i * r_step, s0 + j * s_step), i < n_r, j < n_s
+  const int r0 = CLS ? (c_ph + P.ph) % P.sh : 0, s0 = CLS ? (c_pw + P.pw) % P.sw : 0;
+  const int r_step = CLS ? P.sh : 1, s_step = CLS ? P.sw : 1;
+  const int n_r = CLS ? (r0 < P.KH ? (P.KH - r0 + r_step - 1) / r_step : 0) : P.KH;
+  const int n_s = CLS ? (s0 < P.KW ? (P.KW - s0 + s_step - 1) / s_step : 0) : P.KW;
+  // row index (class-local for CLS) -> output pixel (n, rh, rw)
+#define PP_ROW_PIXEL(mm_, n_, rh_, rw_)                                                                  \
+  {                                                                                                      \
+    if (CLS) {                                                                                           \
+      const int t_ = fdiv(mm_, c_fwc), w2_ = (mm_) - t_ * c_wc;                                          \
+      n_ = fdiv(t_, c_fhc);                                                                              \
+      rw_ = w2_ * P.sw + c_pw; rh_ = (t_ - n_ * c_hc) * P.sh + c_ph;                                     \
+    } else {                                                                                             \
+      const int t_ = fdiv(mm_, P.fd_rw);                                                                 \
+      rw_ = (mm_) - t_ * P.RW; n_ = fdiv(t_, P.fd_rh); rh_ = t_ - n_ * P.RH;                             \
+    }                                                                                                    \
+  }
 
   // ---- per-thread DMA rows (fixed for the whole K loop) -----------------------------------------------------------
   // Piece h, instruction j of wave w fills piece rows (j*8 + w)*8 .. +7; lane l: row +(l >> 3), 16-byte slot l & 7,
   // fetching source chunk slot ^ ((row >> 1) & 7).
-  const int taps = P.KH * P.KW;
   int a_base[2][NA];
   uint32_t a_mask[2][NA];
 #pragma unroll
@@ -95,21 +140,25 @@ __device__ __forceinline__ void pp_igemm_body(const IgemmArgs& P, unsigned char*
       const int wmr = lr / (QM * 32), rem = lr % (QM * 32);
       const int m = m0 + wmr * TM * 32 + h * QM * 32 + rem;
       const int dchunk = (lane & 7) ^ ((lr >> 1) & 7);
-      const bool ok = m < P.M;
+      const bool ok = m < c_cnt;
       const int mm = ok ? m : 0;
-      const int t = fdiv(mm, P.fd_rw);
-      const int rw = mm - t * P.RW, n = fdiv(t, P.fd_rh), rh = t - n * P.RH;
-      const int c0 = MODE == 0 ? rh * P.sh - P.ph : rh + P.ph, c1 = MODE == 0 ? rw * P.sw - P.pw : rw + P.pw;
+      int n, rh, rw;
+      PP_ROW_PIXEL(mm, n, rh, rw);
+      // first visited tap's gathered pixel (c0, c1); visited tap (i, j) reads (c0 +- i, c1 +- j)
+      int c0, c1;
+      if (MODE == 0) { c0 = rh * P.sh - P.ph; c1 = rw * P.sw - P.pw; }
+      else if (CLS) { c0 = (rh + P.ph - r0) / P.sh; c1 = (rw + P.pw - s0) / P.sw; }     // exact inside a parity class
+      else { c0 = rh + P.ph; c1 = rw + P.pw; }
       a_base[h][j] = ((n * P.GH + c0) * P.GW + c1) * P.a_pix_stride + dchunk * 8;
-      // bit (r*KW + s) = tap (r, s) reads inside the image: rows r with 0 <= c0 +- r < GH, columns likewise
+      // bit (i * n_s + j) = visited tap (i, j) reads inside the image: rows i with 0 <= c0 +- i < GH, columns likewise
       uint32_t mk = 0u;
       if (ok) {
         const int s_lo = MODE == 0 ? -c1 : c1 - P.GW + 1, s_hi = MODE == 0 ? P.GW - 1 - c1 : c1;
         const int r_lo = MODE == 0 ? -c0 : c0 - P.GH + 1, r_hi = MODE == 0 ? P.GH - 1 - c0 : c0;
-        const int sl = s_lo > 0 ? s_lo : 0, sh_ = s_hi < P.KW - 1 ? s_hi : P.KW - 1;
+        const int sl = s_lo > 0 ? s_lo : 0, sh_ = s_hi < n_s - 1 ? s_hi : n_s - 1;
         const uint32_t cm = sh_ >= sl ? ((2u << sh_) - 1u) & ~((1u << sl) - 1u) : 0u;
-        for (int r = 0; r < P.KH; ++r)
-          if (r >= r_lo && r <= r_hi) mk |= cm << (r * P.KW);
+        for (int r = 0; r < n_r; ++r)
+          if (r >= r_lo && r <= r_hi) mk |= cm << (r * n_s);
       }
       a_mask[h][j] = mk;
     }
@@ -126,12 +175,12 @@ __device__ __forceinline__ void pp_igemm_body(const IgemmArgs& P, unsigned char*
     }
   const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.A, P.a_bytes), rsrcB = make_rsrc(P.B, P.b_bytes);
   const int kcb = P.Cred >> 6;
-  const int KT = taps * kcb;
+  const int KT = n_r * n_s * kcb;
   const int a_row_step = (MODE == 0 ? P.GW : -P.GW) * P.a_pix_stride, a_col_step = (MODE == 0 ? 1 : -1) * P.a_pix_stride;
 
 #define PP_CURSOR_T PPCursor
 #define PP_CURSOR_ZERO(c_) { (c_).tap = 0; (c_).cb = 0; (c_).r = 0; (c_).s = 0; }
-#define PP_NEXT(c_) { if (++(c_).cb == kcb) { (c_).cb = 0; ++(c_).tap; if (++(c_).s == P.KW) { (c_).s = 0; ++(c_).r; } } }
+#define PP_NEXT(c_) { if (++(c_).cb == kcb) { (c_).cb = 0; ++(c_).tap; if (++(c_).s == n_s) { (c_).s = 0; ++(c_).r; } } }
 #define PP_ISSUE_A(h_, stage_, c_)                                                                       \
   {                                                                                                      \
     const int da_ = (c_).r * a_row_step + (c_).s * a_col_step + ((c_).cb << 6);                          \
@@ -145,7 +194,7 @@ __device__ __forceinline__ void pp_igemm_body(const IgemmArgs& P, unsigned char*
   }
 #define PP_ISSUE_B(h_, stage_, c_)                                                                       \
   {                                                                                                      \
-    const int db_ = (c_).tap * P.b_tap_stride + ((c_).cb << 6);                                          \
+    const int db_ = ((r0 + (c_).r * r_step) * P.KW + s0 + (c_).s * s_step) * P.b_tap_stride + ((c_).cb << 6); \
     _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                                     \
       const int off_ = (int)((uint32_t)(b_base[h_][j] + db_) * 2u);                                      \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                          \
@@ -193,7 +242,9 @@ __device__ __forceinline__ void pp_igemm_body(const IgemmArgs& P, unsigned char*
   // are two A and two B halves)
   constexpr int W4 = 2 * NA + 2 * NB, W2 = NA + NB, W1 = NA;
 
+  if (KT > 0) {        // (a parity class without a reachable tap -- 1x1 / 2: three of four -- only writes zeros)
 #include "convpp_loop.inc"
+  }
 #undef PP_READ_A
 #undef PP_READ_B
 #undef PP_QUAD
@@ -233,17 +284,29 @@ __device__ __forceinline__ void pp_igemm_body(const IgemmArgs& P, unsigned char*
           *reinterpret_cast<uint2*>(stg + row * ROWB + col * 2) = pk;
         }
     const int mrow0 = m0 + wm * TM * 32 + h * QM * 32;
+    // output row of each staged row: the row index itself, or (class-major rows) the pixel it enumerates; -1 = beyond the end
+    int mout[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int lm = mrow0 + it * RPI + rsub;
+      if (CLS) {
+        int n, rh, rw;
+        const int mm = lm < c_cnt ? lm : 0;
+        PP_ROW_PIXEL(mm, n, rh, rw);
+        mout[it] = lm < c_cnt ? (n * P.RH + rh) * P.RW + rw : -1;
+      } else {
+        mout[it] = lm < P.M ? lm : -1;
+      }
+    }
     uint4 addv[ITERS];
     if (P.ADD) {
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it) {
-        const int m = mrow0 + it * RPI + rsub;
-        addv[it] = m < P.M ? *reinterpret_cast<const uint4*>(P.ADD + (int64_t)m * P.ldc + ncol) : make_uint4(0u, 0u, 0u, 0u);
-      }
+      for (int it = 0; it < ITERS; ++it)
+        addv[it] = mout[it] >= 0 ? *reinterpret_cast<const uint4*>(P.ADD + (int64_t)mout[it] * P.ldc + ncol) : make_uint4(0u, 0u, 0u, 0u);
     }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-      const int row = it * RPI + rsub, m = mrow0 + row;
+      const int row = it * RPI + rsub, m = mout[it];
       uint4 v = *reinterpret_cast<const uint4*>(stg + row * ROWB + ch * 16);
       if (MODE == 0 && P.STATS) {
         const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
@@ -253,7 +316,7 @@ __device__ __forceinline__ void pp_igemm_body(const IgemmArgs& P, unsigned char*
           sy[c] += f; sq[c] = fmaf(f, f, sq[c]);
         }
       }
-      if (m < P.M) {
+      if (m >= 0) {
         if (P.ADD) {
           const uint4 q = addv[it];
           v.x = add_bf16x2(v.x, q.x); v.y = add_bf16x2(v.y, q.y); v.z = add_bf16x2(v.z, q.z); v.w = add_bf16x2(v.w, q.w);
@@ -291,10 +354,11 @@ __device__ __forceinline__ void pp_igemm_body(const IgemmArgs& P, unsigned char*
   }
 }
 
-template <int WM, int WN, int TM, int TN, int PH, int MODE>
+#undef PP_ROW_PIXEL
+template <int WM, int WN, int TM, int TN, int PH, int MODE, bool CLS = false>
 __global__ __launch_bounds__(512) void k_igemm_pp(IgemmArgs P) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_pp[];
-  pp_igemm_body<WM, WN, TM, TN, PH, MODE>(P, smem_pp, blockIdx.x, gridDim.x);
+  pp_igemm_body<WM, WN, TM, TN, PH, MODE, CLS>(P, smem_pp, blockIdx.x, gridDim.x);
 }
 
 // ---- weight gradient on the same skeleton ---------------------------------------------------------------------------------
@@ -662,7 +726,7 @@ __device__ __forceinline__ void pp_reduce_body(const ReduceArgs& R, unsigned cha
   }
 }
 
-template <int WMD, int WND, int TMD, int TND, int PHD, int WK /*0: 256x256 tiles, 1: K-grouped 128x128 tiles*/>
+template <int WMD, int WND, int TMD, int TND, int PHD, int WK /*0: 256x256 tiles, 1: K-grouped 128x128 tiles*/, bool CLSD = false>
 __global__ __launch_bounds__(512) void k_bwd_pp(IgemmArgs PD, WgradArgs PW, ReduceArgs PR, uint32_t nd, uint32_t nw, uint32_t wgrad_first) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_pp[];
   // longest jobs first: whichever body has the longer reduction per workgroup takes the low block indices; the reduce
@@ -674,7 +738,7 @@ __global__ __launch_bounds__(512) void k_bwd_pp(IgemmArgs PD, WgradArgs PW, Redu
     if constexpr (WK == 1) pp_wgrad_k_body(PW, smem_pp, wgrad_first ? b : b - nd, nw);
     else pp_wgrad_body<2>(PW, smem_pp, wgrad_first ? b : b - nd, nw);
   } else {
-    pp_igemm_body<WMD, WND, TMD, TND, PHD, 1>(PD, smem_pp, wgrad_first ? b - nw : b, nd);
+    pp_igemm_body<WMD, WND, TMD, TND, PHD, 1, CLSD>(PD, smem_pp, wgrad_first ? b - nw : b, nd);
   }
 }
 
@@ -686,18 +750,49 @@ struct PPPlan { int variant; unsigned grid; int bm, bn; };
 
 
 
-template <int WM, int WN, int TM, int TN, int PH, int MODE>
+template <int WM, int WN, int TM, int TN, int PH, int MODE, bool CLS = false>
 static bool pp_ready() {
-  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm_pp<WM, WN, TM, TN, PH, MODE>),
+  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm_pp<WM, WN, TM, TN, PH, MODE, CLS>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 PPGeom<WM, WN, TM, TN, PH>::SMEM) == hipSuccess;
   return ready;
 }
-template <int WM, int WN, int TM, int TN, int PH, int MODE>
+template <int WM, int WN, int TM, int TN, int PH, int MODE, bool CLS = false>
 static bool pp_launch_one(dim3 grid, const IgemmArgs& a, hipStream_t st) {
-  if (!pp_ready<WM, WN, TM, TN, PH, MODE>()) return false;
-  RIGL_K_LAUNCH((k_igemm_pp<WM, WN, TM, TN, PH, MODE>), grid, dim3(512), (PPGeom<WM, WN, TM, TN, PH>::SMEM), st, a);
+  if (!pp_ready<WM, WN, TM, TN, PH, MODE, CLS>()) return false;
+  RIGL_K_LAUNCH((k_igemm_pp<WM, WN, TM, TN, PH, MODE, CLS>), grid, dim3(512), (PPGeom<WM, WN, TM, TN, PH>::SMEM), st, a);
   return true;
+}
+// Parity-class tables of a strided dgrad on tiles of bm rows (the igemm plan's, on this body's tile height); returns
+// the number of row tiles.
+static int pp_fill_classes(IgemmArgs& a, int bm) {
+  const int n_img = a.M / (a.RH * a.RW);
+  int tiles = 0;
+  for (int c = 0; c < 4; ++c) {
+    const int ph = c / a.sw, pw = c % a.sw;
+    int hc = 0, wc = 0;
+    if (ph < a.sh && c < a.sh * a.sw) { hc = (a.RH - ph + a.sh - 1) / a.sh; wc = (a.RW - pw + a.sw - 1) / a.sw; }
+    a.cls_hc[c] = hc > 0 ? hc : 1; a.cls_wc[c] = wc > 0 ? wc : 1;
+    a.fd_chc[c] = make_fastdiv(a.cls_hc[c]); a.fd_cwc[c] = make_fastdiv(a.cls_wc[c]);
+    a.cls_cnt[c] = hc > 0 && wc > 0 ? n_img * hc * wc : 0;
+    a.cls_tile_begin[c] = tiles;
+    tiles += (a.cls_cnt[c] + bm - 1) / bm;
+  }
+  a.cls_tile_begin[4] = tiles;
+  a.cls_n = 0; a.cls_interleave = 1 << 30;
+  for (int c = 0; c < 4; ++c) {
+    const int tc = a.cls_tile_begin[c + 1] - a.cls_tile_begin[c];
+    if (tc > 0) { a.cls_ids[a.cls_n++] = c; if (tc < a.cls_interleave) a.cls_interleave = tc; }
+  }
+  if (a.cls_n == 0) { a.cls_n = 1; a.cls_ids[0] = 0; a.cls_interleave = 0; }
+  return tiles;
+}
+static inline bool pp_strided(const IgemmArgs& a) { return a.sh > 1 || a.sw > 1; }
+// row tiles of a ping-pong GEMM (class-major for a strided dgrad)
+template <int MODE>
+static int pp_tiles_m(const IgemmArgs& a, int bm) {
+  if (MODE == 1 && pp_strided(a)) { IgemmArgs t = a; return pp_fill_classes(t, bm); }
+  return (a.M + bm - 1) / bm;
 }
 
 static inline void pp_dims(int variant, int& bm, int& bn) {
@@ -719,7 +814,7 @@ static bool pp_legal(const IgemmArgs& a, int variant) {
   if (a.Cred % 64 || a.a_pix_stride != a.Cred) return false;
   if (a.N % bn) return false;
   if (a.KH * a.KW > 32) return false;
-  if (MODE == 1 && (a.sh != 1 || a.sw != 1)) return false;
+  if (MODE == 1 && (a.sh > 2 || a.sw > 2)) return false;     // strided dgrad: parity classes, strides <= 2 like igemm_body
   if (a.BNX) return false;
   if (a.M < bm) return false;
   return true;
@@ -731,7 +826,7 @@ static int pp_bwd_dgrad_variant(const IgemmArgs& a) {
   const int pp_bwd = tune_get("pp_bwd", -1);
   if (pp_bwd == 0) return PP_NONE;
   const int64_t m_out = (int64_t)(a.M / (a.RH * a.RW)) * a.GH * a.GW;
-  if (a.N % 128 || a.Cred % 128 || m_out < 256 || a.KH * a.KW > 32 || a.BNX || a.sh != 1 || a.sw != 1) return PP_NONE;
+  if (a.N % 128 || a.Cred % 128 || m_out < 256 || a.KH * a.KW > 32 || a.BNX || a.sh > 2 || a.sw > 2) return PP_NONE;
   // the weight gradient that would share the launch must exist: 128-channel tiles need the K-grouped body
   const int wkf = tune_get("pp_wk", -1);
   const bool c256 = a.N % 256 == 0 && a.Cred % 256 == 0;
@@ -741,9 +836,10 @@ static int pp_bwd_dgrad_variant(const IgemmArgs& a) {
   if (pp_bwd > 0) return pp_bwd == 2 ? small : big;
   // built-in rule (tools/pp_sweep.py --passes bwd, batch 128): dgrad reductions of >= 16 K-tiles; the 128x64-per-wave
   // dgrad tiles where they give at least ~1/3 of the CUs a tile, the 64x64-per-wave tiles below that
-  const int kt_d = a.KH * a.KW * (a.Cred / 64);
+  // (a strided dgrad: the longest parity class, ceil(KH / sh) x ceil(KW / sw) taps)
+  const int kt_d = ((a.KH + a.sh - 1) / a.sh) * ((a.KW + a.sw - 1) / a.sw) * (a.Cred / 64);
   if (kt_d < tune_get("pp_bwd_min_kt", 16)) return PP_NONE;     // (8-tile reductions measured neutral to slightly slower)
-  const int64_t nbig = wide ? (int64_t)((a.M + 255) / 256) * (a.N / 256) : (int64_t)((a.M + 511) / 512) * (a.N / 128);
+  const int64_t nbig = wide ? (int64_t)pp_tiles_m<1>(a, 256) * (a.N / 256) : (int64_t)pp_tiles_m<1>(a, 512) * (a.N / 128);
   return nbig >= 90 ? big : small;
 }
 
@@ -770,7 +866,7 @@ static PPPlan plan_pp(const IgemmArgs& a) {
   if (v == PP_NONE || !pp_legal<MODE>(a, v)) return p;
   pp_dims(v, p.bm, p.bn);
   p.variant = v;
-  p.grid = (unsigned)(((a.M + p.bm - 1) / p.bm) * (a.N / p.bn));
+  p.grid = (unsigned)(pp_tiles_m<MODE>(a, p.bm) * (a.N / p.bn));
   return p;
 }
 
@@ -783,6 +879,18 @@ static bool launch_pp(const PPPlan& p, const IgemmArgs& a0, hipStream_t st) {
   // phases per K-tile: the 128x64 wave tiles run 2 (16 MFMAs between barriers; "pp_ph" = 4 selects one quadrant per
   // phase), the 64x64 wave tiles 1 with three stages ("pp_ph" = 4 selects the four-phase, two-stage form)
   const int ph = tune_get("pp_ph", 0);
+  if constexpr (MODE == 1) {
+    if (pp_strided(a)) {
+      pp_fill_classes(a, p.bm);
+      switch (p.variant) {
+        case PP_256x256: return pp_launch_one<2, 4, 4, 2, 2, 1, true>(grid, a, st);
+        case PP_128x256: return pp_launch_one<2, 4, 2, 2, 1, 1, true>(grid, a, st);
+        case PP_256x128: return pp_launch_one<4, 2, 2, 2, 1, 1, true>(grid, a, st);
+        case PP_512x128: return pp_launch_one<4, 2, 4, 2, 2, 1, true>(grid, a, st);
+        default: return false;
+      }
+    }
+  }
   switch (p.variant) {
     case PP_256x256:
       return ph == 4 ? pp_launch_one<2, 4, 4, 2, 4, MODE>(grid, a, st) : pp_launch_one<2, 4, 4, 2, 2, MODE>(grid, a, st);
@@ -902,19 +1010,27 @@ static bool pp_wgrad_launch(const PPBwdPlan& p, const WgradArgs& aw, hipStream_t
   }
   return true;
 }
-template <int WMD, int WND, int TMD, int TND, int PHD, int WK>
+template <int WMD, int WND, int TMD, int TND, int PHD, int WK, bool CLSD = false>
 static bool pp_bwd_launch_one(const IgemmArgs& ad, const WgradArgs& aw, const ReduceArgs& pr, unsigned nr, unsigned nd, unsigned nw,
                               bool wgrad_first, hipStream_t st) {
   constexpr int SM_D = PPGeom<WMD, WND, TMD, TND, PHD>::SMEM, SM_W = WK ? PPK_SMEM : PPGeom<2, 4, 4, 2, 2>::SMEM, SM = SM_D > SM_W ? SM_D : SM_W;
-  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_pp<WMD, WND, TMD, TND, PHD, WK>),
+  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_pp<WMD, WND, TMD, TND, PHD, WK, CLSD>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM) == hipSuccess;
   if (!ready) return false;
-  RIGL_K_LAUNCH((k_bwd_pp<WMD, WND, TMD, TND, PHD, WK>), dim3(nd + nw + nr), dim3(512), SM, st, ad, aw, pr, nd, nw, (uint32_t)(wgrad_first ? 1u : 0u));
+  RIGL_K_LAUNCH((k_bwd_pp<WMD, WND, TMD, TND, PHD, WK, CLSD>), dim3(nd + nw + nr), dim3(512), SM, st, ad, aw, pr, nd, nw, (uint32_t)(wgrad_first ? 1u : 0u));
   return true;
 }
-// dvar = the dgrad tile, wk = the weight-gradient body
-static bool pp_bwd_launch(int dvar, int wk, const IgemmArgs& ad, const WgradArgs& aw, const PPBwdPlan& pw, const ReduceArgs& pr, unsigned nr,
-                          hipStream_t st) {
+// dvar = the dgrad tile, wk = the weight-gradient body, strided = parity-class dgrad
+static bool pp_bwd_launch(int dvar, int wk, bool strided, const IgemmArgs& ad, const WgradArgs& aw, const PPBwdPlan& pw, const ReduceArgs& pr,
+                          unsigned nr, hipStream_t st) {
+  if (strided) {
+    if (wk) return false;
+    switch (dvar) {
+      case PP_256x256: return pp_bwd_launch_one<2, 4, 4, 2, 2, 0, true>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
+      case PP_128x256: return pp_bwd_launch_one<2, 4, 2, 2, 1, 0, true>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
+      default: return false;
+    }
+  }
   if (wk) {
     switch (dvar) {
       case PP_256x256: return pp_bwd_launch_one<2, 4, 4, 2, 2, 1>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);

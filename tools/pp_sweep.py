@@ -133,7 +133,7 @@ def legal(v, ps, B, H, W, Cin, Cout, s, Ho, Wo):
   """Mirror of pp_legal (convpp.hpp): where the library would silently keep the igemm body."""
   bm, bn = DIMS[v]
   M, N, K = (B * Ho * Wo, Cout, Cin) if ps == 'fwd' else (B * H * W, Cin, Cout)
-  if ps == 'dgrad' and s != 1:
+  if ps == 'dgrad' and s > 2:
     return False
   return K % 64 == 0 and N % bn == 0 and M >= bm
 

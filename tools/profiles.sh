@@ -36,6 +36,6 @@ python $R/tools/k2_profile.py --summarise $(find $O/k2prof -name "*kernel_stats.
 rm -rf $O/k2prof
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mbprof -o mb -- python $R/bench.py --workload mobilenet_v1 --steps 20 --warmup 5 --no-cpu-baseline --no-prof > $O/mb_run.txt 2>&1
 cp $(find $O/mbprof -name "*kernel_stats.csv" | head -1) $O/mobilenet_kernel_stats.csv; rm -rf $O/mbprof
-timeout 900 python -m pytest tests -q -m gpu > $O/gpu_tests_final.txt 2>&1; echo "pytest gpu rc=$?" | tee -a $O/log.txt; tail -3 $O/gpu_tests_final.txt | tee -a $O/log.txt
+cd $R; timeout 900 python -m pytest tests -q -m gpu > $O/gpu_tests_final.txt 2>&1; echo "pytest gpu rc=$?" | tee -a $O/log.txt; tail -3 $O/gpu_tests_final.txt | tee -a $O/log.txt
 tail -3 $O/pmc_sq_k1.txt | tee -a $O/log.txt; tail -3 $O/k2_kernels.txt | tee -a $O/log.txt; tail -4 $O/bench_kernels_per_layer.txt | tee -a $O/log.txt
 ls -la $O | tee -a $O/log.txt
