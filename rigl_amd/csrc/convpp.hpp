@@ -839,7 +839,9 @@ static int pp_bwd_dgrad_variant(const IgemmArgs& a) {
   // (a strided dgrad: the longest parity class, ceil(KH / sh) x ceil(KW / sw) taps)
   const int kt_d = ((a.KH + a.sh - 1) / a.sh) * ((a.KW + a.sw - 1) / a.sw) * (a.Cred / 64);
   if (kt_d < tune_get("pp_bwd_min_kt", 16)) return PP_NONE;     // (8-tile reductions measured neutral to slightly slower)
-  const int64_t nbig = wide ? (int64_t)pp_tiles_m<1>(a, 256) * (a.N / 256) : (int64_t)pp_tiles_m<1>(a, 512) * (a.N / 128);
+  // (a strided dgrad counts the tiles of ONE parity class: the classes run one after the other in work, not side by side)
+  const int64_t rows = a.M / (a.sh * a.sw);
+  const int64_t nbig = wide ? ((rows + 255) / 256) * (a.N / 256) : ((rows + 511) / 512) * (a.N / 128);
   return nbig >= 90 ? big : small;
 }
 
