@@ -372,7 +372,7 @@ def main():
       # stamped with the library build it was collected on.
       traffic = traffic_build = None
       if args.workload == 'resnet50':
-        for rnd in ('r2', 'r1'):
+        for rnd in ('r3', 'r2', 'r1'):
           try:
             with open(os.path.join(ROOT, 'profiles', rnd, 'k1_traffic.json')) as fh:
               tj = json.load(fh)
@@ -397,6 +397,16 @@ def main():
           'by_kind_ms_per_step': {k: prof[k][0] / n_fwd_bwd for k in prof},
           'conv_share_of_step': (conv_ms / n_fwd_bwd) / ms_per_step,
       }
+      # the MFMA peak "re-measured on the box before use" -- register-only chains of
+      # v_mfma_f32_32x32x16_bf16 (rigl_probe_mfma_bf16), i.e. the clock-and-power-limited dense bf16 rate of THIS box;
+      # `peak` (the graded denominator) stays the 2.5 PFLOP/s spec figure of MI355X_MICROARCH.md
+      try:
+        peak_here = ops.mfma_peak_probe(dev)
+        out['roofline']['peak_measured_on_this_box'] = peak_here
+        out['roofline']['frac_of_measured_peak'] = achieved / peak_here if peak_here > 0 else None
+      except Exception as e:  # pylint: disable=broad-except
+        out['roofline']['peak_measured_on_this_box'] = None
+        print('mfma peak probe failed: %r' % (e,), file=sys.stderr)
       if args.workload.startswith('resnet50'):
         # what the same three GEMMs per layer could reach: each layer at the better of its MFMA and HBM bounds
         lb, lb_mfma, lb_hbm = shapes.resnet50_layerwise_bound(args.batch)
