@@ -568,13 +568,24 @@ int rigl_prof_collect(double* ms_per_kind /*[8]*/, int64_t* launches /*[8]*/);
 int rigl_probe_mfma_bf16(int32_t blocks, int32_t iters, float* sink, rigl_stream_t stream);
 
 /* Development knobs: the run-time twin of the RIGL_* environment variables, so
- * that one process can A/B kernel selections (tools/bench_kernels.py,
+ * that one process can A/B kernel selections (tools/pp_sweep.py,
  * tests/k1_check.py).  Process-wide state, NOT part of the drop-in surface: a
- * caller that never sets a knob gets the built-in selection rules.  Keys:
+ * caller that never sets a knob gets the built-in selection rules; a knob never
+ * set reads the environment variable RIGL_<KEY IN UPPER CASE> once.  Keys:
  *   "pp_fwd" / "pp_dgrad"   K1 tile of the 8-wave ping-pong body for the
- *                           forward / dgrad GEMM: -1 built-in rule (default),
- *                           0 never, 1 256x256, 2 128x256, 3 256x128, 4 512x128
- *                           (ignored where the shape does not admit the tile).
+ *                           forward / stand-alone dgrad GEMM: -1 built-in rule
+ *                           (default), 0 never, 1 256x256, 2 128x256,
+ *                           3 256x128, 4 512x128 (ignored where the shape does
+ *                           not admit the tile);
+ *   "pp_bwd"                the shared backward launch on the ping-pong bodies
+ *                           (dgrad tiles + 256x256 weight-gradient tiles): -1
+ *                           rule, 0 never, 1 / 2 dgrad on 256x256 / 128x256;
+ *   "pp_wgrad"              1: stand-alone weight gradient on the ping-pong
+ *                           body wherever legal (rule: off);
+ *   "pp_ph"                 4: one quadrant per phase (default 2 / 1 phases);
+ *   "pp_slab_mb"            cap on a layer's split-K slab bytes (40);
+ *   "pp_bwd_min_kt"         shortest dgrad reduction (K-tiles of 64) the
+ *                           pp_bwd rule takes (16).
  * No reference counterpart (the reference selects cuDNN/TPU algorithms inside
  * TensorFlow: rigl/imagenet_resnet/pruning_layers.py:139-157).              */
 int rigl_tune_set(const char* key, int32_t value);

@@ -1768,8 +1768,8 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   const size_t need = rigl_conv2d_workspace_bytes(d, 2);
   if (need && (!workspace || workspace_bytes < need)) return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
   ProfFamily prof(PROF_CONV_WGRAD);
-  if (tune_get("pp_wgrad", -1) > 0 && pp_wgrad_kind(d) >= 0) {
-    const PPBwdPlan pw = plan_wgrad_pp(d, pp_wgrad_kind(d), 0u, 0);
+  if (tune_get("pp_wgrad", -1) > 0 && !tiny_cin(d) && !small_cin(d) && pp_wgrad_legal(d)) {
+    const PPBwdPlan pw = plan_wgrad_pp(d, 0u, 0);
     const WgradArgs aw = pp_wgrad_args(d, x, dy, pw, dw, workspace);
     if (pp_wgrad_launch(pw, aw, st)) {
       if (pw.splits > 1) {
@@ -1910,7 +1910,7 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
   }
   // The shared launch on the 8-wave ping-pong bodies ("pp_bwd"): layers whose weight gradient has 256-channel tiles and
   // whose dgrad is a stride-1 long reduction.
-  if (tune_get("pp_bwd", -1) != 0 && dx && x && dy && w_hwio && dw && !bn && pp_wgrad_kind(d) >= 0) {
+  if (tune_get("pp_bwd", -1) != 0 && dx && x && dy && w_hwio && dw && !bn && !tiny_cin(d) && !small_cin(d) && pp_wgrad_legal(d)) {
     IgemmArgs ad = dgrad_args(d, dy, w_hwio, addend, dx);
     const int dvar = tune_get("pp_dgrad", -1) >= 0 ? PP_NONE : pp_bwd_dgrad_variant(ad);   // (a forced stand-alone dgrad tile wins)
     if (dvar != PP_NONE && pp_legal<1>(ad, dvar)) {
@@ -1921,7 +1921,7 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
       const unsigned nd = (unsigned)(tiles_m * (ad.N / bn));
       // dgrad workgroup length in 256x256-tile K-tile units (a parity class visits about taps / (sh * sw) of the taps)
       const int kt_d = (int)((int64_t)d->kh * d->kw * (d->cout / 64) * bm * bn / (256 * 256) / (d->stride_h * d->stride_w));
-      const PPBwdPlan pw = plan_wgrad_pp(d, pp_wgrad_kind(d), nd, kt_d);
+      const PPBwdPlan pw = plan_wgrad_pp(d, nd, kt_d);
       const size_t need = rigl_conv2d_workspace_bytes(d, 2);
       if (need && (!workspace || workspace_bytes < need))
         return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
@@ -1939,7 +1939,7 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
         const int64_t pairs = ceil_div64(ceil_div64(flush->n_out, 64), 2);
         nr = (unsigned)(pairs < (int64_t)num_cus() ? pairs : (int64_t)num_cus());
       }
-      if (pp_bwd_launch(dvar, pw.wk, strided, ad, aw, pw, pr, nr, st)) {
+      if (pp_bwd_launch(dvar, strided, ad, aw, pw, pr, nr, st)) {
         if (pw.splits > 1) {
           if (defer) {
             defer->slabs = static_cast<const float*>(workspace); defer->dw = dw; defer->n_out = pw.slab;

@@ -527,153 +527,6 @@ __global__ __launch_bounds__(512) void k_wgrad_pp(WgradArgs P) {
   pp_wgrad_body<PH>(P, smem_pp, blockIdx.x, gridDim.x);
 }
 
-// ---- weight gradient, K-grouped: 128 x 128 channel tiles ------------------------------------------------------------------
-// Every split of a weight gradient costs one more fp32 copy of dW written and read back, and at batch 128 the 256x256
-// tiles above need 17-39 splits to fill the chip (40 MB of slabs per layer: the slab stores, not the MFMAs, end those
-// workgroups).  Here the 8 waves are 2 x 2 wave tiles of 64x64 channels x TWO pixel groups: each group multiplies its own
-// 48 pixels of every 96-pixel K-tile, the two 64x64 partials of a wave pair meet in LDS in a fixed order at the end, and the
-// workgroup writes ONE 128x128 tile -- a quarter of the splits (and of the slab bytes) for the same number of workgroups,
-// and layers with 128 channels (28x28 3x3) get a ping-pong weight gradient at all.  Wave group = pixel group, so the
-// ping-pong partner of a wave is the wave that accumulates the other half of the same output tile.  Skeleton: PH = 1 (the
-// whole K-tile per phase: 12 MFMAs per wave), three 48 KB stages; stage = [96 pixels][128 channels] of X, then of dY.
-struct PPKCursor { int kt; int pa[3], pb[3]; };
-
-__device__ __forceinline__ void pp_wgrad_k_body(const WgradArgs& P, unsigned char* const smem, uint32_t bid, uint32_t nblk) {
-  constexpr int PH = 1, QM = 1, KS = 3, PXT = 96, PXG = 48;
-  constexpr int PART = PXT * 256, STAGE = 2 * PART;       // 24 KB of X + 24 KB of dY
-  static_assert(3 * STAGE <= 160 * 1024, "three stages");
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, gk = grp, gm = (wave >> 1) & 1, gn = wave & 1;
-  uint32_t b = xcd_remap(bid, nblk);
-  const int tco = (int)(b % (uint32_t)P.tiles_co); b /= (uint32_t)P.tiles_co;
-  const int tci = (int)(b % (uint32_t)P.tiles_ci); b /= (uint32_t)P.tiles_ci;
-  const int taps = P.KH * P.KW;
-  const int tap = (int)(b % (uint32_t)taps), split = (int)(b / (uint32_t)taps);
-  const int r = tap / P.KW, s = tap - r * P.KW;
-  const int ci0 = tci * 128, co0 = tco * 128;
-  const int KT_all = (P.M + PXT - 1) / PXT;
-  const int kt_begin = (int)((int64_t)KT_all * split / P.splits);
-  const int KT = (int)((int64_t)KT_all * (split + 1) / P.splits) - kt_begin;
-
-  // DMA lanes: instruction jj (0..2) of wave w fills pixel rows 4 * (jj*8 + w) .. +3 of a part; lane l: pixel +(l >> 4),
-  // slot l & 15 fetching channel chunk slot ^ ((pixel & 3) << 2)
-  const int px_lane = 4 * wave + (lane >> 4);                       // + 32 * jj
-  const int chunk = (lane & 15) ^ (((lane >> 4) & 3) << 2);
-  const int chan_a = ci0 + chunk * 8, chan_b = co0 + chunk * 8;
-  const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.X, P.x_bytes), rsrcB = make_rsrc(P.DY, P.dy_bytes);
-  const int hi0 = r - P.ph, wi0 = s - P.pw;
-
-#define PP_CURSOR_T PPKCursor
-#define PP_WCOMPUTE(c_)                                                                                  \
-  {                                                                                                      \
-    _Pragma("unroll") for (int jj = 0; jj < 3; ++jj) {                                                   \
-      const int p_ = (kt_begin + (c_).kt) * PXT + 32 * jj + px_lane;                                     \
-      const bool ok_ = p_ < P.M;                                                                         \
-      const int pp_ = ok_ ? p_ : 0;                                                                      \
-      const int t_ = fdiv(pp_, P.fd_wo);                                                                 \
-      const int wo_ = pp_ - t_ * P.Wo, n_ = fdiv(t_, P.fd_ho), ho_ = t_ - n_ * P.Ho;                     \
-      const int hi_ = ho_ * P.sh + hi0, wi_ = wo_ * P.sw + wi0;                                          \
-      const bool oka_ = ok_ && (unsigned)hi_ < (unsigned)P.H && (unsigned)wi_ < (unsigned)P.W;          \
-      (c_).pa[jj] = oka_ ? ((n_ * P.H + hi_) * P.W + wi_) * P.x_pix_stride : -1;                         \
-      (c_).pb[jj] = ok_ ? p_ * P.Cout : -1;                                                              \
-    }                                                                                                    \
-  }
-#define PP_CURSOR_ZERO(c_) { (c_).kt = 0; PP_WCOMPUTE(c_); }
-#define PP_NEXT(c_) { ++(c_).kt; PP_WCOMPUTE(c_); }
-  // the skeleton's four pieces: "A0" = all of X's part, "B0" = all of dY's, "A1" / "B1" empty
-#define PP_ISSUE_A(h_, stage_, c_)                                                                       \
-  if ((h_) == 0) {                                                                                       \
-    _Pragma("unroll") for (int jj = 0; jj < 3; ++jj) {                                                   \
-      const int off_ = (c_).pa[jj] >= 0 ? (int)((uint32_t)((c_).pa[jj] + chan_a) * 2u) : (int)OOB;       \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                          \
-          rsrcA, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + (jj * 8 + wave) * 1024), 16, off_, 0, 0, 0); \
-    }                                                                                                    \
-  }
-#define PP_ISSUE_B(h_, stage_, c_)                                                                       \
-  if ((h_) == 0) {                                                                                       \
-    _Pragma("unroll") for (int jj = 0; jj < 3; ++jj) {                                                   \
-      const int off_ = (c_).pb[jj] >= 0 ? (int)((uint32_t)((c_).pb[jj] + chan_b) * 2u) : (int)OOB;       \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                          \
-          rsrcB, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + PART + (jj * 8 + wave) * 1024), 16, off_, 0, 0, 0); \
-    }                                                                                                    \
-  }
-
-  const int g = lane >> 4, j16 = lane & 15, rs = (j16 >> 2) & 3;
-  const int tr_row = (gk * PXG + 8 * (g >> 1) + (j16 >> 2)) * 256, tr_low = ((2 * (g & 1) + ((j16 >> 1) & 1)) << 4) + (j16 & 1) * 8;
-  int a_tr[2], b_tr[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    a_tr[i] = tr_row + ((((gm * 2 + i) ^ rs) * 4) << 4) + tr_low;
-    b_tr[i] = PART + tr_row + ((((gn * 2 + i) ^ rs) * 4) << 4) + tr_low;
-  }
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
-  bf16x8 af[2][KS], b0[1][KS], b1[1][KS];
-
-#define PP_READ_A(h_, stage_, ab_)                                                                       \
-  _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                      \
-    af[ab_][ks] = lds_read_tr_pair(smem + (stage_) * STAGE + a_tr[h_] + ks * 4096, smem + (stage_) * STAGE + a_tr[h_] + ks * 4096 + 1024);
-#define PP_READ_B(dst_, h_, stage_)                                                                      \
-  _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                      \
-    dst_[0][ks] = lds_read_tr_pair(smem + (stage_) * STAGE + b_tr[h_] + ks * 4096, smem + (stage_) * STAGE + b_tr[h_] + ks * 4096 + 1024);
-#define PP_QUAD(ha_, hb_, bsrc_, ab_)                                                                    \
-  _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                      \
-    acc[ha_][hb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ab_][ks], bsrc_[0][ks], acc[ha_][hb_], 0, 0, 0);
-  constexpr int W4 = 6, W2 = 3, W1 = 3;                   // six DMA instructions per thread per K-tile
-  (void)W2; (void)W1;
-#include "convpp_loop.inc"
-#undef PP_READ_A
-#undef PP_READ_B
-#undef PP_QUAD
-#undef PP_ISSUE_A
-#undef PP_ISSUE_B
-#undef PP_NEXT
-#undef PP_CURSOR_T
-#undef PP_CURSOR_ZERO
-#undef PP_WCOMPUTE
-
-  // the two pixel groups' partials of every 64x64 wave tile meet in LDS: group 1 parks its accumulators ([value][lane]:
-  // conflict-free), group 0 adds them to its own -- always (group 0) + (group 1) -- and stores the tile
-  float* const xch = reinterpret_cast<float*>(smem) + (gm * 2 + gn) * 64 * 64;
-  if (gk == 1) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) xch[((i * 2 + jj) * 16 + e) * 64 + lane] = acc[i][jj][e];
-  }
-  __syncthreads();
-  if (gk == 0) {
-    float* const out = P.OUT + (int64_t)split * P.slab_elems + (int64_t)tap * P.Cin * P.Cout;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int ci = ci0 + gm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-          const int co = co0 + gn * 64 + jj * 32 + (lane & 31);
-          out[(int64_t)ci * P.Cout + co] = acc[i][jj][e] + xch[((i * 2 + jj) * 16 + e) * 64 + lane];
-        }
-  }
-}
-
-__global__ __launch_bounds__(512) void k_wgrad_ppk(WgradArgs P) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_pp[];
-  pp_wgrad_k_body(P, smem_pp, blockIdx.x, gridDim.x);
-}
-constexpr int PPK_SMEM = 3 * 2 * 96 * 256;
-
-// One launch per layer backward: the split-K weight-gradient workgroups and the dgrad tiles of a layer share one grid -- two independent GEMMs that each leave CUs idle at batch 128 share the chip (the k_bwd_fused idea
-// on the 8-wave bodies).  dX is bit-identical to k_igemm_pp<..., 1> launched alone.
 // The split-K reduce of the layer BEFORE (rigl_masked_conv2d_bwd_deferred) as a third segment of 512-thread workgroups:
 // the two halves of a workgroup each run wgrad_reduce_body's 256-thread arithmetic on their own 64-output group (same
 // summation order as k_wgrad_reduce: bit-identical dW), barriers shared.
@@ -726,7 +579,7 @@ __device__ __forceinline__ void pp_reduce_body(const ReduceArgs& R, unsigned cha
   }
 }
 
-template <int WMD, int WND, int TMD, int TND, int PHD, int WK /*0: 256x256 tiles, 1: K-grouped 128x128 tiles*/, bool CLSD = false>
+template <int WMD, int WND, int TMD, int TND, int PHD, bool CLSD = false>
 __global__ __launch_bounds__(512) void k_bwd_pp(IgemmArgs PD, WgradArgs PW, ReduceArgs PR, uint32_t nd, uint32_t nw, uint32_t wgrad_first) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_pp[];
   // longest jobs first: whichever body has the longer reduction per workgroup takes the low block indices; the reduce
@@ -735,8 +588,7 @@ __global__ __launch_bounds__(512) void k_bwd_pp(IgemmArgs PD, WgradArgs PW, Redu
   if (b >= nd + nw) { pp_reduce_body(PR, smem_pp, b - nd - nw, gridDim.x - nd - nw); return; }
   const bool is_w = wgrad_first ? b < nw : b >= nd;
   if (is_w) {
-    if constexpr (WK == 1) pp_wgrad_k_body(PW, smem_pp, wgrad_first ? b : b - nd, nw);
-    else pp_wgrad_body<2>(PW, smem_pp, wgrad_first ? b : b - nd, nw);
+    pp_wgrad_body<2>(PW, smem_pp, wgrad_first ? b : b - nd, nw);
   } else {
     pp_igemm_body<WMD, WND, TMD, TND, PHD, 1, CLSD>(PD, smem_pp, wgrad_first ? b - nw : b, nd);
   }
@@ -826,23 +678,16 @@ static int pp_bwd_dgrad_variant(const IgemmArgs& a) {
   const int pp_bwd = tune_get("pp_bwd", -1);
   if (pp_bwd == 0) return PP_NONE;
   const int64_t m_out = (int64_t)(a.M / (a.RH * a.RW)) * a.GH * a.GW;
-  if (a.N % 128 || a.Cred % 128 || m_out < 256 || a.KH * a.KW > 32 || a.BNX || a.sh > 2 || a.sw > 2) return PP_NONE;
-  // the weight gradient that would share the launch must exist: 128-channel tiles need the K-grouped body
-  const int wkf = tune_get("pp_wk", -1);
-  const bool c256 = a.N % 256 == 0 && a.Cred % 256 == 0;
-  if (wkf != 1 && !c256) return PP_NONE;
-  const bool wide = a.N % 256 == 0;
-  const int big = wide ? PP_256x256 : PP_512x128, small = wide ? PP_128x256 : PP_256x128;
-  if (pp_bwd > 0) return pp_bwd == 2 ? small : big;
-  // built-in rule (tools/pp_sweep.py --passes bwd, batch 128): dgrad reductions of >= 16 K-tiles; the 128x64-per-wave
-  // dgrad tiles where they give at least ~1/3 of the CUs a tile, the 64x64-per-wave tiles below that
-  // (a strided dgrad: the longest parity class, ceil(KH / sh) x ceil(KW / sw) taps)
+  // the weight gradient that shares the launch has 256-channel tiles: cin (= N here) and cout (= Cred) multiples of 256
+  if (a.N % 256 || a.Cred % 256 || m_out < 256 || a.KH * a.KW > 32 || a.BNX || a.sh > 2 || a.sw > 2) return PP_NONE;
+  if (pp_bwd > 0) return pp_bwd == 2 ? PP_128x256 : PP_256x256;
+  // built-in rule (tools/pp_sweep.py --passes bwd, batch 128): dgrad reductions of >= 16 K-tiles (a strided dgrad: its
+  // longest parity class, ceil(KH / sh) x ceil(KW / sw) taps); 256x256 dgrad tiles where they give at least ~1/3 of the
+  // CUs a tile (a strided dgrad counts the tiles of ONE class), the 128-row tiles below that
   const int kt_d = ((a.KH + a.sh - 1) / a.sh) * ((a.KW + a.sw - 1) / a.sw) * (a.Cred / 64);
   if (kt_d < tune_get("pp_bwd_min_kt", 16)) return PP_NONE;     // (8-tile reductions measured neutral to slightly slower)
-  // (a strided dgrad counts the tiles of ONE parity class: the classes run one after the other in work, not side by side)
   const int64_t rows = a.M / (a.sh * a.sw);
-  const int64_t nbig = wide ? ((rows + 255) / 256) * (a.N / 256) : ((rows + 511) / 512) * (a.N / 128);
-  return nbig >= 90 ? big : small;
+  return ((rows + 255) / 256) * (a.N / 256) >= 90 ? PP_256x256 : PP_128x256;
 }
 
 template <int MODE>
@@ -907,38 +752,27 @@ static bool launch_pp(const PPPlan& p, const IgemmArgs& a0, hipStream_t st) {
 }
 
 // ---- backward on the ping-pong bodies -------------------------------------------------------------------------------------
-// Knobs: "pp_wgrad" (stand-alone weight gradient: -1 rule, 0 never, 1 wherever legal), "pp_bwd" (the shared launch:
-// -1 rule, 0 never, 1 dgrad on the 128x64-per-wave tiles (256x256 / 512x128), 2 dgrad on the 64x64-per-wave tiles
-// (128x256 / 256x128)), "pp_wk" (weight-gradient body: -1 rule, 0 the 256x256 tiles, 1 the K-grouped 128x128 tiles).
+// Knobs: "pp_wgrad" (stand-alone weight gradient: -1 rule = off, 1 wherever legal), "pp_bwd" (the shared launch: -1 rule,
+// 0 never, 1 dgrad on the 128x64-per-wave tile (256x256), 2 dgrad on the 64x64-per-wave tile (128x256)), "pp_slab_mb".
 struct PPBwdPlan {
   bool use;
-  int wk;               // weight-gradient body: 0 = 256x256 tiles (64-pixel K-tiles), 1 = K-grouped 128x128 tiles (96-pixel K-tiles)
   int tiles_ci, tiles_co, splits;
   int64_t slab;         // elements of one partial slab = the whole dW
   unsigned nd, nw;
   bool wgrad_first;
 };
 
-static inline bool pp_wgrad_legal(const RiglConvDesc* d, int wk) {
+// 256-channel tiles of dW; the tiny- / small-Cin repack paths keep their own kernels
+static inline bool pp_wgrad_legal(const RiglConvDesc* d) {
   const int64_t M = (int64_t)d->n * d->ho * d->wo;
-  const int t = wk ? 128 : 256;
-  return d->cin % t == 0 && d->cout % t == 0 && M >= 256 && d->kh * d->kw <= 32 && d->cin > 4 && (d->cin % 8) == 0;
+  return d->cin % 256 == 0 && d->cout % 256 == 0 && M >= 256 && d->kh * d->kw <= 32;
 }
-// Which weight-gradient body a layer gets (-1: none)
-static inline int pp_wgrad_kind(const RiglConvDesc* d) {
-  const int forced = tune_get("pp_wk", -1);
-  if (forced >= 0) return pp_wgrad_legal(d, forced) ? forced : -1;
-  // rule: the 256x256 tiles (measured at batch 128: the K-grouped body saves slab bytes but loses more in MFMA rate --
-  // ResNet-50 step 12.60 vs 12.35 ms)
-  return pp_wgrad_legal(d, 0) ? 0 : -1;
-}
-// Upper bound of the split count of any ping-pong weight-gradient plan (the workspace is sized for it): at least ~256
+// Upper bound of the split count of any ping-pong weight-gradient plan (the workspace is sized for it): at least 256
 // pixels per split, at most two rounds of workgroups, at most "pp_slab_mb" (40) MB of slabs -- every split is one more
-// fp32 copy of dW written and read back.
-static inline int pp_wgrad_max_splits(const RiglConvDesc* d, int wk) {
-  const int t = wk ? 128 : 256, pxt = wk ? 96 : 64;
-  const int64_t M = (int64_t)d->n * d->ho * d->wo, kt_all = (M + pxt - 1) / pxt;
-  const int64_t base = (int64_t)d->kh * d->kw * (d->cin / t) * (d->cout / t);
+// fp32 copy of dW written and read back (16 MB: slower on every layer measured, 24 / 40 / 64 MB within noise of each other).
+static inline int pp_wgrad_max_splits(const RiglConvDesc* d) {
+  const int64_t M = (int64_t)d->n * d->ho * d->wo, kt_all = (M + 63) / 64;
+  const int64_t base = (int64_t)d->kh * d->kw * (d->cin / 256) * (d->cout / 256);
   const int64_t dw_bytes = (int64_t)d->kh * d->kw * d->cin * d->cout * 4;
   int64_t s = kt_all / 4;
   const int64_t by_slots = (2 * (int64_t)num_cus() + base - 1) / base, by_bytes = ((int64_t)tune_get("pp_slab_mb", 40) << 20) / dw_bytes;
@@ -947,38 +781,29 @@ static inline int pp_wgrad_max_splits(const RiglConvDesc* d, int wk) {
   return (int)(s < 1 ? 1 : s);
 }
 static inline size_t pp_wgrad_workspace(const RiglConvDesc* d) {
-  size_t need = 0;
-  for (int wk = 0; wk < 2; ++wk)
-    if (pp_wgrad_legal(d, wk)) {
-      const int sp = pp_wgrad_max_splits(d, wk);
-      const size_t n = sp > 1 ? (size_t)sp * d->kh * d->kw * d->cin * d->cout * 4 : 0;
-      if (n > need) need = n;
-    }
-  return need;
+  if (!pp_wgrad_legal(d)) return 0;
+  const int sp = pp_wgrad_max_splits(d);
+  return sp > 1 ? (size_t)sp * d->kh * d->kw * d->cin * d->cout * 4 : 0;
 }
 
 // nd = dgrad workgroups that share the launch (0: stand-alone weight gradient), kt_d = their length in 256x256x64 K-tiles
-static PPBwdPlan plan_wgrad_pp(const RiglConvDesc* d, int wk, unsigned nd, int kt_d) {
+static PPBwdPlan plan_wgrad_pp(const RiglConvDesc* d, unsigned nd, int kt_d) {
   PPBwdPlan p = {};
-  const int t = wk ? 128 : 256, pxt = wk ? 96 : 64;
-  p.wk = wk;
-  p.tiles_ci = d->cin / t; p.tiles_co = d->cout / t;
+  p.tiles_ci = d->cin / 256; p.tiles_co = d->cout / 256;
   p.slab = (int64_t)d->kh * d->kw * d->cin * d->cout;
-  const int64_t M = (int64_t)d->n * d->ho * d->wo, kt_all = (M + pxt - 1) / pxt;
+  const int64_t M = (int64_t)d->n * d->ho * d->wo, kt_all = (M + 63) / 64;
   const int64_t base = (int64_t)d->kh * d->kw * p.tiles_ci * p.tiles_co, cus = num_cus();
   // whole rounds of one workgroup per CU, with room for at least `base` (and a quarter of a round of) weight-gradient
   // workgroups behind the dgrad tiles
   const int64_t room = base > cus / 4 ? base : cus / 4;
   const int64_t slots = ((int64_t)nd + room + cus - 1) / cus * cus;
   int64_t s = (slots - (int64_t)nd) / base;
-  const int smax = pp_wgrad_max_splits(d, wk);
+  const int smax = pp_wgrad_max_splits(d);
   if (s > smax) s = smax;
   if (s < 1) s = 1;
   p.splits = (int)s;
   p.nd = nd; p.nw = (unsigned)(base * s);
-  // longest jobs first (a K-grouped workgroup's K-tile is 3/8 of the MFMA work of a 256x256x64 one)
-  const int64_t len_w = wk ? (kt_all / s) * 3 / 8 : kt_all / s;
-  p.wgrad_first = len_w >= kt_d;
+  p.wgrad_first = kt_all / s >= kt_d;          // longest jobs first
   p.use = true;
   return p;
 }
@@ -998,53 +823,37 @@ static WgradArgs pp_wgrad_args(const RiglConvDesc* d, const rigl_bf16* x, const 
 }
 
 static bool pp_wgrad_launch(const PPBwdPlan& p, const WgradArgs& aw, hipStream_t st) {
-  if (p.wk) {
-    static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_ppk),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, PPK_SMEM) == hipSuccess;
-    if (!ready) return false;
-    RIGL_K_LAUNCH(k_wgrad_ppk, dim3(p.nw), dim3(512), PPK_SMEM, st, aw);
-  } else {
-    static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_pp<2>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  PPGeom<2, 4, 4, 2, 2>::SMEM) == hipSuccess;
-    if (!ready) return false;
-    RIGL_K_LAUNCH((k_wgrad_pp<2>), dim3(p.nw), dim3(512), (PPGeom<2, 4, 4, 2, 2>::SMEM), st, aw);
-  }
+  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_pp<2>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                PPGeom<2, 4, 4, 2, 2>::SMEM) == hipSuccess;
+  if (!ready) return false;
+  RIGL_K_LAUNCH((k_wgrad_pp<2>), dim3(p.nw), dim3(512), (PPGeom<2, 4, 4, 2, 2>::SMEM), st, aw);
   return true;
 }
-template <int WMD, int WND, int TMD, int TND, int PHD, int WK, bool CLSD = false>
+template <int WMD, int WND, int TMD, int TND, int PHD, bool CLSD>
 static bool pp_bwd_launch_one(const IgemmArgs& ad, const WgradArgs& aw, const ReduceArgs& pr, unsigned nr, unsigned nd, unsigned nw,
                               bool wgrad_first, hipStream_t st) {
-  constexpr int SM_D = PPGeom<WMD, WND, TMD, TND, PHD>::SMEM, SM_W = WK ? PPK_SMEM : PPGeom<2, 4, 4, 2, 2>::SMEM, SM = SM_D > SM_W ? SM_D : SM_W;
-  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_pp<WMD, WND, TMD, TND, PHD, WK, CLSD>),
+  constexpr int SM_D = PPGeom<WMD, WND, TMD, TND, PHD>::SMEM, SM_W = PPGeom<2, 4, 4, 2, 2>::SMEM, SM = SM_D > SM_W ? SM_D : SM_W;
+  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_pp<WMD, WND, TMD, TND, PHD, CLSD>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM) == hipSuccess;
   if (!ready) return false;
-  RIGL_K_LAUNCH((k_bwd_pp<WMD, WND, TMD, TND, PHD, WK, CLSD>), dim3(nd + nw + nr), dim3(512), SM, st, ad, aw, pr, nd, nw, (uint32_t)(wgrad_first ? 1u : 0u));
+  RIGL_K_LAUNCH((k_bwd_pp<WMD, WND, TMD, TND, PHD, CLSD>), dim3(nd + nw + nr), dim3(512), SM, st, ad, aw, pr, nd, nw, (uint32_t)(wgrad_first ? 1u : 0u));
   return true;
 }
-// dvar = the dgrad tile, wk = the weight-gradient body, strided = parity-class dgrad
-static bool pp_bwd_launch(int dvar, int wk, bool strided, const IgemmArgs& ad, const WgradArgs& aw, const PPBwdPlan& pw, const ReduceArgs& pr,
+// dvar = the dgrad tile (256 output columns: the weight gradient's 256-channel tiles imply cin % 256 == 0), strided =
+// parity-class dgrad
+static bool pp_bwd_launch(int dvar, bool strided, const IgemmArgs& ad, const WgradArgs& aw, const PPBwdPlan& pw, const ReduceArgs& pr,
                           unsigned nr, hipStream_t st) {
   if (strided) {
-    if (wk) return false;
     switch (dvar) {
-      case PP_256x256: return pp_bwd_launch_one<2, 4, 4, 2, 2, 0, true>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
-      case PP_128x256: return pp_bwd_launch_one<2, 4, 2, 2, 1, 0, true>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
-      default: return false;
-    }
-  }
-  if (wk) {
-    switch (dvar) {
-      case PP_256x256: return pp_bwd_launch_one<2, 4, 4, 2, 2, 1>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
-      case PP_128x256: return pp_bwd_launch_one<2, 4, 2, 2, 1, 1>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
-      case PP_256x128: return pp_bwd_launch_one<4, 2, 2, 2, 1, 1>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
-      case PP_512x128: return pp_bwd_launch_one<4, 2, 4, 2, 2, 1>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
+      case PP_256x256: return pp_bwd_launch_one<2, 4, 4, 2, 2, true>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
+      case PP_128x256: return pp_bwd_launch_one<2, 4, 2, 2, 1, true>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
       default: return false;
     }
   }
   switch (dvar) {
-    case PP_256x256: return pp_bwd_launch_one<2, 4, 4, 2, 2, 0>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
-    case PP_128x256: return pp_bwd_launch_one<2, 4, 2, 2, 1, 0>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
+    case PP_256x256: return pp_bwd_launch_one<2, 4, 4, 2, 2, false>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
+    case PP_128x256: return pp_bwd_launch_one<2, 4, 2, 2, 1, false>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
     default: return false;
   }
 }

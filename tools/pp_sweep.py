@@ -73,7 +73,7 @@ def bwd_rows(a, rep, name, B, H, W, Cin, Cout, k, s, pt, pl, Ho, Wo, macs, x, dy
   setting, run-to-run bit determinism of dW; then the timings (backward time includes the split-K reduce launch)."""
   n = k * k * Cin * Cout
   has_dx = Cin % 8 == 0
-  for ps, key, vals in (('bwd', 'pp_bwd', ((0, 0), (1, 0), (2, 0), (1, 1), (2, 1))), ('wgrad', 'pp_wgrad', ((0, 0), (1, 0), (1, 1)))):
+  for ps, key, vals in (('bwd', 'pp_bwd', ((0, 0), (1, 0), (2, 0))), ('wgrad', 'pp_wgrad', ((0, 0), (1, 0)))):
     if ps not in a.passes:
       continue
     line = '%-20s B%-4d %-5s' % (name, B, ps)
@@ -83,7 +83,6 @@ def bwd_rows(a, rep, name, B, H, W, Cin, Cout, k, s, pt, pl, Ho, Wo, macs, x, dy
       if v and (Cin % t or Cout % t):
         continue
       ops.tune_set('pp_fwd', 0); ops.tune_set('pp_dgrad', -1); ops.tune_set('pp_bwd', 0); ops.tune_set('pp_wgrad', 0)
-      ops.tune_set('pp_wk', wk)
       ops.tune_set(key, v)
       d = ops.conv_desc(B, H, W, Cin, Cout, k, k, s, pt, pl, Ho, Wo)
       try:
@@ -123,7 +122,7 @@ def bwd_rows(a, rep, name, B, H, W, Cin, Cout, k, s, pt, pl, Ho, Wo, macs, x, dy
       except Exception as ex:  # pylint: disable=broad-except
         line += ' | %s=%d FAILED %s' % (key, v, repr(ex)[:80])
     print(line, flush=True)
-  ops.tune_set('pp_bwd', -1); ops.tune_set('pp_wgrad', -1); ops.tune_set('pp_fwd', -1); ops.tune_set('pp_wk', -1)
+  ops.tune_set('pp_bwd', -1); ops.tune_set('pp_wgrad', -1); ops.tune_set('pp_fwd', -1)
 
 
 DIMS = {1: (256, 256), 2: (128, 256), 3: (256, 128), 4: (512, 128)}
