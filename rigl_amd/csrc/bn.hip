@@ -155,7 +155,21 @@ __device__ __forceinline__ void sum_partials(const Geom& G, const float* __restr
   __syncthreads();
   leader = pl == 0 && c < G.C;
   s0 = s1 = 0.0;
-  if (leader) {
+  if constexpr (CL == 1) {
+    // 256 part-lanes of one channel: 16 threads sum 16 lanes each, the leader sums those (a fixed two-level order)
+    __shared__ double acc2[2][16];
+    if (threadIdx.x < 16) {
+      double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { t0 += acc[0][threadIdx.x * 16 + k][0]; t1 += acc[1][threadIdx.x * 16 + k][0]; }
+      acc2[0][threadIdx.x] = t0; acc2[1][threadIdx.x] = t1;
+    }
+    __syncthreads();
+    if (leader) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { s0 += acc2[0][k]; s1 += acc2[1][k]; }
+    }
+  } else if (leader) {
 #pragma unroll 8
     for (int k = 0; k < PL; ++k) { s0 += acc[0][k][cl]; s1 += acc[1][k][cl]; }
   }
@@ -516,7 +530,13 @@ static int fwd_statistics(Geom& g, int32_t c, const rigl_bf16* x, const float* g
   } else {
     g.parts = stats_parts;               // the producer's partial sums [stats_parts][2][C] replace the reduction pass
   }
-  if (g.parts > 256)
+  // parts > 1024 (the 56x56 layers: 3136 conv-epilogue partials per channel, 64-256 channels): one workgroup per channel --
+  // with 4 channels per workgroup a 64-channel layer is 16 workgroups each walking 49 rows per lane in dependent batches
+  // (11.8 us on average over the step's 25 such finalizes; round 3)
+  if (g.parts > 1024)
+    hipLaunchKernelGGL(k_fwd_finalize<1>, dim3((unsigned)c), dim3(THREADS), 0, st, g, partial, gamma,
+                       beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale, save_shift);
+  else if (g.parts > 256)
     hipLaunchKernelGGL(k_fwd_finalize<4>, dim3((unsigned)((c + 3) / 4)), dim3(THREADS), 0, st, g, partial, gamma,
                        beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale, save_shift);
   else
