@@ -533,7 +533,7 @@ static int fwd_statistics(Geom& g, int32_t c, const rigl_bf16* x, const float* g
   // parts > 1024 (the 56x56 layers: 3136 conv-epilogue partials per channel, 64-256 channels): one workgroup per channel --
   // with 4 channels per workgroup a 64-channel layer is 16 workgroups each walking 49 rows per lane in dependent batches
   // (11.8 us on average over the step's 25 such finalizes; round 3)
-  if (g.parts > 1024)
+  if (g.parts > 1024 && tune_get("bn_fin1", 1) != 0)
     hipLaunchKernelGGL(k_fwd_finalize<1>, dim3((unsigned)c), dim3(THREADS), 0, st, g, partial, gamma,
                        beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale, save_shift);
   else if (g.parts > 256)
