@@ -1,0 +1,248 @@
+// K1, single-pass backward of the big-M 1x1 convs (included inside namespace rigl::k1 of conv.hip).
+//
+// The 56x56 1x1 layers of ResNet-50 (64 <-> 256 channels, 401 408 pixels at batch 128) are HBM-bound, and their backward
+// reads the output gradient TWICE: once for dX = dY W^T, once for dW = X^T dY -- 205 MB each time for the 64->256 layers,
+// and the shared launch of the igemm / tr bodies takes exactly the sum of the two streams (84 us ~ 39 + 48).  Here a
+// workgroup walks a range of pixels once: every 32-pixel K-tile of dY and X is brought into LDS by LDS-DMA, multiplied
+// by the register-resident W for dX (v_mfma_f32_16x16x32_bf16, D = W-fragment x dY-fragment so a lane holds 4 consecutive
+// input channels of one pixel) and by X^T for the workgroup's private dW accumulators (v_mfma_f32_32x32x16_bf16 on
+// ds_read_b64_tr_b16 fragments), dX goes out tile by tile (+ the shortcut gradient), the dW partial once at the end into
+// the workgroup's split-K slab (rigl::k1::launch_wgrad_reduce sums the slabs in a fixed order).  dY is read once.
+// The dY tile serves both a row-major ds_read_b128 (k = output channel) and a transposing read (k = pixel): its 16-byte
+// chunks are XORed with a row function found by exhaustive search over XOR-linear maps (tools/probes/swizzle_search.py)
+// that is conflict-free for BOTH access patterns -- 512-byte rows: ((r & 1) << 1) | ((r >> 1 & 1) << 2) | ((r ^ r >> 2) & 1) << 3,
+// 128-byte rows: ((r >> 1) & 1) << 1 | ((r >> 1 ^ r >> 2) & 1) << 2 -- applied on the DMA's source side.
+// Memory-bound by ~3x (512 MFMA cycles per wave per 20 KB K-tile), so the loop is the plain ring: counted vmcnt, one
+// barrier per K-tile, two 256-thread workgroups per CU.
+// Reference: the autodiff of layers.masked_conv2d (pruning_layers.py:139-157; sparse_optimizers_base.py:478-485).
+#pragma once
+
+struct Bwd1x1Args {
+  const uint16_t* X;    // [M][CI] bf16
+  const uint16_t* DY;   // [M][CO] bf16
+  const uint16_t* W;    // [CI][CO] bf16 (the HWIO shadow of a 1x1 kernel)
+  const uint16_t* ADD;  // [M][CI] bf16 or NULL: added to dX (bf16(bf16(dgrad) + addend), like the dgrad epilogue)
+  uint16_t* DX;         // [M][CI] bf16
+  float* SLAB;          // [splits][CI][CO] fp32 partial dW (NULL with DO_W = false)
+  int M, splits;
+  uint32_t x_bytes, dy_bytes;
+};
+
+template <int ROWB>
+__device__ __forceinline__ int dual_swz(int row) {
+  if (ROWB == 512) return ((row & 1) << 1) | (((row >> 1) & 1) << 2) | (((row ^ (row >> 2)) & 1) << 3);
+  return (((row >> 1) & 1) << 1) | ((((row >> 1) ^ (row >> 2)) & 1) << 2);
+}
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <int CI, int CO, bool DO_W>
+__global__ __launch_bounds__(THREADS) void k_bwd1x1(Bwd1x1Args P) {
+  constexpr int PX = 32, NST = 3;
+  constexpr int YROWB = CO * 2, XROWB = CI * 2;
+  constexpr int Y_BYTES = PX * YROWB, X_BYTES = DO_W ? PX * XROWB : 0, STAGE = Y_BYTES + X_BYTES;
+  constexpr int YI = YROWB / 32, XI = XROWB / 32;             // DMA wave-instructions per tile (1 KB each)
+  constexpr int YPW = YI / 4 > 0 ? YI / 4 : 1, XPW = XI / 4 > 0 ? XI / 4 : 1;   // per wave
+  static_assert(YI % 4 == 0 && XI % 4 == 0, "tiles are whole rounds of four waves");
+  constexpr int L = YPW + (DO_W ? XPW : 0);                  // DMA instructions per thread per K-tile
+  constexpr int CF = CI / 16, CFW = CF / 2;                  // dgrad: 16-channel fragments, per wave (2 pixel fragments x 2 wave columns)
+  constexpr int KSD = CO / 32;                               // dgrad k-steps (output channels, 32 per MFMA)
+  constexpr int NFI = CI / 32, NFO = CO / 32;                // wgrad: 32x32 fragments of dW
+  // wgrad fragments per wave: the longer side is split over wave pairs
+  constexpr bool WIDE_O = NFO >= NFI;
+  constexpr int WF = NFI * NFO / 4 > 0 ? NFI * NFO / 4 : 1;  // fragments per wave
+  static_assert(CFW * KSD * 4 <= 96, "W fragments stay in registers");
+  static_assert(NST * STAGE <= 65536, "static LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x;
+  const int KT_all = (P.M + PX - 1) / PX;
+  const int kt_begin = (int)((int64_t)KT_all * split / P.splits);
+  const int KT = (int)((int64_t)KT_all * (split + 1) / P.splits) - kt_begin;
+  const __amdgpu_buffer_rsrc_t rsrcY = make_rsrc(P.DY, P.dy_bytes), rsrcX = make_rsrc(P.X, P.x_bytes);
+
+  // ---- DMA lanes ------------------------------------------------------------------------------------------------------
+  // wave-instruction i of a tile with ROWB-byte rows fills rows i * (1024 / ROWB) ..; lane l: row + l / (ROWB / 16),
+  // 16-byte slot l % (ROWB / 16), fetching the logical chunk slot ^ swizzle(row)
+  int y_row[YPW], y_col[YPW], x_row[XPW], x_col[XPW];
+#pragma unroll
+  for (int q = 0; q < YPW; ++q) {
+    const int i = q * 4 + wave, row = i * (1024 / YROWB) + lane / (YROWB / 16), slot = lane % (YROWB / 16);
+    y_row[q] = row; y_col[q] = (slot ^ dual_swz<YROWB>(row)) * 8;
+  }
+#pragma unroll
+  for (int q = 0; q < XPW; ++q) {
+    const int i = q * 4 + wave, row = i * (1024 / XROWB) + lane / (XROWB / 16), slot = lane % (XROWB / 16);
+    x_row[q] = row; x_col[q] = (slot ^ dual_swz<XROWB>(row)) * 8;
+  }
+#define B1_ISSUE(kt_, stage_)                                                                            \
+  {                                                                                                      \
+    const int p0_ = (kt_begin + (kt_)) * PX;                                                             \
+    _Pragma("unroll") for (int q = 0; q < YPW; ++q) {                                                    \
+      const int p_ = p0_ + y_row[q];                                                                     \
+      const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * CO + y_col[q]) * 2u) : (int)OOB;                 \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                          \
+          rsrcY, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + (q * 4 + wave) * 1024), 16, off_, 0, 0, 0); \
+    }                                                                                                    \
+    if (DO_W) {                                                                                          \
+      _Pragma("unroll") for (int q = 0; q < XPW; ++q) {                                                  \
+        const int p_ = p0_ + x_row[q];                                                                   \
+        const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * CI + x_col[q]) * 2u) : (int)OOB;               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
+            rsrcX, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + Y_BYTES + (q * 4 + wave) * 1024), 16, off_, 0, 0, 0); \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+
+  // ---- dgrad: W fragments in registers ------------------------------------------------------------------------------------
+  // wave (pf = wave & 1, half = wave >> 1): pixel fragment pf (16 pixels), channel fragments half * CFW .. + CFW
+  const int pf = wave & 1, chalf = wave >> 1;
+  bf16x8 wfr[CFW][KSD];
+#pragma unroll
+  for (int c = 0; c < CFW; ++c)
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) {
+      const int ci = (chalf * CFW + c) * 16 + (lane & 15), co = ks * 32 + (lane >> 4) * 8;
+      wfr[c][ks] = *reinterpret_cast<const bf16x8*>(P.W + (int64_t)ci * CO + co);
+    }
+  // dY fragment of k-step ks: lane l = row 16 * pf + (l & 15), logical chunk 4 * ks + (l >> 4)
+  const int d_row = 16 * pf + (lane & 15);
+  const int d_base = d_row * YROWB, d_swz = dual_swz<YROWB>(d_row), d_hi = lane >> 4;
+
+  // ---- wgrad: transposing fragment reads -------------------------------------------------------------------------------------
+  const int g = lane >> 4, j16 = lane & 15;
+  const int t_row = 8 * (g >> 1) + (j16 >> 2);                      // + 16 * ks2 (+ 4 for the second half of the 8 pixels)
+  const int t_low = 2 * (g & 1) + ((j16 >> 1) & 1), t_half = (j16 & 1) * 8;
+  // fragment assignment: the wave's WF fragments of the NFI x NFO grid
+  //   WIDE_O: input fragment wave % NFI... (CI = 64: fi = wave & 1), output fragments (wave / NFI) * WF ..
+  //   else  : output fragment wave % NFO, input fragments (wave / NFO) * WF ..
+  f32x16 acc2[DO_W ? WF : 1];
+  if (DO_W) {
+#pragma unroll
+    for (int f = 0; f < WF; ++f)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc2[f][e] = 0.f;
+  }
+  const int w_fix = WIDE_O ? wave % NFI : wave % NFO;               // the fragment index on the short side
+  const int w_var0 = WIDE_O ? (wave / NFI) * WF : (wave / NFO) * WF;   // first fragment index on the long side
+  // byte offsets (inside a tile) of the two 4-pixel halves of a fragment's rows, for k-step 0
+#define B1_TR_OFF(ROWB_, chunk_, plus4_) \
+  ((t_row + (plus4_)) * (ROWB_) + ((((chunk_) + t_low) ^ dual_swz<ROWB_>(t_row + (plus4_))) << 4) + t_half)
+
+  constexpr int W_OUT = L * (NST - 2);
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < KT) B1_ISSUE(t, t);
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + NST - 1 <= KT) wait_vmcnt<W_OUT>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NST - 1 < KT) B1_ISSUE(kt + NST - 1, (kt + NST - 1) % NST);
+    const unsigned char* Ys = smem + (kt % NST) * STAGE;
+    const unsigned char* Xs = Ys + Y_BYTES;
+    // the shortcut gradient of this tile's pixels: requested now, used after the MFMAs
+    const int px = (kt_begin + kt) * PX + 16 * pf + (lane & 15);
+    uint2 addv[CFW];
+    if (P.ADD) {
+#pragma unroll
+      for (int c = 0; c < CFW; ++c)
+        addv[c] = px < P.M ? *reinterpret_cast<const uint2*>(P.ADD + (int64_t)px * CI + (chalf * CFW + c) * 16 + (lane >> 4) * 4)
+                           : make_uint2(0u, 0u);
+    }
+    // ---- dX tile: D[ci][px] = W-fragment x dY-fragment --------------------------------------------------------------------
+    f32x4 acc1[CFW];
+#pragma unroll
+    for (int c = 0; c < CFW; ++c) acc1[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) {
+      const bf16x8 yf = *reinterpret_cast<const bf16x8*>(Ys + d_base + (((4 * ks + d_hi) ^ d_swz) << 4));
+#pragma unroll
+      for (int c = 0; c < CFW; ++c) acc1[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[c][ks], yf, acc1[c], 0, 0, 0);
+    }
+    // ---- dW partial: D2[ci][co] += X^T-fragment x dY^T-fragment, two k-steps of 16 pixels --------------------------------------
+    if (DO_W) {
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        bf16x8 fa[WIDE_O ? 1 : WF], fb[WIDE_O ? WF : 1];
+        if (WIDE_O) {
+          fa[0] = lds_read_tr_pair(Xs + k2 * 16 * XROWB + B1_TR_OFF(XROWB, w_fix * 4, 0), Xs + k2 * 16 * XROWB + B1_TR_OFF(XROWB, w_fix * 4, 4));
+#pragma unroll
+          for (int f = 0; f < WF; ++f)
+            fb[f] = lds_read_tr_pair(Ys + k2 * 16 * YROWB + B1_TR_OFF(YROWB, (w_var0 + f) * 4, 0),
+                                     Ys + k2 * 16 * YROWB + B1_TR_OFF(YROWB, (w_var0 + f) * 4, 4));
+#pragma unroll
+          for (int f = 0; f < WF; ++f) acc2[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[f], acc2[f], 0, 0, 0);
+        } else {
+          fb[0] = lds_read_tr_pair(Ys + k2 * 16 * YROWB + B1_TR_OFF(YROWB, w_fix * 4, 0), Ys + k2 * 16 * YROWB + B1_TR_OFF(YROWB, w_fix * 4, 4));
+#pragma unroll
+          for (int f = 0; f < WF; ++f)
+            fa[f] = lds_read_tr_pair(Xs + k2 * 16 * XROWB + B1_TR_OFF(XROWB, (w_var0 + f) * 4, 0),
+                                     Xs + k2 * 16 * XROWB + B1_TR_OFF(XROWB, (w_var0 + f) * 4, 4));
+#pragma unroll
+          for (int f = 0; f < WF; ++f) acc2[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f], fb[0], acc2[f], 0, 0, 0);
+        }
+      }
+    }
+    // ---- store the dX tile: lane (l & 15) = pixel, 4 consecutive channels (l >> 4) * 4 .. of each fragment ---------------------
+    if (px < P.M) {
+#pragma unroll
+      for (int c = 0; c < CFW; ++c) {
+        const f32x2 lo = {acc1[c][0], acc1[c][1]}, hi2 = {acc1[c][2], acc1[c][3]};
+        uint2 pk;
+        pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));
+        pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi2, bf16x2));
+        if (P.ADD) { pk.x = add_bf16x2(pk.x, addv[c].x); pk.y = add_bf16x2(pk.y, addv[c].y); }
+        *reinterpret_cast<uint2*>(P.DX + (int64_t)px * CI + (chalf * CFW + c) * 16 + (lane >> 4) * 4) = pk;
+      }
+    }
+  }
+#undef B1_ISSUE
+#undef B1_TR_OFF
+  // ---- the workgroup's dW partial -> its slab: D2 row (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) = ci, column lane & 31 = co ------
+  if (DO_W) {
+    float* const out = P.SLAB + (int64_t)split * CI * CO;
+#pragma unroll
+    for (int f = 0; f < WF; ++f) {
+      const int fi = WIDE_O ? w_fix : w_var0 + f, fo = WIDE_O ? w_var0 + f : w_fix;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = fi * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), co = fo * 32 + (lane & 31);
+        out[(int64_t)ci * CO + co] = acc2[f][e];
+      }
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+// Legal: 1x1, stride 1, no padding, (cin, cout) one of the instantiated pairs, a long pixel axis.  "bwd1x1" = 0 turns the
+// kernel off (a layer's dX then comes from the igemm body again, in both entry points).
+static inline int bwd1x1_kind(const RiglConvDesc* d) {
+  if (d->kh != 1 || d->kw != 1 || d->stride_h != 1 || d->stride_w != 1 || d->pad_top || d->pad_left) return 0;
+  if ((int64_t)d->n * d->h * d->w < 65536) return 0;
+  if (tune_get("bwd1x1", 1) == 0) return 0;
+  if (d->cin == 64 && d->cout == 256) return 1;
+  if (d->cin == 256 && d->cout == 64) return 2;
+  if (d->cin == 64 && d->cout == 64) return 3;
+  return 0;
+}
+static inline int bwd1x1_splits() { return 2 * num_cus(); }       // two 256-thread workgroups per CU, one round
+static inline size_t bwd1x1_workspace(const RiglConvDesc* d) {
+  return bwd1x1_kind(d) ? (size_t)bwd1x1_splits() * d->cin * d->cout * 4 : 0;
+}
+static bool launch_bwd1x1(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                          const rigl_bf16* addend, rigl_bf16* dx, float* slab, hipStream_t st) {
+  Bwd1x1Args a = {};
+  a.X = x; a.DY = dy; a.W = w_hwio; a.ADD = addend; a.DX = dx; a.SLAB = slab;
+  a.M = d->n * d->h * d->w; a.splits = bwd1x1_splits();
+  a.x_bytes = (uint32_t)((size_t)a.M * d->cin * 2); a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
+  const dim3 grid((unsigned)a.splits), blk(THREADS);
+  const bool w = slab != nullptr;
+  switch (bwd1x1_kind(d)) {
+    case 1: if (w) RIGL_K_LAUNCH((k_bwd1x1<64, 256, true>), grid, blk, 0, st, a); else RIGL_K_LAUNCH((k_bwd1x1<64, 256, false>), grid, blk, 0, st, a); return true;
+    case 2: if (w) RIGL_K_LAUNCH((k_bwd1x1<256, 64, true>), grid, blk, 0, st, a); else RIGL_K_LAUNCH((k_bwd1x1<256, 64, false>), grid, blk, 0, st, a); return true;
+    case 3: if (w) RIGL_K_LAUNCH((k_bwd1x1<64, 64, true>), grid, blk, 0, st, a); else RIGL_K_LAUNCH((k_bwd1x1<64, 64, false>), grid, blk, 0, st, a); return true;
+    default: return false;
+  }
+}

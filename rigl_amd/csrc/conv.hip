@@ -1505,6 +1505,7 @@ static inline bool small_cin(const RiglConvDesc* d) { return (d->cin % 8) != 0 &
 static inline int kpad(const RiglConvDesc* d) { return (d->kh * d->kw * d->cin + 31) / 32 * 32; }
 
 #include "convpp.hpp"
+#include "bwd1x1.hpp"
 
 struct WgradPlan { int tm, tn, tiles_ci, tiles_co, splits; int64_t slab; };
 // DMA ring depth of the tr kernel: 3 stages for the 128x128 tile (48 KB -> 3 workgroups/CU),
@@ -1604,6 +1605,8 @@ size_t rigl_conv2d_workspace_bytes(const RiglConvDesc* d, int32_t which) {
     size_t need = p.splits > 1 ? align_up((size_t)p.splits * p.slab * 4, 256) : 0;
     const size_t npp = align_up(pp_wgrad_workspace(d), 256);   // the ping-pong weight gradients have their own split plans
     if (npp > need) need = npp;
+    const size_t n11 = align_up(bwd1x1_workspace(d), 256);     // ... and the single-pass 1x1 backward one slab per workgroup
+    if (n11 > need) need = n11;
     return need;
   }
   return 0;
@@ -1700,6 +1703,7 @@ int32_t rigl_conv2d_dgrad_stats_parts(const RiglConvDesc* d) {
   using namespace rigl::k1;
   if (!d || check_desc(d, "rigl_conv2d_dgrad_stats_parts")) return 0;
   if ((d->cin % 8) || (d->cout % 8)) return 0;
+  if (bwd1x1_kind(d)) return 0;               // the single-pass 1x1 backward has no reduction epilogue
   IgemmArgs a = dgrad_args(d, nullptr, nullptr, nullptr, nullptr);
   if (plan_pp<1>(a).variant) return 0;        // the ping-pong dgrad has no reduction epilogue
   const IgemmPlan pl = plan_igemm<1>(a);
@@ -1738,6 +1742,14 @@ static int dgrad_impl(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf1
   if ((d->cin % 8) || (d->cout % 8)) return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_dgrad: cin/cout %% 8 != 0 (use the reference kernel)");
   hipStream_t st = as_stream(stream);
   ProfFamily prof(PROF_CONV_DGRAD);
+  if (!bn && bwd1x1_kind(d)) {
+    // the big-M 1x1 layers: dX from the single-pass backward kernel (without its weight-gradient half), so that it has
+    // the bits rigl_masked_conv2d_bwd gives it
+    if (launch_bwd1x1(d, nullptr, dy, w_hwio, addend, dx, nullptr, st)) {
+      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
+      return RIGL_OK;
+    }
+  }
   IgemmArgs a = dgrad_args(d, dy, w_hwio, addend, dx);
   rc = attach_bn(a, d, bn);
   if (rc) return rc;
@@ -1907,6 +1919,26 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
   if (dx && (d->cin % 8) == 0 && (d->cout % 8) == 0 && !bn) {
     const IgemmArgs ap = dgrad_args(d, dy, w_hwio, addend, dx);
     dgrad_pp = plan_pp<1>(ap).variant != 0;
+  }
+  // The big-M 1x1 layers: dX and dW in ONE pass over dY (bwd1x1.hpp), one slab per workgroup, then the reduce
+  if (dx && x && dy && w_hwio && dw && !bn && bwd1x1_kind(d)) {
+    const size_t need = rigl_conv2d_workspace_bytes(d, 2);
+    if (need && (!workspace || workspace_bytes < need))
+      return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
+    if (have_flush) { ProfFamily pf(PROF_CONV_BWD); launch_pending_reduce(flush, st); }
+    ProfFamily prof(PROF_CONV_BWD);
+    if (launch_bwd1x1(d, x, dy, w_hwio, addend, dx, static_cast<float*>(workspace), st)) {
+      const int64_t n_out = (int64_t)d->cin * d->cout;
+      if (defer) {
+        defer->slabs = static_cast<const float*>(workspace); defer->dw = dw; defer->n_out = n_out;
+        defer->slab_elems = n_out; defer->splits = bwd1x1_splits();
+      } else {
+        ReduceArgs ra = {static_cast<const float*>(workspace), dw, n_out, n_out, bwd1x1_splits()};
+        launch_wgrad_reduce(ra, st);
+      }
+      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");
+      return RIGL_OK;
+    }
   }
   // The shared launch on the 8-wave ping-pong bodies ("pp_bwd"): layers whose weight gradient has 256-channel tiles and
   // whose dgrad is a stride-1 long reduction.
