@@ -585,7 +585,15 @@ int rigl_probe_mfma_bf16(int32_t blocks, int32_t iters, float* sink, rigl_stream
  *   "pp_ph"                 4: one quadrant per phase (default 2 / 1 phases);
  *   "pp_slab_mb"            cap on a layer's split-K slab bytes (40);
  *   "pp_bwd_min_kt"         shortest dgrad reduction (K-tiles of 64) the
- *                           pp_bwd rule takes (16).
+ *                           pp_bwd rule takes (16);
+ *   "bwd1x1"                0: the single-pass backward of the 56x56-class 1x1
+ *                           layers (64->256, 64->64; dY read once) off (1);
+ *   "bwd1x1_256x64"         1: also for 256->64 (measured level: 0);
+ *   "bwd1x1_wgs"            workgroups per CU of that kernel, 2 (3-deep ring
+ *                           each) or 1 (7-deep ring); "bwd1x1_il" 0: contiguous
+ *                           pixel ranges per workgroup instead of interleaved
+ *                           K-tiles; "bn_fin1" 0: the one-level forward
+ *                           batch-norm finalize for every size.
  * No reference counterpart (the reference selects cuDNN/TPU algorithms inside
  * TensorFlow: rigl/imagenet_resnet/pruning_layers.py:139-157).              */
 int rigl_tune_set(const char* key, int32_t value);

@@ -13,7 +13,11 @@
 // that is conflict-free for BOTH access patterns -- 512-byte rows: ((r & 1) << 1) | ((r >> 1 & 1) << 2) | ((r ^ r >> 2) & 1) << 3,
 // 128-byte rows: ((r >> 1) & 1) << 1 | ((r >> 1 ^ r >> 2) & 1) << 2 -- applied on the DMA's source side.
 // Memory-bound by ~3x (512 MFMA cycles per wave per 20 KB K-tile), so the loop is the plain ring: counted vmcnt, one
-// barrier per K-tile, two 256-thread workgroups per CU.
+// barrier per K-tile, two 256-thread workgroups per CU.  Measured at batch 128 (gpurun r3p-r3s): 64->256 84 -> 70 us,
+// 64->64 39 -> 32 us, 256->64 110 -> 109 us (level: off by default).  What mattered, in order: workgroups take every
+// splits-th K-tile instead of a contiguous range (77 -> 70 us: the grid streams one contiguous window instead of 512
+// streams 400 KB apart); dX leaves through LDS as whole 16-byte row segments; the stores of tile kt are issued at the top
+// of iteration kt + 1 (stores and loads share vmcnt on gfx9) and the wait counts LOADS only.
 // Reference: the autodiff of layers.masked_conv2d (pruning_layers.py:139-157; sparse_optimizers_base.py:478-485).
 #pragma once
 
@@ -24,7 +28,7 @@ struct Bwd1x1Args {
   const uint16_t* ADD;  // [M][CI] bf16 or NULL: added to dX (bf16(bf16(dgrad) + addend), like the dgrad epilogue)
   uint16_t* DX;         // [M][CI] bf16
   float* SLAB;          // [splits][CI][CO] fp32 partial dW (NULL with DO_W = false)
-  int M, splits;
+  int M, splits, interleave;
   uint32_t x_bytes, dy_bytes;
 };
 
@@ -36,9 +40,11 @@ __device__ __forceinline__ int dual_swz(int row) {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-template <int CI, int CO, bool DO_W>
+template <int CI, int CO, bool DO_W, int NST>
+struct Bwd1x1Smem { static constexpr int BYTES = NST * 32 * ((DO_W ? CI : 0) + CO) * 2 + (CI <= 64 ? 2 : 1) * 32 * (CI * 2 + 16); };
+template <int CI, int CO, bool DO_W, int NST>
 __global__ __launch_bounds__(THREADS) void k_bwd1x1(Bwd1x1Args P) {
-  constexpr int PX = 32, NST = 3;
+  constexpr int PX = 32;
   constexpr int YROWB = CO * 2, XROWB = CI * 2;
   constexpr int Y_BYTES = PX * YROWB, X_BYTES = DO_W ? PX * XROWB : 0, STAGE = Y_BYTES + X_BYTES;
   constexpr int YI = YROWB / 32, XI = XROWB / 32;             // DMA wave-instructions per tile (1 KB each)
@@ -52,15 +58,29 @@ __global__ __launch_bounds__(THREADS) void k_bwd1x1(Bwd1x1Args P) {
   constexpr bool WIDE_O = NFO >= NFI;
   constexpr int WF = NFI * NFO / 4 > 0 ? NFI * NFO / 4 : 1;  // fragments per wave
   static_assert(CFW * KSD * 4 <= 96, "W fragments stay in registers");
-  static_assert(NST * STAGE <= 65536, "static LDS");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+  // the dX tile of a K-tile is staged in LDS ([32 pixels][CI] bf16, rows padded by 16 bytes) so that it leaves as whole
+  // 16-byte-per-lane row segments: straight from the accumulators a lane owns 8 bytes of 16 different pixels' rows
+  // The tile of K-tile kt is written after its MFMAs and stored at the top of iteration kt + 1, behind that iteration's
+  // barrier: on gfx9 stores count in vmcnt like loads, so stores issued just before the DMA wait would have to retire
+  // (or part of the NEXT stage's DMA land) before the wait is satisfied.  Two staging tiles where they are small
+  // (CI = 64); one tile and a second barrier per iteration for CI = 256.
+  constexpr bool DXDB = CI <= 64;
+  constexpr int NDX = DXDB ? 2 : 1;
+  constexpr int DXROWB = XROWB + 16, DX_BYTES = PX * DXROWB;
+  static_assert(NST * STAGE + NDX * DX_BYTES == Bwd1x1Smem<CI, CO, DO_W, NST>::BYTES, "host and device agree on the LDS size");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char* const dxs = smem + NST * STAGE;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int split = blockIdx.x;
   const int KT_all = (P.M + PX - 1) / PX;
-  const int kt_begin = (int)((int64_t)KT_all * split / P.splits);
-  const int KT = (int)((int64_t)KT_all * (split + 1) / P.splits) - kt_begin;
+  // K-tiles of this workgroup: every splits-th one (interleave: at any moment the grid streams ONE contiguous window
+  // of the tensors, splits x 16-20 KB, instead of `splits` streams a fixed 400 KB apart) or a contiguous range
+  const int kt_begin = P.interleave ? split : (int)((int64_t)KT_all * split / P.splits);
+  const int kt_step = P.interleave ? P.splits : 1;
+  const int KT = P.interleave ? (split < KT_all ? (KT_all - split + P.splits - 1) / P.splits : 0)
+                              : (int)((int64_t)KT_all * (split + 1) / P.splits) - kt_begin;
   const __amdgpu_buffer_rsrc_t rsrcY = make_rsrc(P.DY, P.dy_bytes), rsrcX = make_rsrc(P.X, P.x_bytes);
 
   // ---- DMA lanes ------------------------------------------------------------------------------------------------------
@@ -79,7 +99,7 @@ __global__ __launch_bounds__(THREADS) void k_bwd1x1(Bwd1x1Args P) {
   }
 #define B1_ISSUE(kt_, stage_)                                                                            \
   {                                                                                                      \
-    const int p0_ = (kt_begin + (kt_)) * PX;                                                             \
+    const int p0_ = (kt_begin + (kt_) * kt_step) * PX;                                                             \
     _Pragma("unroll") for (int q = 0; q < YPW; ++q) {                                                    \
       const int p_ = p0_ + y_row[q];                                                                     \
       const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * CO + y_col[q]) * 2u) : (int)OOB;                 \
@@ -131,25 +151,58 @@ __global__ __launch_bounds__(THREADS) void k_bwd1x1(Bwd1x1Args P) {
 #define B1_TR_OFF(ROWB_, chunk_, plus4_) \
   ((t_row + (plus4_)) * (ROWB_) + ((((chunk_) + t_low) ^ dual_swz<ROWB_>(t_row + (plus4_))) << 4) + t_half)
 
-  constexpr int W_OUT = L * (NST - 2);
+  constexpr int DXP = PX * (CI / 8) / THREADS;               // 16-byte pieces of a dX tile per thread
+  static_assert(PX * (CI / 8) % THREADS == 0, "whole pieces per thread");
+  // LOADS issued after stage kt's DMA when iteration kt waits for it (loads return in order among themselves; stores
+  // may retire earlier, so only loads may be counted on): the DMA of NST - 2 later stages and, with a shortcut
+  // gradient, NST - 1 addend tiles
+  constexpr int W_N = L * (NST - 2), W_A = W_N + DXP * (NST - 1);
+  uint4 addv[DXP];                                            // the shortcut gradient of the tile stored next
+  // stores tile ktp (staged in LDS by every wave before the barrier this is called behind)
+#define B1_FLUSH(ktp_, second_barrier_)                                                                    \
+  {                                                                                                        \
+    const int p0_ = (kt_begin + (ktp_) * kt_step) * PX;                                                              \
+    const unsigned char* src_ = dxs + ((ktp_) & (NDX - 1)) * DX_BYTES;                                     \
+    uint4 v_[DXP];                                                                                         \
+    _Pragma("unroll") for (int q = 0; q < DXP; ++q) {                                                      \
+      const int idx = q * THREADS + tid, row = idx / (CI / 8), ch = idx % (CI / 8);                        \
+      v_[q] = *reinterpret_cast<const uint4*>(src_ + row * DXROWB + ch * 16);                              \
+    }                                                                                                      \
+    if (second_barrier_) __syncthreads();                                                                  \
+    _Pragma("unroll") for (int q = 0; q < DXP; ++q) {                                                      \
+      const int idx = q * THREADS + tid, row = idx / (CI / 8), ch = idx % (CI / 8);                        \
+      if (p0_ + row < P.M) {                                                                               \
+        uint4 v = v_[q];                                                                                   \
+        if (P.ADD) {                                                                                       \
+          const uint4 a = addv[q];                                                                         \
+          v.x = add_bf16x2(v.x, a.x); v.y = add_bf16x2(v.y, a.y); v.z = add_bf16x2(v.z, a.z); v.w = add_bf16x2(v.w, a.w); \
+        }                                                                                                  \
+        *reinterpret_cast<uint4*>(P.DX + (int64_t)(p0_ + row) * CI + ch * 8) = v;                          \
+      }                                                                                                    \
+    }                                                                                                      \
+  }
   for (int t = 0; t < NST - 1; ++t)
     if (t < KT) B1_ISSUE(t, t);
   for (int kt = 0; kt < KT; ++kt) {
-    if (kt + NST - 1 <= KT) wait_vmcnt<W_OUT>();
-    else wait_vmcnt<0>();
+    if (kt + NST - 1 <= KT) {
+      if (P.ADD && kt >= NST - 1) wait_vmcnt<W_A>();     // (the first NST - 1 iterations have fewer addend loads behind them)
+      else wait_vmcnt<W_N>();
+    } else {
+      wait_vmcnt<0>();
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (kt + NST - 1 < KT) B1_ISSUE(kt + NST - 1, (kt + NST - 1) % NST);
+    if (kt > 0) B1_FLUSH(kt - 1, !DXDB);
     const unsigned char* Ys = smem + (kt % NST) * STAGE;
     const unsigned char* Xs = Ys + Y_BYTES;
-    // the shortcut gradient of this tile's pixels: requested now, used after the MFMAs
-    const int px = (kt_begin + kt) * PX + 16 * pf + (lane & 15);
-    uint2 addv[CFW];
     if (P.ADD) {
+      const int p0 = (kt_begin + kt * kt_step) * PX;
 #pragma unroll
-      for (int c = 0; c < CFW; ++c)
-        addv[c] = px < P.M ? *reinterpret_cast<const uint2*>(P.ADD + (int64_t)px * CI + (chalf * CFW + c) * 16 + (lane >> 4) * 4)
-                           : make_uint2(0u, 0u);
+      for (int q = 0; q < DXP; ++q) {
+        const int idx = q * THREADS + tid, row = idx / (CI / 8), ch = idx % (CI / 8);
+        addv[q] = p0 + row < P.M ? *reinterpret_cast<const uint4*>(P.ADD + (int64_t)(p0 + row) * CI + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
+      }
     }
     // ---- dX tile: D[ci][px] = W-fragment x dY-fragment --------------------------------------------------------------------
     f32x4 acc1[CFW];
@@ -185,19 +238,25 @@ __global__ __launch_bounds__(THREADS) void k_bwd1x1(Bwd1x1Args P) {
         }
       }
     }
-    // ---- store the dX tile: lane (l & 15) = pixel, 4 consecutive channels (l >> 4) * 4 .. of each fragment ---------------------
-    if (px < P.M) {
+    // ---- dX tile -> LDS (lane (l & 15) = pixel, 4 consecutive channels (l >> 4) * 4 .. of each fragment) -------------------------
+    {
+      const int prow = 16 * pf + (lane & 15);
+      unsigned char* const dst = dxs + (kt & (NDX - 1)) * DX_BYTES;
 #pragma unroll
       for (int c = 0; c < CFW; ++c) {
         const f32x2 lo = {acc1[c][0], acc1[c][1]}, hi2 = {acc1[c][2], acc1[c][3]};
         uint2 pk;
         pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));
         pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi2, bf16x2));
-        if (P.ADD) { pk.x = add_bf16x2(pk.x, addv[c].x); pk.y = add_bf16x2(pk.y, addv[c].y); }
-        *reinterpret_cast<uint2*>(P.DX + (int64_t)px * CI + (chalf * CFW + c) * 16 + (lane >> 4) * 4) = pk;
+        *reinterpret_cast<uint2*>(dst + prow * DXROWB + ((chalf * CFW + c) * 16 + (lane >> 4) * 4) * 2) = pk;
       }
     }
   }
+  if (KT > 0) {
+    __syncthreads();
+    B1_FLUSH(KT - 1, false);
+  }
+#undef B1_FLUSH
 #undef B1_ISSUE
 #undef B1_TR_OFF
   // ---- the workgroup's dW partial -> its slab: D2 row (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) = ci, column lane & 31 = co ------
@@ -223,26 +282,44 @@ static inline int bwd1x1_kind(const RiglConvDesc* d) {
   if ((int64_t)d->n * d->h * d->w < 65536) return 0;
   if (tune_get("bwd1x1", 1) == 0) return 0;
   if (d->cin == 64 && d->cout == 256) return 1;
-  if (d->cin == 256 && d->cout == 64) return 2;
+  // 256 -> 64 measured level with the fused igemm launch (109 vs 110 us at batch 128): off unless asked for
+  if (d->cin == 256 && d->cout == 64) return tune_get("bwd1x1_256x64", 0) ? 2 : 0;
   if (d->cin == 64 && d->cout == 64) return 3;
   return 0;
 }
-static inline int bwd1x1_splits() { return 2 * num_cus(); }       // two 256-thread workgroups per CU, one round
+// one round of workgroups: "bwd1x1_wgs" per CU (2: a 3-deep ring each; 1: half the slabs and a 7-deep ring)
+static inline int bwd1x1_wgs_per_cu() { const int v = tune_get("bwd1x1_wgs", 2); return v == 1 ? 1 : 2; }
+static inline int bwd1x1_splits() { return bwd1x1_wgs_per_cu() * num_cus(); }
 static inline size_t bwd1x1_workspace(const RiglConvDesc* d) {
-  return bwd1x1_kind(d) ? (size_t)bwd1x1_splits() * d->cin * d->cout * 4 : 0;
+  return bwd1x1_kind(d) ? (size_t)2 * num_cus() * d->cin * d->cout * 4 : 0;
+}
+template <int CI, int CO, bool DO_W, int NST>
+static bool launch_bwd1x1_i(const Bwd1x1Args& a, hipStream_t st) {
+  constexpr int SMEM = Bwd1x1Smem<CI, CO, DO_W, NST>::BYTES;
+  static_assert(SMEM <= 160 * 1024 / (NST == 3 ? 2 : 1), "the ring of the workgroups resident on a CU fits its LDS");
+  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd1x1<CI, CO, DO_W, NST>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess;
+  if (!ready) return false;
+  RIGL_K_LAUNCH((k_bwd1x1<CI, CO, DO_W, NST>), dim3((unsigned)a.splits), dim3(THREADS), SMEM, st, a);
+  return true;
+}
+template <int CI, int CO>
+static bool launch_bwd1x1_t(const Bwd1x1Args& a, bool w, bool deep, hipStream_t st) {
+  constexpr int DEEP = 7;                                    // ring depth of the one-workgroup-per-CU variant
+  if (w) return deep ? launch_bwd1x1_i<CI, CO, true, DEEP>(a, st) : launch_bwd1x1_i<CI, CO, true, 3>(a, st);
+  return deep ? launch_bwd1x1_i<CI, CO, false, DEEP>(a, st) : launch_bwd1x1_i<CI, CO, false, 3>(a, st);
 }
 static bool launch_bwd1x1(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
                           const rigl_bf16* addend, rigl_bf16* dx, float* slab, hipStream_t st) {
   Bwd1x1Args a = {};
   a.X = x; a.DY = dy; a.W = w_hwio; a.ADD = addend; a.DX = dx; a.SLAB = slab;
-  a.M = d->n * d->h * d->w; a.splits = bwd1x1_splits();
+  a.M = d->n * d->h * d->w; a.splits = bwd1x1_splits(); a.interleave = tune_get("bwd1x1_il", 1);
   a.x_bytes = (uint32_t)((size_t)a.M * d->cin * 2); a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
-  const dim3 grid((unsigned)a.splits), blk(THREADS);
-  const bool w = slab != nullptr;
+  const bool w = slab != nullptr, deep = bwd1x1_wgs_per_cu() == 1;
   switch (bwd1x1_kind(d)) {
-    case 1: if (w) RIGL_K_LAUNCH((k_bwd1x1<64, 256, true>), grid, blk, 0, st, a); else RIGL_K_LAUNCH((k_bwd1x1<64, 256, false>), grid, blk, 0, st, a); return true;
-    case 2: if (w) RIGL_K_LAUNCH((k_bwd1x1<256, 64, true>), grid, blk, 0, st, a); else RIGL_K_LAUNCH((k_bwd1x1<256, 64, false>), grid, blk, 0, st, a); return true;
-    case 3: if (w) RIGL_K_LAUNCH((k_bwd1x1<64, 64, true>), grid, blk, 0, st, a); else RIGL_K_LAUNCH((k_bwd1x1<64, 64, false>), grid, blk, 0, st, a); return true;
+    case 1: return launch_bwd1x1_t<64, 256>(a, w, deep, st);
+    case 2: return launch_bwd1x1_t<256, 64>(a, w, deep, st);
+    case 3: return launch_bwd1x1_t<64, 64>(a, w, deep, st);
     default: return false;
   }
 }

@@ -93,8 +93,16 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t b
 template <int N> __device__ __forceinline__ void wait_vmcnt();
 #define RIGL_WAIT_VMCNT(N) template <> __device__ __forceinline__ void wait_vmcnt<N>() { asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); }
 RIGL_WAIT_VMCNT(0) RIGL_WAIT_VMCNT(1) RIGL_WAIT_VMCNT(2) RIGL_WAIT_VMCNT(3) RIGL_WAIT_VMCNT(4) RIGL_WAIT_VMCNT(5)
-RIGL_WAIT_VMCNT(6) RIGL_WAIT_VMCNT(7) RIGL_WAIT_VMCNT(8) RIGL_WAIT_VMCNT(9) RIGL_WAIT_VMCNT(10) RIGL_WAIT_VMCNT(12)
-RIGL_WAIT_VMCNT(16)
+RIGL_WAIT_VMCNT(6) RIGL_WAIT_VMCNT(7) RIGL_WAIT_VMCNT(8) RIGL_WAIT_VMCNT(9) RIGL_WAIT_VMCNT(10) RIGL_WAIT_VMCNT(11)
+RIGL_WAIT_VMCNT(12) RIGL_WAIT_VMCNT(13) RIGL_WAIT_VMCNT(14) RIGL_WAIT_VMCNT(15) RIGL_WAIT_VMCNT(16) RIGL_WAIT_VMCNT(17)
+RIGL_WAIT_VMCNT(18) RIGL_WAIT_VMCNT(19) RIGL_WAIT_VMCNT(20) RIGL_WAIT_VMCNT(21) RIGL_WAIT_VMCNT(22) RIGL_WAIT_VMCNT(23)
+RIGL_WAIT_VMCNT(24) RIGL_WAIT_VMCNT(25) RIGL_WAIT_VMCNT(26) RIGL_WAIT_VMCNT(27) RIGL_WAIT_VMCNT(28) RIGL_WAIT_VMCNT(29)
+RIGL_WAIT_VMCNT(30) RIGL_WAIT_VMCNT(31) RIGL_WAIT_VMCNT(32) RIGL_WAIT_VMCNT(33) RIGL_WAIT_VMCNT(34) RIGL_WAIT_VMCNT(35)
+RIGL_WAIT_VMCNT(36) RIGL_WAIT_VMCNT(37) RIGL_WAIT_VMCNT(38) RIGL_WAIT_VMCNT(39) RIGL_WAIT_VMCNT(40) RIGL_WAIT_VMCNT(41)
+RIGL_WAIT_VMCNT(42) RIGL_WAIT_VMCNT(43) RIGL_WAIT_VMCNT(44) RIGL_WAIT_VMCNT(45) RIGL_WAIT_VMCNT(46) RIGL_WAIT_VMCNT(47)
+RIGL_WAIT_VMCNT(48) RIGL_WAIT_VMCNT(49) RIGL_WAIT_VMCNT(50) RIGL_WAIT_VMCNT(51) RIGL_WAIT_VMCNT(52) RIGL_WAIT_VMCNT(53)
+RIGL_WAIT_VMCNT(54) RIGL_WAIT_VMCNT(55) RIGL_WAIT_VMCNT(56) RIGL_WAIT_VMCNT(57) RIGL_WAIT_VMCNT(58) RIGL_WAIT_VMCNT(59)
+RIGL_WAIT_VMCNT(60) RIGL_WAIT_VMCNT(61) RIGL_WAIT_VMCNT(62) RIGL_WAIT_VMCNT(63)
 #undef RIGL_WAIT_VMCNT
 
 __device__ __forceinline__ uint32_t dword_of(const uint4& v, int d) {
