@@ -246,7 +246,12 @@ int rigl_masked_conv2d_dgrad(const RiglConvDesc* d, const rigl_bf16* dy,
  * resnet_model.py:41-82, whose first pass re-reads the whole activation):
  * stats[p][0][c] = sum, stats[p][1][c] = sum of squares of the bf16-rounded
  * outputs of 128-row tile p, p < rigl_conv2d_stats_parts(d), computed in the
- * epilogue from the tile already in LDS (deterministic, no atomics).
+ * epilogue from the tile already in LDS (deterministic, no atomics).  The
+ * parts are disjoint row sets that cover the output; which rows a part holds
+ * is the kernel's choice: rows [128p, 128p + 128) for every layer but the
+ * ImageNet stem (7x7/2, 3 -> 64 channels, knob "stem_direct"), whose kernel
+ * works on 16 x 16 output-pixel tiles t = (image, tile row, tile column) and
+ * leaves part 2t + h = pixel rows [8h, 8h + 8) of tile t.
  * stats == NULL: plain rigl_masked_conv2d_fwd.                              */
 int32_t rigl_conv2d_stats_parts(const RiglConvDesc* d);
 int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x,
@@ -586,6 +591,9 @@ int rigl_probe_mfma_bf16(int32_t blocks, int32_t iters, float* sink, rigl_stream
  *   "pp_slab_mb"            cap on a layer's split-K slab bytes (40);
  *   "pp_bwd_min_kt"         shortest dgrad reduction (K-tiles of 64) the
  *                           pp_bwd rule takes (16);
+ *   "stem_direct"           0: the ImageNet stem through the generic bodies
+ *                           over a padded 4-channel copy instead of the
+ *                           LDS-resident-patch kernels (1);
  *   "bwd1x1"                0: the single-pass backward of the 56x56-class 1x1
  *                           layers (64->256, 64->64; dY read once) off (1);
  *   "bwd1x1_256x64"         1: also for 256->64 (measured level: 0);

@@ -1321,15 +1321,16 @@ __global__ __launch_bounds__(THREADS) void k_stem_weights(const uint16_t* __rest
   }
 }
 // dw[(r*KW+s)*Cin + c][co]  <-  t[r][s*4 + c][co]
+// (shift: the column the first filter tap sits in -- 1 for the stem.hpp kernels, whose windows start one pixel early)
 __global__ __launch_bounds__(THREADS) void k_stem_unpack(const float* __restrict__ t, float* __restrict__ dw, int KH,
-                                                          int KW, int Cin, int Cred, int cout) {
+                                                          int KW, int Cin, int Cred, int cout, int shift) {
   const int total = KH * KW * Cin * cout;
   for (int i = blockIdx.x * THREADS + threadIdx.x; i < total; i += gridDim.x * THREADS) {
     const int co = i % cout;
     int k = i / cout;
     const int c = k % Cin; k /= Cin;
     const int s2 = k % KW, r = k / KW;
-    dw[i] = t[((int64_t)r * Cred + s2 * 4 + c) * cout + co];
+    dw[i] = t[((int64_t)r * Cred + (s2 + shift) * 4 + c) * cout + co];
   }
 }
 struct TinyGeom { int cred, hp, wp; };
@@ -1514,6 +1515,7 @@ static inline int kpad(const RiglConvDesc* d) { return (d->kh * d->kw * d->cin +
 
 #include "convpp.hpp"
 #include "bwd1x1.hpp"
+#include "stem.hpp"
 
 struct WgradPlan { int tm, tn, tiles_ci, tiles_co, splits; int64_t slab; };
 // DMA ring depth of the tr kernel: 3 stages for the 128x128 tile (48 KB -> 3 workgroups/CU),
@@ -1594,7 +1596,9 @@ size_t rigl_conv2d_workspace_bytes(const RiglConvDesc* d, int32_t which) {
     if (which == 0) return xp + align_up((size_t)d->cout * d->kh * tg.cred * 2, 256);
     if (which == 2) {
       WgradPlan p = tiny_wgrad_plan((int)M, tg.cred, d->cout, d->kh);
-      return xp + align_up((size_t)p.slab * 4, 256) + align_up((size_t)p.splits * p.slab * 4, 256);
+      const size_t generic = xp + align_up((size_t)p.slab * 4, 256) + align_up((size_t)p.splits * p.slab * 4, 256);
+      const size_t direct = stem_wgrad_workspace(d);       // stem.hpp: no padded copy, one slab per workgroup
+      return generic > direct ? generic : direct;
     }
     return 0;
   }
@@ -1651,6 +1655,14 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, cons
     const size_t xp_bytes = (size_t)d->n * tg.hp * tg.wp * 4 * 2;
     uint16_t* xp = static_cast<uint16_t*>(workspace);
     uint16_t* wp = reinterpret_cast<uint16_t*>(static_cast<char*>(workspace) + align_up(xp_bytes, 256));
+    if (stem_direct_legal(d)) {
+      // the ImageNet stem: the image patch of a 16 x 16 output tile resident in LDS, no padded copy (stem.hpp)
+      RIGL_K_LAUNCH(k_stem_weights_shift, dim3(56), dim3(THREADS), 0, st, w_ohwi, wp, d->cout);
+      if (launch_stem_fwd(d, x, wp, y, stats, st)) {
+        RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
+        return RIGL_OK;
+      }
+    }
     PadArgs pa = {x, xp, d->n, d->h, d->w, d->cin, tg.hp, tg.wp, d->pad_top, d->pad_left};
     RIGL_K_LAUNCH(k_pad_input4, dim3(2048), dim3(THREADS), 0, st, pa);
     RIGL_K_LAUNCH(k_stem_weights, dim3(64), dim3(THREADS), 0, st, w_ohwi, wp, d->cout, d->kh, d->kw, d->cin, tg.cred);
@@ -1800,6 +1812,18 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
       return RIGL_OK;
     }
   }
+  if (tiny_cin(d) && stem_direct_legal(d) && tune_get("stem_wgrad", 1) != 0) {
+    // the ImageNet stem: patch and dY tile resident in LDS, both operands by transposing reads (stem.hpp)
+    float* tmp = static_cast<float*>(workspace);
+    float* slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)7 * 32 * 64 * 4, 256));
+    if (launch_stem_wgrad(d, x, dy, slabs, st)) {
+      ReduceArgs ra = {slabs, tmp, (int64_t)7 * 32 * 64, (int64_t)7 * 32 * 64, stem_wgrad_grid(d)};
+      launch_wgrad_reduce(ra, st);
+      RIGL_K_LAUNCH(k_stem_unpack, dim3(64), dim3(THREADS), 0, st, tmp, dw, 7, 7, 3, 32, 64, 1);
+      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_wgrad");
+      return RIGL_OK;
+    }
+  }
   WgradArgs a = {};
   a.DY = dy; a.M = d->n * d->ho * d->wo; a.Cout = d->cout;
   a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
@@ -1866,7 +1890,7 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
     launch_wgrad_reduce(ra, st);
   }
   if (tiny_tmp)
-    RIGL_K_LAUNCH(k_stem_unpack, dim3(64), blk, 0, st, tiny_tmp, dw, d->kh, d->kw, d->cin, tg.cred, d->cout);
+    RIGL_K_LAUNCH(k_stem_unpack, dim3(64), blk, 0, st, tiny_tmp, dw, d->kh, d->kw, d->cin, tg.cred, d->cout, 0);
   RIGL_CHECK_LAUNCH("rigl_masked_conv2d_wgrad");
   return RIGL_OK;
 }

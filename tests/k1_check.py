@@ -60,6 +60,17 @@ PP_CASES = [
 ]
 
 
+# The ImageNet stem kernels (stem.hpp): image borders on every side, odd tile counts, the TF-SAME top padding of 2
+STEM_CASES = [
+    (2, 64, 64, 3, 64, 7, 2, 3, 3, 32, 32),        # 2 x 2 tiles per image
+    (3, 32, 96, 3, 64, 7, 2, 3, 3, 16, 48),        # H != W, one tile row
+    (1, 96, 32, 3, 64, 7, 2, 3, 3, 48, 16),        # one tile column: both side borders in every tile
+    (5, 64, 64, 3, 64, 7, 2, 2, 3, 32, 32),        # 2 rows of padding above, 3 + 1 below
+    (4, 224, 224, 3, 64, 7, 2, 3, 3, 112, 112),    # the benchmarked image size (7 x 7 tiles)
+    (2, 60, 64, 3, 64, 7, 2, 3, 3, 30, 32),        # not a whole number of tiles: the generic path
+]
+
+
 def resnet50_shapes(batch):
   seen, out = set(), []
   out.append((batch, 224, 224, 3, 64, 7, 2, 3, 3, 112, 112))
@@ -132,7 +143,18 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
       rows = 128                                     # one partial per 128 output rows, whatever the tile
       assert part.shape[0] == (yf.shape[0] + rows - 1) // rows
       t = min(part.shape[0] - 1, 1)
-      blk = yf[t * rows:(t + 1) * rows]
+      stem_direct = (k == 7 and stride == 2 and Cin == 3 and Cout == 64 and pl == 3 and Ho % 16 == 0 and Wo % 16 == 0 and
+                     W % 4 == 0 and ops.tune_get('stem_direct', 1) != 0)
+      if stem_direct:
+        # the stem kernel's parts are halves of 16 x 16 output tiles (include/rigl_hip.h): check one in the interior
+        t = min(part.shape[0] - 1, 2 * (Wo // 16 + 1) + 1)
+        tile, h = t // 2, t % 2
+        per = (Ho // 16) * (Wo // 16)
+        ni, r = tile // per, tile % per
+        oh0, ow0 = (r // (Wo // 16)) * 16 + 8 * h, (r % (Wo // 16)) * 16
+        blk = y.double()[ni, oh0:oh0 + 8, ow0:ow0 + 16].reshape(-1, Cout)
+      else:
+        blk = yf[t * rows:(t + 1) * rows]
       assert float((part[t, 0].double() - blk.sum(0)).abs().max()) <= 1e-5 * float(blk.abs().sum(0).max()) + 1e-6, \
           'statistics: a tile partial is not the sum of its own rows'
   del y
@@ -171,11 +193,11 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
 
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument('--set', default='small', choices=['small', 'pp', 'resnet50'])
+  ap.add_argument('--set', default='small', choices=['small', 'pp', 'stem', 'resnet50'])
   ap.add_argument('--batch', type=int, default=128)
   ap.add_argument('--only', type=int, default=-1)
   a = ap.parse_args()
-  cases = SMALL_CASES if a.set == 'small' else (PP_CASES if a.set == 'pp' else resnet50_shapes(a.batch))
+  cases = {'small': SMALL_CASES, 'pp': PP_CASES, 'stem': STEM_CASES}.get(a.set) or resnet50_shapes(a.batch)
   worst, n = 0.0, 0
   for i, c in enumerate(cases):
     if a.only >= 0 and i != a.only:

@@ -62,3 +62,12 @@ def test_resnet50_layer_shapes_at_batch_128(env):
   can run in the step is pinned directly against the fp64 reference at the benchmarked sizes."""
   out = _run(['--set', 'resnet50', '--batch', '128'], env, timeout=3000)
   assert out['cases'] == 23
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
+@pytest.mark.parametrize('env', [{}, {'RIGL_STEM_DIRECT': '0'}])
+def test_imagenet_stem_shapes(env):
+  """The 7x7 / 2 stem on the LDS-resident-patch kernels (stem.hpp) and, with the knob off, on the generic bodies over the
+  padded copy: image borders on all sides, H != W, TF-SAME top padding, the statistics parts of 16 x 16 tiles."""
+  out = _run(['--set', 'stem'], env)
+  assert out['cases'] == 6
