@@ -591,6 +591,11 @@ int rigl_probe_mfma_bf16(int32_t blocks, int32_t iters, float* sink, rigl_stream
  *   "pp_slab_mb"            cap on a layer's split-K slab bytes (40);
  *   "pp_bwd_min_kt"         shortest dgrad reduction (K-tiles of 64) the
  *                           pp_bwd rule takes (16);
+ *   "bn_nt"                 non-temporal accesses of the batch-norm apply
+ *                           passes: 0 none, 1 stores, 2 loads and stores (2;
+ *                           -0.10 ms per ResNet-50 step); "bn_nt_mb" applies it
+ *                           only to tensors of at least that many MB (0);
+ *   "stem_wgrad"            0: only the stem's forward on stem.hpp (1);
  *   "stem_direct"           0: the ImageNet stem through the generic bodies
  *                           over a padded 4-channel copy instead of the
  *                           LDS-resident-patch kernels (1);
