@@ -56,6 +56,16 @@ __device__ __forceinline__ uint32_t add_bf16x2(uint32_t a, uint32_t b) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
+typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16(uint16_t* p, const uint4& v, int nt) {
+  if (nt) { const u32x4_nt t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<u32x4_nt*>(p)); }
+  else *reinterpret_cast<uint4*>(p) = v;
+}
+static inline int k1_nt(size_t out_bytes) {
+  const int mb = tune_get("k1_nt_mb", -1);
+  return mb >= 0 && out_bytes >= (size_t)mb * (1u << 20) ? 1 : 0;
+}
+
 // Byte offset of 16-byte chunk `chunk` of row `row` in a [rows][BK] bf16 tile.
 // The chunk index is XORed with a row-derived value so that the 16-lane groups
 // of ds_read_b128 (rows r..r+3, r+12.., r+20..) hit 16 distinct 16-B slots.
@@ -154,6 +164,7 @@ struct IgemmArgs {
   int cls_tile_begin[5];       // tile_m prefix per class (sh*sw <= 4 classes)
   int cls_cnt[4], cls_hc[4], cls_wc[4];
   int cls_n, cls_ids[4], cls_interleave;   // non-empty classes and the common tile count they interleave over
+  int nt_out;           // 1: output rows leave with non-temporal stores (knob "k1_nt_mb": outputs of at least that many MB)
   FastDiv fd_rw, fd_rh, fd_cwc[4], fd_chc[4];
 };
 
@@ -619,7 +630,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P, unsigned char* sm
             const uint4 q = addv[it];
             v.x = add_bf16x2(v.x, q.x); v.y = add_bf16x2(v.y, q.y); v.z = add_bf16x2(v.z, q.z); v.w = add_bf16x2(v.w, q.w);
           }
-          *reinterpret_cast<uint4*>(C + (int64_t)m * P.ldc + n) = v;
+          store16(C + (int64_t)m * P.ldc + n, v, P.nt_out);
         }
       }
     } else {
@@ -1647,6 +1658,7 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, cons
   ProfFamily prof(PROF_CONV_FWD);
   IgemmArgs a = {};
   a.C = y; a.M = d->n * d->ho * d->wo; a.N = d->cout; a.ldc = d->cout; a.STATS = stats;
+  a.nt_out = k1_nt((size_t)a.M * d->cout * 2);
   const size_t need = rigl_conv2d_workspace_bytes(d, 0);
   if (need && (!workspace || workspace_bytes < need))
     return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_fwd: workspace %zu < %zu", workspace_bytes, need);
@@ -1707,6 +1719,7 @@ static rigl::k1::IgemmArgs dgrad_args(const RiglConvDesc* d, const rigl_bf16* dy
                                       const rigl_bf16* addend, rigl_bf16* dx) {
   rigl::k1::IgemmArgs a = {};
   a.A = dy; a.B = w_hwio; a.C = dx; a.ADD = addend;
+  a.nt_out = rigl::k1::k1_nt((size_t)d->n * d->h * d->w * d->cin * 2);
   a.M = d->n * d->h * d->w; a.N = d->cin; a.Cred = d->cout; a.ldc = d->cin;
   a.KH = d->kh; a.KW = d->kw; a.RH = d->h; a.RW = d->w; a.GH = d->ho; a.GW = d->wo;
   a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;

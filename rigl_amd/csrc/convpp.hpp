@@ -321,7 +321,7 @@ __device__ __forceinline__ void pp_igemm_body(const IgemmArgs& P, unsigned char*
           const uint4 q = addv[it];
           v.x = add_bf16x2(v.x, q.x); v.y = add_bf16x2(v.y, q.y); v.z = add_bf16x2(v.z, q.z); v.w = add_bf16x2(v.w, q.w);
         }
-        *reinterpret_cast<uint4*>(C + (int64_t)m * P.ldc + ncol) = v;
+        store16(C + (int64_t)m * P.ldc + ncol, v, P.nt_out);
       }
     }
   }
