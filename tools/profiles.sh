@@ -12,9 +12,11 @@ for w in resnet50_erk99 mobilenet_v1 wrn22; do
 done
 timeout 300 python bench.py --workload wrn22 --graph --no-cpu-baseline > $O/bench_wrn22_graph.json 2>>$O/bench_err.txt; echo "wrn22 graph rc=$?" | tee -a $O/log.txt
 timeout 600 python tools/bench_kernels.py > $O/bench_kernels_per_layer.txt 2>&1; echo "bench_kernels rc=$?" | tee -a $O/log.txt
+if [ "${SKIP_SWEEP:-0}" != "1" ]; then
 timeout 600 python tools/pp_sweep.py --batch 128 --iters 20 --out $O/pp_sweep_b128.json > $O/pp_sweep_b128.txt 2>&1; echo "pp_sweep 128 rc=$?" | tee -a $O/log.txt
 timeout 600 python tools/pp_sweep.py --batch 512 --iters 10 --layers g3_c2_3x3_256 g3_c1_1024_256 g3_c3_256_1024 g4_c2_3x3_512 g2_c2_3x3_128 --out $O/pp_sweep_b512.json > $O/pp_sweep_b512.txt 2>&1; echo "pp_sweep 512 rc=$?" | tee -a $O/log.txt
 timeout 600 python tools/pp_sweep.py --batch 128 --iters 10 --passes bwd wgrad --out $O/pp_sweep_bwd_b128.json > $O/pp_sweep_bwd_b128.txt 2>&1; echo "pp_sweep bwd rc=$?" | tee -a $O/log.txt
+fi
 for i in 1 2 3; do timeout 300 python bench.py --no-cpu-baseline >> $O/bench_n1_runs.jsonl 2>>$O/bench_err.txt; done; echo "bench x3 rc=$?" | tee -a $O/log.txt
 timeout 300 python tools/k2_time.py > $O/k2_time.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
