@@ -28,7 +28,7 @@ struct Bwd1x1Args {
   const uint16_t* ADD;  // [M][CI] bf16 or NULL: added to dX (bf16(bf16(dgrad) + addend), like the dgrad epilogue)
   uint16_t* DX;         // [M][CI] bf16
   float* SLAB;          // [splits][CI][CO] fp32 partial dW (NULL with DO_W = false)
-  int M, splits, interleave;
+  int M, splits, interleave, nt;   // nt: operand tiles fetched with the non-temporal hint (knob "bwd1x1_nt")
   uint32_t x_bytes, dy_bytes;
 };
 
@@ -103,14 +103,18 @@ __global__ __launch_bounds__(THREADS) void k_bwd1x1(Bwd1x1Args P) {
     _Pragma("unroll") for (int q = 0; q < YPW; ++q) {                                                    \
       const int p_ = p0_ + y_row[q];                                                                     \
       const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * CO + y_col[q]) * 2u) : (int)OOB;                 \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                          \
+      if (P.nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(                                               \
+          rsrcY, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + (q * 4 + wave) * 1024), 16, off_, 0, 0, 2); \
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                     \
           rsrcY, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + (q * 4 + wave) * 1024), 16, off_, 0, 0, 0); \
     }                                                                                                    \
     if (DO_W) {                                                                                          \
       _Pragma("unroll") for (int q = 0; q < XPW; ++q) {                                                  \
         const int p_ = p0_ + x_row[q];                                                                   \
         const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * CI + x_col[q]) * 2u) : (int)OOB;               \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
+        if (P.nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
+            rsrcX, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + Y_BYTES + (q * 4 + wave) * 1024), 16, off_, 0, 0, 2); \
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                   \
             rsrcX, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + Y_BYTES + (q * 4 + wave) * 1024), 16, off_, 0, 0, 0); \
       }                                                                                                  \
     }                                                                                                    \
@@ -313,7 +317,7 @@ static bool launch_bwd1x1(const RiglConvDesc* d, const rigl_bf16* x, const rigl_
                           const rigl_bf16* addend, rigl_bf16* dx, float* slab, hipStream_t st) {
   Bwd1x1Args a = {};
   a.X = x; a.DY = dy; a.W = w_hwio; a.ADD = addend; a.DX = dx; a.SLAB = slab;
-  a.M = d->n * d->h * d->w; a.splits = bwd1x1_splits(); a.interleave = tune_get("bwd1x1_il", 1);
+  a.M = d->n * d->h * d->w; a.splits = bwd1x1_splits(); a.interleave = tune_get("bwd1x1_il", 1); a.nt = tune_get("bwd1x1_nt", 0);
   a.x_bytes = (uint32_t)((size_t)a.M * d->cin * 2); a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
   const bool w = slab != nullptr, deep = bwd1x1_wgs_per_cu() == 1;
   switch (bwd1x1_kind(d)) {

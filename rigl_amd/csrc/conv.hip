@@ -164,6 +164,10 @@ struct IgemmArgs {
   int cls_tile_begin[5];       // tile_m prefix per class (sh*sw <= 4 classes)
   int cls_cnt[4], cls_hc[4], cls_wc[4];
   int cls_n, cls_ids[4], cls_interleave;   // non-empty classes and the common tile count they interleave over
+  // two-way K split of the ping-pong forward (layers whose tiles would leave most CUs idle): each half of the reduction
+  // is a workgroup; the first to finish leaves its fp32 partial tile in KS_SLAB[tile][half], the second adds it and
+  // runs the epilogue (a + b = b + a: the same bits whichever arrives last).  KS_CNT[tile] = arrivals, zeroed per call.
+  float* KS_SLAB; uint32_t* KS_CNT; int ksplit;
   int nt_out;           // 1: output rows leave with non-temporal stores (knob "k1_nt_mb": outputs of at least that many MB)
   FastDiv fd_rw, fd_rh, fd_cwc[4], fd_chc[4];
 };
@@ -1528,6 +1532,17 @@ static inline int kpad(const RiglConvDesc* d) { return (d->kh * d->kw * d->cin +
 #include "bwd1x1.hpp"
 #include "stem.hpp"
 
+// Scratch of the K-split ping-pong forward (convpp.hpp: pp_ksplit_ok): two fp32 partial tiles + a counter per tile.
+static size_t pp_ksplit_workspace(const RiglConvDesc* d) {
+  if (d->cin <= 4 || (d->cin % 8) || (d->cout % 8)) return 0;
+  IgemmArgs a = {};
+  a.M = d->n * d->ho * d->wo; a.N = d->cout; a.Cred = d->cin; a.a_pix_stride = d->cin; a.KH = d->kh; a.KW = d->kw;
+  a.RH = d->ho; a.RW = d->wo; a.GH = d->h; a.GW = d->w; a.sh = d->stride_h; a.sw = d->stride_w;
+  const PPPlan p = plan_pp<0>(a);
+  if (!pp_ksplit_ok(a, p)) return 0;
+  return (size_t)p.grid * 2 * p.bm * p.bn * 4 + align_up((size_t)p.grid * 4, 256);
+}
+
 struct WgradPlan { int tm, tn, tiles_ci, tiles_co, splits; int64_t slab; };
 // DMA ring depth of the tr kernel: 3 stages for the 128x128 tile (48 KB -> 3 workgroups/CU),
 // 4 for the smaller tiles (measured per layer; RIGL_WGRAD_STAGES=3|4 forces one).
@@ -1623,6 +1638,7 @@ size_t rigl_conv2d_workspace_bytes(const RiglConvDesc* d, int32_t which) {
     }
     return 0;
   }
+  if (which == 0) return pp_ksplit_workspace(d);     // the K-split partial tiles of the few-tile forwards (else 0)
   if (which == 2) {
     WgradPlan p = plan_wgrad((int)M, d->cin, d->cout, d->kh * d->kw);
     size_t need = p.splits > 1 ? align_up((size_t)p.splits * p.slab * 4, 256) : 0;
@@ -1660,7 +1676,8 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, cons
   a.C = y; a.M = d->n * d->ho * d->wo; a.N = d->cout; a.ldc = d->cout; a.STATS = stats;
   a.nt_out = k1_nt((size_t)a.M * d->cout * 2);
   const size_t need = rigl_conv2d_workspace_bytes(d, 0);
-  if (need && (!workspace || workspace_bytes < need))
+  // (the ordinary layers' only workspace is the optional K-split scratch: without it they run unsplit)
+  if ((tiny_cin(d) || small_cin(d)) && need && (!workspace || workspace_bytes < need))
     return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_fwd: workspace %zu < %zu", workspace_bytes, need);
   if (tiny_cin(d)) {
     const TinyGeom tg = tiny_geom(d);
@@ -1700,6 +1717,12 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, cons
     a.a_bytes = (uint32_t)((size_t)d->n * d->h * d->w * d->cin * 2);
     a.b_bytes = (uint32_t)((size_t)d->kh * d->kw * d->cin * d->cout * 2);
     const PPPlan pp = plan_pp<0>(a);           // long reductions: the 8-wave ping-pong body
+    if (pp.variant && pp_ksplit_ok(a, pp) && workspace && workspace_bytes >= need && need) {
+      a.ksplit = 2;
+      a.KS_SLAB = static_cast<float*>(workspace);
+      a.KS_CNT = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + (size_t)pp.grid * 2 * pp.bm * pp.bn * 4);
+      RIGL_HIP(hipMemsetAsync(a.KS_CNT, 0, (size_t)pp.grid * 4, st));
+    }
     if (pp.variant && launch_pp<0>(pp, a, st)) {
       RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
       return RIGL_OK;

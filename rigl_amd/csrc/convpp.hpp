@@ -81,7 +81,11 @@ __device__ __forceinline__ void pp_igemm_body(const IgemmArgs& P, unsigned char*
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int grp = wave >> 2;                 // waves w and w + 4 share a SIMD: one of each group per SIMD
-  const uint32_t tile = xcd_remap(bid, nblk);
+  // K split (forward only): logical block 2 t + h = half h of tile t's reduction
+  const bool ksp = MODE == 0 && !CLS && P.ksplit == 2;
+  const uint32_t lblk = xcd_remap(bid, nblk);
+  const uint32_t tile = ksp ? lblk >> 1 : lblk;
+  const int khalf = ksp ? (int)(lblk & 1u) : 0;
   const int tile_m = (int)(tile / (uint32_t)P.tiles_n);
   const int n0 = (int)(tile % (uint32_t)P.tiles_n) * BN;
   int m0 = tile_m * BM;
@@ -175,14 +179,22 @@ __device__ __forceinline__ void pp_igemm_body(const IgemmArgs& P, unsigned char*
     }
   const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.A, P.a_bytes), rsrcB = make_rsrc(P.B, P.b_bytes);
   const int kcb = P.Cred >> 6;
-  const int KT = n_r * n_s * kcb;
+  const int KT_all = n_r * n_s * kcb;
+  const int kt_first = ksp && khalf ? KT_all / 2 : 0;                       // this workgroup's K-tiles [kt_first, kt_first + KT)
+  const int KT = ksp ? (khalf ? KT_all - KT_all / 2 : KT_all / 2) : KT_all;
   const int a_row_step = (MODE == 0 ? P.GW : -P.GW) * P.a_pix_stride, a_col_step = (MODE == 0 ? 1 : -1) * P.a_pix_stride;
 
 #define PP_CURSOR_T PPCursor
-#define PP_CURSOR_ZERO(c_) { (c_).tap = 0; (c_).cb = 0; (c_).r = 0; (c_).s = 0; }
+#define PP_CURSOR_ZERO(c_) { (c_).tap = kt_first / kcb; (c_).cb = kt_first % kcb; (c_).r = (c_).tap / n_s; (c_).s = (c_).tap % n_s; }
 #define PP_NEXT(c_) { if (++(c_).cb == kcb) { (c_).cb = 0; ++(c_).tap; if (++(c_).s == n_s) { (c_).s = 0; ++(c_).r; } } }
+// (-DRIGL_ABLATE_A3: timing experiment only -- the A pieces of the second and third tap of a filter row are not fetched)
+#ifdef RIGL_ABLATE_A3
+#define PP_ABLATE_SKIP(c_) if ((c_).s == 0)
+#else
+#define PP_ABLATE_SKIP(c_)
+#endif
 #define PP_ISSUE_A(h_, stage_, c_)                                                                       \
-  {                                                                                                      \
+  PP_ABLATE_SKIP(c_) {                                                                                   \
     const int da_ = (c_).r * a_row_step + (c_).s * a_col_step + ((c_).cb << 6);                          \
     _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                     \
       const bool ok_ = ((a_mask[h_][j] >> (c_).tap) & 1u) != 0u;                                         \
@@ -253,6 +265,45 @@ __device__ __forceinline__ void pp_igemm_body(const IgemmArgs& P, unsigned char*
 #undef PP_NEXT
 #undef PP_CURSOR_T
 #undef PP_CURSOR_ZERO
+
+  // ---- K split: hand-off of the partial tile (cdna_hip_programming.md, split-K hand-off in its counter form) --------------
+  if constexpr (MODE == 0 && !CLS) {
+    if (ksp) {
+      constexpr int SLAB = BM * BN;                                     // floats per partial tile
+      const __amdgpu_buffer_rsrc_t rs_my = make_rsrc(P.KS_SLAB + ((int64_t)tile * 2 + khalf) * SLAB, SLAB * 4);
+      const __amdgpu_buffer_rsrc_t rs_other = make_rsrc(P.KS_SLAB + ((int64_t)tile * 2 + (khalf ^ 1)) * SLAB, SLAB * 4);
+      // thread-major image: store g of a thread = 16 bytes at (g * 512 + tid) * 16 -- whole 8 KB rows per instruction;
+      // write-through (sc1) stores, read back by the partner with sc1 loads wherever it runs
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x16& a = acc[i][j];
+            const u32x4 v = {__float_as_uint(a[4 * q]), __float_as_uint(a[4 * q + 1]), __float_as_uint(a[4 * q + 2]), __float_as_uint(a[4 * q + 3])};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_my, ((((i * TN + j) * 4 + q) * 512) + tid) * 16, 0, 16);
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      volatile uint32_t* const flag = reinterpret_cast<volatile uint32_t*>(smem);
+      if (tid == 0) *flag = __hip_atomic_fetch_add(P.KS_CNT + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const uint32_t ticket = *flag;
+      __syncthreads();                                                   // (the flag's word is the first wave's staging area)
+      if (ticket == 0u) return;                                          // first to arrive: the partner finishes the tile
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_other, ((((i * TN + j) * 4 + q) * 512) + tid) * 16, 0, 16);
+            acc[i][j][4 * q] += __uint_as_float(v.x); acc[i][j][4 * q + 1] += __uint_as_float(v.y);
+            acc[i][j][4 * q + 2] += __uint_as_float(v.z); acc[i][j][4 * q + 3] += __uint_as_float(v.w);
+          }
+    }
+  }
 
   // ---- epilogue ------------------------------------------------------------------------------------------------------
   // Every wave stages its own tile (half of its rows at a time) in a private LDS area and stores full 128-byte row
@@ -717,12 +768,24 @@ static PPPlan plan_pp(const IgemmArgs& a) {
   return p;
 }
 
+// Forward layers whose tiles would occupy at most half of the CUs (the 7x7 layers at batch 128: 98 tiles) split the
+// reduction in two ("pp_ksplit" = 0: never).  Measured at batch 128 (forward alone, us): 7x7x512 3x3 52.4 -> 43.5 (565 -> 681
+// TFLOP/s), its stride-2 sibling 50.9 -> 42.9, 2048->512 1x1 (32 K-tiles) 26.9 -> 28.5 -- the 256 KB hand-off per tile
+// (write-through stores, drained before the ticket; the partner's read) costs ~8 us, so only reductions of >= 48 K-tiles
+// split.  Forward only: a layer's dX must have the same bits from the stand-alone dgrad and from the shared backward
+// launch, which does not split (its weight-gradient workgroups already fill the chip).
+static inline bool pp_ksplit_ok(const IgemmArgs& a, const PPPlan& p) {
+  if (!p.variant || tune_get("pp_ksplit", 1) == 0) return false;
+  const int kt = a.KH * a.KW * (a.Cred / 64);
+  return 2 * (int64_t)p.grid <= (int64_t)num_cus() && kt >= 48;
+}
+
 template <int MODE>
 static bool launch_pp(const PPPlan& p, const IgemmArgs& a0, hipStream_t st) {
   IgemmArgs a = a0;
   a.fd_rw = make_fastdiv(a.RW); a.fd_rh = make_fastdiv(a.RH);
   a.tiles_n = a.N / p.bn;
-  const dim3 grid(p.grid);
+  const dim3 grid(MODE == 0 && a.ksplit == 2 ? 2 * p.grid : p.grid);
   // phases per K-tile: the 128x64 wave tiles run 2 (16 MFMAs between barriers; "pp_ph" = 4 selects one quadrant per
   // phase), the 64x64 wave tiles 1 with three stages ("pp_ph" = 4 selects the four-phase, two-stage form)
   const int ph = tune_get("pp_ph", 0);

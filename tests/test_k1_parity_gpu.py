@@ -34,6 +34,7 @@ PP_SETTINGS = [
     {'RIGL_PP_FWD': '4', 'RIGL_PP_DGRAD': '4'},                                  # 512x128
     {'RIGL_PP_FWD': '1', 'RIGL_PP_DGRAD': '2', 'RIGL_PP_PH': '4'},               # the four-phase schedule of both wave tiles
     {'RIGL_PP_FWD': '0', 'RIGL_PP_DGRAD': '0'},                                  # the igemm body everywhere
+    {'RIGL_PP_KSPLIT': '0'},                                                     # no K split of the few-tile forwards (on by default)
 ]
 
 
