@@ -591,6 +591,8 @@ int rigl_probe_mfma_bf16(int32_t blocks, int32_t iters, float* sink, rigl_stream
  *   "pp_slab_mb"            cap on a layer's split-K slab bytes (40);
  *   "pp_bwd_min_kt"         shortest dgrad reduction (K-tiles of 64) the
  *                           pp_bwd rule takes (16);
+ *   "wgrad_il"              0: the splits of a weight gradient take contiguous
+ *                           pixel ranges instead of interleaved K-tiles (1);
  *   "pp_ksplit"             0: no two-way K split of the few-tile forwards
  *                           (7x7 3x3 layers at batch 128) (1);
  *   "bn_nt"                 non-temporal accesses of the batch-norm apply

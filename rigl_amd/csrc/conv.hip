@@ -764,6 +764,7 @@ struct WgradArgs {
   int fold;            // > 0 (k_wgrad_tr only): the KH taps are folded into the channel axis, `fold` channels per
                        // tap -- channel c of the GEMM is tap c / fold, input channel c % fold (KW == 1, Cin = taps*fold)
   FastDiv fd_wo, fd_ho;   // (ping-pong body only) launch-time divisors of the output-pixel decomposition
+  int interleave;         // splits take interleaved K-tiles (knob "wgrad_il"; k_wgrad_tr: the 1x1 layers only)
 };
 
 template <int TM, int TN>
@@ -954,10 +955,15 @@ __device__ __forceinline__ void wgrad_tr_body(const WgradArgs& P, unsigned char*
   const int r = tap / P.KW, s = tap % P.KW;
   const int ci0 = tci * BM, co0 = tco * BN;
   const int KT_all = (P.M + BK - 1) / BK;
-  const int kt_begin = (int)((int64_t)KT_all * split / P.splits);
-  const int kt_end = (int)((int64_t)KT_all * (split + 1) / P.splits);
-  const int KT = kt_end - kt_begin;
   const bool direct = !P.fold && P.KH == 1 && P.KW == 1 && P.sh == 1 && P.sw == 1 && P.ph == 0 && P.pw == 0;
+  // the 1x1 layers ("wgrad_il"): a split takes every splits-th K-tile, so that the splits of a tile stream one window
+  // of X and dY together instead of `splits` streams far apart; other layers keep contiguous pixel ranges (their
+  // lane-local pixel decomposition advances incrementally)
+  const bool il = P.interleave != 0 && direct && P.splits > 1;
+  const int kt_begin = il ? split : (int)((int64_t)KT_all * split / P.splits);
+  const int KT = il ? (split < KT_all ? (KT_all - split + P.splits - 1) / P.splits : 0)
+                    : (int)((int64_t)KT_all * (split + 1) / P.splits) - kt_begin;
+  const int m_step = il ? BK * P.splits : BK;
   const bool fast_inc = (BK / P.Wo + 1) <= P.Ho;
   const int inc_w = BK % P.Wo, inc_h = BK / P.Wo;
   const int hi0 = r - P.ph, wi0 = s - P.pw;
@@ -1004,7 +1010,7 @@ __device__ __forceinline__ void wgrad_tr_body(const WgradArgs& P, unsigned char*
       const int boff = ok ? (int)((uint32_t)off * 2u) : (int)OOB;                                     \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                       \
           rsrcX, (__attribute__((address_space(3))) void*)(As_ + (q * THREADS + wave_u * 64) * 16), 16, boff, 0, 0, 0); \
-      a_m[q] += BK;                                                                                   \
+      a_m[q] += m_step;                                                                                \
       if (!direct) {                                                                                  \
         if (fast_inc) {                                                                               \
           a_wo[q] += inc_w; if (a_wo[q] >= P.Wo) { a_wo[q] -= P.Wo; ++a_ho[q]; }                      \
@@ -1020,7 +1026,7 @@ __device__ __forceinline__ void wgrad_tr_body(const WgradArgs& P, unsigned char*
       const int boff = okb ? (int)((uint32_t)(b_m[q] * P.Cout + b_ch[q]) * 2u) : (int)OOB;            \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                       \
           rsrcY, (__attribute__((address_space(3))) void*)(Bs_ + (q * THREADS + wave_u * 64) * 16), 16, boff, 0, 0, 0); \
-      b_m[q] += BK;                                                                                   \
+      b_m[q] += m_step;                                                                                \
     }                                                                                                 \
   }
 
@@ -1861,6 +1867,7 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
     }
   }
   WgradArgs a = {};
+  a.interleave = tune_get("wgrad_il", 1);
   a.DY = dy; a.M = d->n * d->ho * d->wo; a.Cout = d->cout;
   a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
   int64_t n_out;
@@ -2061,6 +2068,7 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
     if (rc) return rc;
     const IgemmPlan pd = plan_igemm<1>(ad);
     WgradArgs aw = {};
+    aw.interleave = tune_get("wgrad_il", 1);
     aw.DY = dy; aw.M = d->n * d->ho * d->wo; aw.Cout = d->cout;
     aw.dy_bytes = (uint32_t)((size_t)aw.M * d->cout * 2);
     aw.X = x; aw.Cin = d->cin; aw.x_pix_stride = d->cin; aw.KH = d->kh; aw.KW = d->kw; aw.H = d->h; aw.W = d->w;

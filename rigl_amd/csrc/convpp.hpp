@@ -444,8 +444,13 @@ __device__ __forceinline__ void pp_wgrad_body(const WgradArgs& P, unsigned char*
   const int r = tap / P.KW, s = tap - r * P.KW;
   const int ci0 = tci * 256, co0 = tco * 256;
   const int KT_all = (P.M + 63) >> 6;
-  const int kt_begin = (int)((int64_t)KT_all * split / P.splits);
-  const int KT = (int)((int64_t)KT_all * (split + 1) / P.splits) - kt_begin;
+  // a split takes every splits-th K-tile ("wgrad_il", default) or a contiguous range: interleaved, the splits of a tile
+  // stream ONE window of the tensors together instead of `splits` streams far apart (bwd1x1.hpp measured the same)
+  const bool il = P.interleave != 0 && P.splits > 1;
+  const int kt_begin = il ? split : (int)((int64_t)KT_all * split / P.splits);
+  const int kt_step = il ? P.splits : 1;
+  const int KT = il ? (split < KT_all ? (KT_all - split + P.splits - 1) / P.splits : 0)
+                    : (int)((int64_t)KT_all * (split + 1) / P.splits) - kt_begin;
 
   // DMA lanes: instruction jj of wave w fills pixel rows 4 * (jj*8 + w) .. +3 of a piece; lane l: pixel +(l >> 4), 16-byte
   // slot l & 15, fetching channel chunk slot ^ ((pixel & 3) << 2)
@@ -464,7 +469,7 @@ __device__ __forceinline__ void pp_wgrad_body(const WgradArgs& P, unsigned char*
 #define PP_WCOMPUTE(c_)                                                                                  \
   {                                                                                                      \
     _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                   \
-      const int p_ = ((kt_begin + (c_).kt) << 6) + 32 * jj + px_lane;                                    \
+      const int p_ = ((kt_begin + (c_).kt * kt_step) << 6) + 32 * jj + px_lane;                          \
       const bool ok_ = p_ < P.M;                                                                         \
       const int pp_ = ok_ ? p_ : 0;                                                                      \
       const int t_ = fdiv(pp_, P.fd_wo);                                                                 \
@@ -874,6 +879,7 @@ static PPBwdPlan plan_wgrad_pp(const RiglConvDesc* d, unsigned nd, int kt_d) {
 static WgradArgs pp_wgrad_args(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const PPBwdPlan& p, float* dw,
                                void* workspace) {
   WgradArgs a = {};
+  a.interleave = tune_get("wgrad_il", 1);
   a.X = x; a.DY = dy; a.M = d->n * d->ho * d->wo; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw;
   a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
   a.tiles_ci = p.tiles_ci; a.tiles_co = p.tiles_co; a.splits = p.splits; a.slab_elems = p.slab;
