@@ -52,6 +52,7 @@ __device__ __forceinline__ uint4 ld16(const uint16_t* p, int nt) {
 
 struct Geom {
   int nt;             // non-temporal mode of the apply passes
+  int il;             // reductions: parts interleave groups of rows
   int64_t M;
   int C, cg;          // channels, 8-channel groups
   int tpr, rpb;       // threads per row (pow2 >= min(cg,256)), rows per pass
@@ -88,8 +89,12 @@ __global__ __launch_bounds__(THREADS) void k_reduce(Geom G, const uint16_t* __re
     }
   }
   if (c_ok) {
+    // a part = every parts-th group of rpb rows ("bn_il", default: the grid streams one window of the tensors) or a
+    // contiguous range of rows
+    const int64_t rb = G.il ? (int64_t)blockIdx.x * G.rpb + ty : r0 + ty, re = G.il ? G.M : r1;
+    const int64_t rstep = G.il ? (int64_t)G.parts * G.rpb : (int64_t)G.rpb;
 #pragma unroll 2
-    for (int64_t r = r0 + ty; r < r1; r += G.rpb) {
+    for (int64_t r = rb; r < re; r += rstep) {
       const int64_t off = r * G.C + (int64_t)cgi * 8;
       float xv[8];
       unpack8(*reinterpret_cast<const uint4*>(x + off), xv);
@@ -384,8 +389,10 @@ __global__ __launch_bounds__(THREADS) void k_reduce_pair(Geom G, const uint16_t*
     for (int j = 0; j < 8; ++j) {
       mu[j] = mean[cgi * 8 + j]; is[j] = invstd[cgi * 8 + j]; mu2[j] = mean2[cgi * 8 + j]; is2[j] = invstd2[cgi * 8 + j];
     }
+    const int64_t rb = G.il ? (int64_t)blockIdx.x * G.rpb + ty : r0 + ty, re = G.il ? G.M : r1;
+    const int64_t rstep = G.il ? (int64_t)G.parts * G.rpb : (int64_t)G.rpb;
 #pragma unroll 2
-    for (int64_t r = r0 + ty; r < r1; r += G.rpb) {
+    for (int64_t r = rb; r < re; r += rstep) {
       const int64_t off = r * G.C + (int64_t)cgi * 8;
       float xv[8], x2v[8], dv[8];
       unpack8(*reinterpret_cast<const uint4*>(x + off), xv);
@@ -482,6 +489,7 @@ static Geom make_geom(int64_t m, int c) {
   Geom g;
   // measured in the ResNet-50 step (round 3): 0 -> 2 = -0.06 .. -0.10 ms, the convs gain too (less of their L2 evicted)
   g.nt = (int64_t)m * c * 2 >= (int64_t)tune_get("bn_nt_mb", 0) * (1 << 20) ? tune_get("bn_nt", 2) : 0;
+  g.il = tune_get("bn_il", 1);
   g.M = m; g.C = c; g.cg = c / 8;
   int tpr = 1;
   while (tpr < g.cg && tpr < THREADS) tpr <<= 1;
