@@ -595,6 +595,8 @@ int rigl_probe_mfma_bf16(int32_t blocks, int32_t iters, float* sink, rigl_stream
  *                           pixel ranges instead of interleaved K-tiles (1);
  *   "pp_ksplit"             0: no two-way K split of the few-tile forwards
  *                           (7x7 3x3 layers at batch 128) (1);
+ *   "bn_il"                 0: a batch-norm reduction part is a contiguous range
+ *                           of rows instead of every parts-th group (1);
  *   "bn_nt"                 non-temporal accesses of the batch-norm apply
  *                           passes: 0 none, 1 stores, 2 loads and stores (2;
  *                           -0.10 ms per ResNet-50 step); "bn_nt_mb" applies it
