@@ -55,7 +55,10 @@ def test_pingpong_edge_shapes(env):
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
-@pytest.mark.parametrize('env', PP_SETTINGS[:3] + PP_SETTINGS[4:5])
+@pytest.mark.parametrize('env', PP_SETTINGS[:3] + PP_SETTINGS[4:5] + [
+    {'RIGL_BWD1X1_256X64': '1', 'RIGL_BWD1X1_WGS': '1'},     # single-pass 1x1 backward: the third shape class, the 7-deep ring
+    {'RIGL_BWD1X1': '0', 'RIGL_STEM_DIRECT': '0', 'RIGL_WGRAD_IL': '0'},   # round-2 paths of those layers
+])
 def test_resnet50_layer_shapes_at_batch_128(env):
   """All distinct ResNet-50 conv shapes at the benchmarked per-GPU batch: fwd, fwd + statistics,
   dgrad, dgrad + addend, wgrad and the one-call backward, under the default kernel selection (the ping-pong body on the
