@@ -240,7 +240,7 @@ def main():
   if int(gs.value) < UPDATE_PERIOD - 1:
     gs.value = UPDATE_PERIOD - 1
   if graphed is not None:                   # capture now (its own warm-up + capture step), then re-position the schedule
-    for _ in range(6):
+    for _ in range(10):
       graphed()
       if graphed.replays:
         break

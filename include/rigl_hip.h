@@ -288,29 +288,7 @@ int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x,
                            rigl_bf16* dx /* nullable */, void* workspace,
                            size_t workspace_bytes, rigl_stream_t stream);
 
-/* The same with the split-K reduce of dW handed from one layer's backward to the
- * next launch: `defer` (nullable) receives this layer's pending reduce instead of
- * running it (splits == 0: nothing pending, dW is complete); `flush` (nullable)
- * is the pending reduce of the layer before, executed by a third segment of
- * workgroups inside this layer's launch (or by a kernel of its own on the
- * fallback paths).  The caller keeps the pending layer's workspace alive and
- * passes a DIFFERENT workspace here; the last pending reduce of a backward pass
- * is run by rigl_wgrad_reduce_pending.  Same bits as rigl_masked_conv2d_bwd.     */
-typedef struct RiglPendingReduce {
-  const float* slabs;   /* [splits][slab_elems] partial sums                   */
-  float* dw;            /* destination, n_out elements                          */
-  int64_t n_out, slab_elems;
-  int32_t splits;       /* 0 = nothing pending                                  */
-} RiglPendingReduce;
-int rigl_masked_conv2d_bwd_deferred(const RiglConvDesc* d, const rigl_bf16* x,
-                                    const rigl_bf16* dy, const rigl_bf16* w_hwio,
-                                    const rigl_bf16* addend, float* dw, rigl_bf16* dx,
-                                    void* workspace, size_t workspace_bytes,
-                                    const RiglPendingReduce* flush,
-                                    RiglPendingReduce* defer, rigl_stream_t stream);
-int rigl_wgrad_reduce_pending(const RiglPendingReduce* pending, rigl_stream_t stream);
-
-/* rigl_masked_conv2d_bwd_deferred with the BATCH-NORM BACKWARD REDUCTIONS of the
+/* rigl_masked_conv2d_bwd with the BATCH-NORM BACKWARD REDUCTIONS of the
  * tensor dX is the gradient of riding in the dgrad epilogue.  In the reference every
  * conv input is y = relu?(batch_norm(x_bn) [+ shortcut]) (resnet_model.py:41-82,
  * 456-501), and autodiff's batch-norm gradient starts with two per-channel sums
@@ -338,7 +316,6 @@ int rigl_masked_conv2d_bwd_bn(const RiglConvDesc* d, const rigl_bf16* x,
                               const rigl_bf16* dy, const rigl_bf16* w_hwio,
                               const rigl_bf16* addend, float* dw, rigl_bf16* dx,
                               void* workspace, size_t workspace_bytes,
-                              const RiglPendingReduce* flush, RiglPendingReduce* defer,
                               const RiglBnReduceFuse* bn /* nullable */,
                               rigl_stream_t stream);
 
@@ -587,7 +564,6 @@ int rigl_probe_mfma_bf16(int32_t blocks, int32_t iters, float* sink, rigl_stream
  *                           rule, 0 never, 1 / 2 dgrad on 256x256 / 128x256;
  *   "pp_wgrad"              1: stand-alone weight gradient on the ping-pong
  *                           body wherever legal (rule: off);
- *   "pp_ph"                 4: one quadrant per phase (default 2 / 1 phases);
  *   "pp_slab_mb"            cap on a layer's split-K slab bytes (40);
  *   "pp_bwd_min_kt"         shortest dgrad reduction (K-tiles of 64) the
  *                           pp_bwd rule takes (16);
@@ -607,16 +583,19 @@ int rigl_probe_mfma_bf16(int32_t blocks, int32_t iters, float* sink, rigl_stream
  *                           LDS-resident-patch kernels (1);
  *   "bwd1x1"                0: the single-pass backward of the 56x56-class 1x1
  *                           layers (64->256, 64->64; dY read once) off (1);
- *   "bwd1x1_256x64"         1: also for 256->64 (measured level: 0);
- *   "bwd1x1_wgs"            workgroups per CU of that kernel, 2 (3-deep ring
- *                           each) or 1 (7-deep ring); "bwd1x1_il" 0: contiguous
- *                           pixel ranges per workgroup instead of interleaved
- *                           K-tiles; "bn_fin1" 0: the one-level forward
- *                           batch-norm finalize for every size.
+ *   "bwd1x1_il"             0: contiguous pixel ranges per workgroup instead of
+ *                           interleaved K-tiles (1); "bn_fin1" 0: the one-level
+ *                           forward batch-norm finalize for every size (1).
+ * Knobs whose A/B measurements said "no" in rounds 2-3 are gone with their
+ * kernels (k1_nt_mb, pp_ph, bwd1x1_wgs, bwd1x1_256x64, stem_nt, RIGL_WGRAD_DEFER,
+ * RIGL_WGRAD_STREAM, RIGL_CONV_STAGES, RIGL_CONV_W4_KT, RIGL_WGRAD_TR).
  * No reference counterpart (the reference selects cuDNN/TPU algorithms inside
  * TensorFlow: rigl/imagenet_resnet/pruning_layers.py:139-157).              */
 int rigl_tune_set(const char* key, int32_t value);
 int32_t rigl_tune_get(const char* key, int32_t dflt);
+/* Back to "never set" (the RIGL_<KEY> environment variable, else the built-in
+ * default); rigl_tune_set(key, INT32_MIN) is the same call.                  */
+int rigl_tune_unset(const char* key);
 
 #ifdef __cplusplus
 }

@@ -73,13 +73,6 @@ class RandomItem(C.Structure):
               ('dist', C.c_int32), ('scale', C.c_float), ('shift', C.c_float)]
 
 
-class PendingReduce(C.Structure):
-  """RiglPendingReduce: a layer's split-K reduce handed to the next backward launch."""
-  _fields_ = [('slabs', C.c_void_p), ('dw', C.c_void_p), ('n_out', C.c_int64),
-              ('slab_elems', C.c_int64), ('splits', C.c_int32)]
-
-
-
 # name -> (restype, argtypes); every symbol declared in include/rigl_hip.h
 _P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -110,12 +103,9 @@ SIGNATURES = {
                                                _SZ, _P, _SZ, _P]),
     'rigl_masked_conv2d_dgrad_acc': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P,
                                                _P, _P, _SZ, _P]),
-    'rigl_masked_conv2d_bwd_deferred': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ,
-                                                  C.POINTER(PendingReduce), C.POINTER(PendingReduce), _P]),
-    'rigl_wgrad_reduce_pending': (C.c_int, [C.POINTER(PendingReduce), _P]),
     'rigl_conv2d_dgrad_stats_parts': (_I32, [C.POINTER(ConvDesc)]),
     'rigl_masked_conv2d_bwd_bn': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ,
-                                            C.POINTER(PendingReduce), C.POINTER(PendingReduce), C.POINTER(BnReduceFuse), _P]),
+                                            C.POINTER(BnReduceFuse), _P]),
     'rigl_masked_conv2d_bwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'rigl_masked_conv2d_wgrad': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P,
                                            _SZ, _P]),
@@ -153,6 +143,7 @@ SIGNATURES = {
     'rigl_probe_mfma_bf16': (C.c_int, [_I32, _I32, _P, _P]),
     'rigl_tune_set': (C.c_int, [C.c_char_p, _I32]),
     'rigl_tune_get': (_I32, [C.c_char_p, _I32]),
+    'rigl_tune_unset': (C.c_int, [C.c_char_p]),
 }
 
 _lib = None

@@ -488,8 +488,8 @@ __global__ __launch_bounds__(THREADS) void k_bwd_apply_pair(Geom G, const uint16
 static Geom make_geom(int64_t m, int c) {
   Geom g;
   // measured in the ResNet-50 step (round 3): 0 -> 2 = -0.06 .. -0.10 ms, the convs gain too (less of their L2 evicted)
-  g.nt = (int64_t)m * c * 2 >= (int64_t)tune_get("bn_nt_mb", 0) * (1 << 20) ? tune_get("bn_nt", 2) : 0;
-  g.il = tune_get("bn_il", 1);
+  g.nt = (int64_t)m * c * 2 >= (int64_t)RIGL_TUNE("bn_nt_mb", 0) * (1 << 20) ? RIGL_TUNE("bn_nt", 2) : 0;
+  g.il = RIGL_TUNE("bn_il", 1);
   g.M = m; g.C = c; g.cg = c / 8;
   int tpr = 1;
   while (tpr < g.cg && tpr < THREADS) tpr <<= 1;
@@ -555,7 +555,7 @@ static int fwd_statistics(Geom& g, int32_t c, const rigl_bf16* x, const float* g
   // parts > 1024 (the 56x56 layers: 3136 conv-epilogue partials per channel, 64-256 channels): one workgroup per channel --
   // with 4 channels per workgroup a 64-channel layer is 16 workgroups each walking 49 rows per lane in dependent batches
   // (11.8 us on average over the step's 25 such finalizes; round 3)
-  if (g.parts > 1024 && tune_get("bn_fin1", 1) != 0)
+  if (g.parts > 1024 && RIGL_TUNE("bn_fin1", 1) != 0)
     hipLaunchKernelGGL(k_fwd_finalize<1>, dim3((unsigned)c), dim3(THREADS), 0, st, g, partial, gamma,
                        beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale, save_shift);
   else if (g.parts > 256)

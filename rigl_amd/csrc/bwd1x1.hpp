@@ -28,7 +28,7 @@ struct Bwd1x1Args {
   const uint16_t* ADD;  // [M][CI] bf16 or NULL: added to dX (bf16(bf16(dgrad) + addend), like the dgrad epilogue)
   uint16_t* DX;         // [M][CI] bf16
   float* SLAB;          // [splits][CI][CO] fp32 partial dW (NULL with DO_W = false)
-  int M, splits, interleave, nt;   // nt: operand tiles fetched with the non-temporal hint (knob "bwd1x1_nt")
+  int M, splits, interleave;
   uint32_t x_bytes, dy_bytes;
 };
 
@@ -103,18 +103,14 @@ __global__ __launch_bounds__(THREADS) void k_bwd1x1(Bwd1x1Args P) {
     _Pragma("unroll") for (int q = 0; q < YPW; ++q) {                                                    \
       const int p_ = p0_ + y_row[q];                                                                     \
       const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * CO + y_col[q]) * 2u) : (int)OOB;                 \
-      if (P.nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(                                               \
-          rsrcY, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + (q * 4 + wave) * 1024), 16, off_, 0, 0, 2); \
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                          \
           rsrcY, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + (q * 4 + wave) * 1024), 16, off_, 0, 0, 0); \
     }                                                                                                    \
     if (DO_W) {                                                                                          \
       _Pragma("unroll") for (int q = 0; q < XPW; ++q) {                                                  \
         const int p_ = p0_ + x_row[q];                                                                   \
         const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * CI + x_col[q]) * 2u) : (int)OOB;               \
-        if (P.nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
-            rsrcX, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + Y_BYTES + (q * 4 + wave) * 1024), 16, off_, 0, 0, 2); \
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                   \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
             rsrcX, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + Y_BYTES + (q * 4 + wave) * 1024), 16, off_, 0, 0, 0); \
       }                                                                                                  \
     }                                                                                                    \
@@ -284,46 +280,55 @@ __global__ __launch_bounds__(THREADS) void k_bwd1x1(Bwd1x1Args P) {
 static inline int bwd1x1_kind(const RiglConvDesc* d) {
   if (d->kh != 1 || d->kw != 1 || d->stride_h != 1 || d->stride_w != 1 || d->pad_top || d->pad_left) return 0;
   if ((int64_t)d->n * d->h * d->w < 65536) return 0;
-  if (tune_get("bwd1x1", 1) == 0) return 0;
+  if (RIGL_TUNE("bwd1x1", 1) == 0) return 0;
   if (d->cin == 64 && d->cout == 256) return 1;
-  // 256 -> 64 measured level with the fused igemm launch (109 vs 110 us at batch 128): off unless asked for
-  if (d->cin == 256 && d->cout == 64) return tune_get("bwd1x1_256x64", 0) ? 2 : 0;
+  // (256 -> 64 measured level with the fused igemm launch, 109 vs 110 us at batch 128: not instantiated)
   if (d->cin == 64 && d->cout == 64) return 3;
   return 0;
 }
-// one round of workgroups: "bwd1x1_wgs" per CU (2: a 3-deep ring each; 1: half the slabs and a 7-deep ring)
-static inline int bwd1x1_wgs_per_cu() { const int v = tune_get("bwd1x1_wgs", 2); return v == 1 ? 1 : 2; }
-static inline int bwd1x1_splits() { return bwd1x1_wgs_per_cu() * num_cus(); }
+// one round of workgroups: two per CU, a 3-deep ring each (one per CU with a 7-deep ring measured slower: 12.40 vs 12.37 ms per step)
+static inline int bwd1x1_splits() { return 2 * num_cus(); }
 static inline size_t bwd1x1_workspace(const RiglConvDesc* d) {
   return bwd1x1_kind(d) ? (size_t)2 * num_cus() * d->cin * d->cout * 4 : 0;
 }
 template <int CI, int CO, bool DO_W, int NST>
-static bool launch_bwd1x1_i(const Bwd1x1Args& a, hipStream_t st) {
+static bool bwd1x1_ready_i() {
   constexpr int SMEM = Bwd1x1Smem<CI, CO, DO_W, NST>::BYTES;
-  static_assert(SMEM <= 160 * 1024 / (NST == 3 ? 2 : 1), "the ring of the workgroups resident on a CU fits its LDS");
+  static_assert(SMEM <= 160 * 1024 / 2, "the rings of the two workgroups resident on a CU fit its LDS");
   static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd1x1<CI, CO, DO_W, NST>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess;
-  if (!ready) return false;
+  return ready;
+}
+// Will the single-pass kernel (with its weight-gradient half) launch for this layer?  Asked BEFORE a caller commits to its
+// path (workspace layout, reduce), so a refused dynamic-LDS opt-in falls through to the generic bodies cleanly.
+static bool bwd1x1_ready(const RiglConvDesc* d) {
+  switch (bwd1x1_kind(d)) {
+    case 1: return bwd1x1_ready_i<64, 256, true, 3>();
+    case 3: return bwd1x1_ready_i<64, 64, true, 3>();
+    default: return false;
+  }
+}
+template <int CI, int CO, bool DO_W, int NST>
+static bool launch_bwd1x1_i(const Bwd1x1Args& a, hipStream_t st) {
+  constexpr int SMEM = Bwd1x1Smem<CI, CO, DO_W, NST>::BYTES;
+  if (!bwd1x1_ready_i<CI, CO, DO_W, NST>()) return false;
   RIGL_K_LAUNCH((k_bwd1x1<CI, CO, DO_W, NST>), dim3((unsigned)a.splits), dim3(THREADS), SMEM, st, a);
   return true;
 }
 template <int CI, int CO>
-static bool launch_bwd1x1_t(const Bwd1x1Args& a, bool w, bool deep, hipStream_t st) {
-  constexpr int DEEP = 7;                                    // ring depth of the one-workgroup-per-CU variant
-  if (w) return deep ? launch_bwd1x1_i<CI, CO, true, DEEP>(a, st) : launch_bwd1x1_i<CI, CO, true, 3>(a, st);
-  return deep ? launch_bwd1x1_i<CI, CO, false, DEEP>(a, st) : launch_bwd1x1_i<CI, CO, false, 3>(a, st);
+static bool launch_bwd1x1_t(const Bwd1x1Args& a, bool w, hipStream_t st) {
+  return w ? launch_bwd1x1_i<CI, CO, true, 3>(a, st) : launch_bwd1x1_i<CI, CO, false, 3>(a, st);
 }
 static bool launch_bwd1x1(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
                           const rigl_bf16* addend, rigl_bf16* dx, float* slab, hipStream_t st) {
   Bwd1x1Args a = {};
   a.X = x; a.DY = dy; a.W = w_hwio; a.ADD = addend; a.DX = dx; a.SLAB = slab;
-  a.M = d->n * d->h * d->w; a.splits = bwd1x1_splits(); a.interleave = tune_get("bwd1x1_il", 1); a.nt = tune_get("bwd1x1_nt", 0);
+  a.M = d->n * d->h * d->w; a.splits = bwd1x1_splits(); a.interleave = RIGL_TUNE("bwd1x1_il", 1);
   a.x_bytes = (uint32_t)((size_t)a.M * d->cin * 2); a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
-  const bool w = slab != nullptr, deep = bwd1x1_wgs_per_cu() == 1;
+  const bool w = slab != nullptr;
   switch (bwd1x1_kind(d)) {
-    case 1: return launch_bwd1x1_t<64, 256>(a, w, deep, st);
-    case 2: return launch_bwd1x1_t<256, 64>(a, w, deep, st);
-    case 3: return launch_bwd1x1_t<64, 64>(a, w, deep, st);
+    case 1: return launch_bwd1x1_t<64, 256>(a, w, st);
+    case 3: return launch_bwd1x1_t<64, 64>(a, w, st);
     default: return false;
   }
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdarg.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -16,6 +17,12 @@ int fail(int code, const char* fmt, ...);
 // Process-wide development knobs (rigl_tune_set): the run-time twin of the RIGL_* environment variables, for
 // A/B runs inside one process.  Unknown keys read as the caller's default.
 int tune_get(const char* key, int dflt);
+// Per-call-site cache of a knob: valid until the next rigl_tune_set / rigl_tune_unset (a generation counter), so the
+// launch paths read their knobs with two atomic loads instead of a mutex and a string scan.  Use through RIGL_TUNE.
+struct TuneSite { std::atomic<uint64_t> gen{0}; std::atomic<int> value{0}; };
+uint64_t tune_generation();
+int tune_cached(TuneSite& site, const char* key, int dflt);
+#define RIGL_TUNE(key, dflt) ([]() -> int { static ::rigl::TuneSite site__; return ::rigl::tune_cached(site__, key, dflt); }())
 
 inline hipStream_t as_stream(rigl_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -56,15 +56,7 @@ __device__ __forceinline__ uint32_t add_bf16x2(uint32_t a, uint32_t b) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
-typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store16(uint16_t* p, const uint4& v, int nt) {
-  if (nt) { const u32x4_nt t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<u32x4_nt*>(p)); }
-  else *reinterpret_cast<uint4*>(p) = v;
-}
-static inline int k1_nt(size_t out_bytes) {
-  const int mb = tune_get("k1_nt_mb", -1);
-  return mb >= 0 && out_bytes >= (size_t)mb * (1u << 20) ? 1 : 0;
-}
+__device__ __forceinline__ void store16(uint16_t* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
 
 // Byte offset of 16-byte chunk `chunk` of row `row` in a [rows][BK] bf16 tile.
 // The chunk index is XORed with a row-derived value so that the 16-lane groups
@@ -168,19 +160,18 @@ struct IgemmArgs {
   // is a workgroup; the first to finish leaves its fp32 partial tile in KS_SLAB[tile][half], the second adds it and
   // runs the epilogue (a + b = b + a: the same bits whichever arrives last).  KS_CNT[tile] = arrivals, zeroed per call.
   float* KS_SLAB; uint32_t* KS_CNT; int ksplit;
-  int nt_out;           // 1: output rows leave with non-temporal stores (knob "k1_nt_mb": outputs of at least that many MB)
   FastDiv fd_rw, fd_rh, fd_cwc[4], fd_chc[4];
 };
 
-// STAGES: 2 = register-staged double buffer; 3 / 4 = LDS-DMA ring of that depth; 22 = LDS-DMA ring of
-// depth 2 (32 KB: with the 128-VGPR cap of k_igemm_w4 that is 4 workgroups per CU, for short reductions).
+// STAGES: 2 = register-staged double buffer; 3 = LDS-DMA ring of that depth (a 4-deep ring and a 2-deep one under a
+// 128-VGPR cap were measured in rounds 1-2: 4-7 % slower over the layer set / neutral, and are gone).
 // LDS bytes of one igemm workgroup (the kernels own the array; igemm_body gets a pointer so that
 // a fused launch can run it next to another body in the same allocation).
 // WM = wave rows of the workgroup (2 x WM waves of TM x TN 32x32 tiles each): 2 -> 256 threads, BM = 64*TM;
 // 4 -> 512 threads, BM = 128*TM (the 256x128 tile: 24 KB of operands per K-tile for twice the MFMA work).
 template <int TM, int TN, int BK, int MODE, bool OUT_F32, bool CLS, int STAGES, int WM = 2>
 constexpr int igemm_smem_bytes() {
-  constexpr int NST = (STAGES == 22) ? 2 : STAGES;
+  constexpr int NST = STAGES;
   constexpr int NT = 128 * WM;
   constexpr int BM = 32 * WM * TM, BN = 64 * TN;
   constexpr int STAGE = (BM + BN) * BK * 2;
@@ -196,7 +187,7 @@ constexpr int igemm_smem_bytes() {
 
 template <int TM, int TN, int BK, int MODE /*0 fwd, 1 dgrad*/, bool OUT_F32, bool CLS, int STAGES, int WM = 2>
 __device__ __forceinline__ void igemm_body(const IgemmArgs& P, unsigned char* smem, uint32_t bid, uint32_t nblk) {
-  constexpr int NST = (STAGES == 22) ? 2 : STAGES;
+  constexpr int NST = STAGES;
   constexpr int THREADS = 128 * WM;        // (shadows the file-wide 256 inside this body)
   constexpr int BM = 32 * WM * TM, BN = 64 * TN, CPR = BK / 8, RPP = THREADS / CPR;
   constexpr int APASS = (BM + RPP - 1) / RPP, BPASS = (BN + RPP - 1) / RPP;
@@ -634,7 +625,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P, unsigned char* sm
             const uint4 q = addv[it];
             v.x = add_bf16x2(v.x, q.x); v.y = add_bf16x2(v.y, q.y); v.z = add_bf16x2(v.z, q.z); v.w = add_bf16x2(v.w, q.w);
           }
-          store16(C + (int64_t)m * P.ldc + n, v, P.nt_out);
+          store16(C + (int64_t)m * P.ldc + n, v);
         }
       }
     } else {
@@ -738,14 +729,6 @@ __global__ __launch_bounds__(512) void k_igemm_big(IgemmArgs P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_big[];
   igemm_body<2, 2, 32, MODE, false, CLS, 3, 4>(P, smem_big, blockIdx.x, gridDim.x);
 }
-// Same body compiled for 4 waves per SIMD (<= 128 VGPRs): with the 2-deep ring's 35 KB of LDS that
-// is 4 workgroups per CU for the latency-bound short reductions.
-template <int TM, int TN, int BK, int MODE, bool OUT_F32, bool CLS, int STAGES>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_igemm_w4(IgemmArgs P) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[igemm_smem_bytes<TM, TN, BK, MODE, OUT_F32, CLS, STAGES>()];
-  igemm_body<TM, TN, BK, MODE, OUT_F32, CLS, STAGES>(P, smem, blockIdx.x, gridDim.x);
-}
-
 // ------------------------------------------------------------------ wgrad
 struct WgradArgs {
   const uint16_t* X;   // NHWC input activations
@@ -767,149 +750,9 @@ struct WgradArgs {
   int interleave;         // splits take interleaved K-tiles (knob "wgrad_il"; k_wgrad_tr: the 1x1 layers only)
 };
 
-template <int TM, int TN>
-__global__ __launch_bounds__(THREADS) void k_wgrad(WgradArgs P) {
-  constexpr int BK = 64;  // pixels per K-tile
-  constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_BLOCKS = (BM / 8) * 8, B_BLOCKS = (BN / 8) * 8;  // 8x8 transposition blocks
-  constexpr int NPASS = (A_BLOCKS + B_BLOCKS + THREADS - 1) / THREADS;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  // block -> (split, tap, tile_ci, tile_co); co fastest so neighbours share X
-  uint32_t b = xcd_remap(blockIdx.x, gridDim.x);
-  const int tco = b % P.tiles_co; b /= P.tiles_co;
-  const int tci = b % P.tiles_ci; b /= P.tiles_ci;
-  const int tap = b % (P.KH * P.KW);
-  const int split = b / (P.KH * P.KW);
-  const int r = tap / P.KW, s = tap % P.KW;
-  const int ci0 = tci * BM, co0 = tco * BN;
-  const int KT_all = (P.M + BK - 1) / BK;
-  const int kt_begin = (int)((int64_t)KT_all * split / P.splits);
-  const int kt_end = (int)((int64_t)KT_all * (split + 1) / P.splits);
-  const bool direct = P.KH == 1 && P.KW == 1 && P.sh == 1 && P.sw == 1 && P.ph == 0 && P.pw == 0;
-
-  uint4 rg[NPASS][8];
-  const __amdgpu_buffer_rsrc_t rsrcX = make_rsrc(P.X, P.x_bytes), rsrcY = make_rsrc(P.DY, P.dy_bytes);
-
-  // Each thread owns 8x8 blocks: 8 consecutive pixels x one 8-channel chunk.
-  // (macros rather than lambdas so that rg[][] stays in registers)
-#define RIGL_W_LOAD(kt_)                                                                              \
-  {                                                                                                   \
-    const int mbase = (kt_) * BK;                                                                     \
-    _Pragma("unroll") for (int q = 0; q < NPASS; ++q) {                                               \
-      const int blk = q * THREADS + tid;                                                              \
-      if (blk < A_BLOCKS) {                                                                           \
-        const int cc = blk % (BM / 8), pg = blk / (BM / 8);                                           \
-        const int ch = ci0 + cc * 8;                                                                  \
-        const bool c_ok = ch < P.Cin;                                                                 \
-        const int m = mbase + pg * 8;                                                                 \
-        if (direct) {                                                                                 \
-          _Pragma("unroll") for (int i = 0; i < 8; ++i)                                               \
-            rg[q][i] = buf_load16(rsrcX, (c_ok && m + i < P.M) ? (uint32_t)((m + i) * P.x_pix_stride + ch) * 2u : OOB); \
-        } else {                                                                                      \
-          int wo = m % P.Wo, t = m / P.Wo, ho = t % P.Ho, n = t / P.Ho;                               \
-          _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                             \
-            const int hi = ho * P.sh - P.ph + r, wi = wo * P.sw - P.pw + s;                           \
-            const bool ok = c_ok && (m + i) < P.M && (unsigned)hi < (unsigned)P.H && (unsigned)wi < (unsigned)P.W; \
-            rg[q][i] = buf_load16(rsrcX, ok ? (uint32_t)(((n * P.H + hi) * P.W + wi) * P.x_pix_stride + ch) * 2u : OOB); \
-            if (++wo == P.Wo) { wo = 0; if (++ho == P.Ho) { ho = 0; ++n; } }                          \
-          }                                                                                           \
-        }                                                                                             \
-      } else if (blk < A_BLOCKS + B_BLOCKS) {                                                         \
-        const int bb = blk - A_BLOCKS;                                                                \
-        const int cc = bb % (BN / 8), pg = bb / (BN / 8);                                             \
-        const int ch = co0 + cc * 8;                                                                  \
-        const bool c_ok = ch < P.Cout;                                                                \
-        const int m = mbase + pg * 8;                                                                 \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                 \
-          rg[q][i] = buf_load16(rsrcY, (c_ok && m + i < P.M) ? (uint32_t)((m + i) * P.Cout + ch) * 2u : OOB); \
-      }                                                                                               \
-    }                                                                                                 \
-  }
-  // 8x8 bf16 transpose in registers, then 8 x 16-byte LDS stores ([channel][pixel] tile).
-#define RIGL_W_STORE(buf_)                                                                            \
-  {                                                                                                   \
-    unsigned char* As_ = smem + (buf_) * STAGE;                                                       \
-    unsigned char* Bs_ = As_ + A_BYTES;                                                               \
-    _Pragma("unroll") for (int q = 0; q < NPASS; ++q) {                                               \
-      const int blk = q * THREADS + tid;                                                              \
-      if (blk < A_BLOCKS + B_BLOCKS) {                                                                \
-        const bool isA = blk < A_BLOCKS;                                                              \
-        const int bb = isA ? blk : blk - A_BLOCKS;                                                    \
-        const int nch = isA ? (BM / 8) : (BN / 8);                                                    \
-        const int cc = bb % nch, pg = bb / nch;                                                       \
-        unsigned char* base = isA ? As_ : Bs_;                                                        \
-        _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                               \
-          uint32_t o[4];                                                                              \
-          _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                             \
-            const uint32_t lo = dword_of(rg[q][2 * d], c >> 1), hi = dword_of(rg[q][2 * d + 1], c >> 1); \
-            o[d] = (c & 1) ? ((lo >> 16) | (hi & 0xFFFF0000u)) : ((lo & 0xFFFFu) | (hi << 16));        \
-          }                                                                                           \
-          *reinterpret_cast<uint4*>(base + lds_off<BK>(cc * 8 + c, pg)) = make_uint4(o[0], o[1], o[2], o[3]); \
-        }                                                                                             \
-      }                                                                                               \
-    }                                                                                                 \
-  }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  if (kt_begin < kt_end) {
-    RIGL_W_LOAD(kt_begin);
-    RIGL_W_STORE(0);
-    __syncthreads();
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const int buf = (kt - kt_begin) & 1;
-      const bool more = kt + 1 < kt_end;
-      if (more) RIGL_W_LOAD(kt + 1);
-      const unsigned char* As = smem + buf * STAGE;
-      const unsigned char* Bs = As + A_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        const int chunk = ks * 2 + (lane >> 5);
-        bf16x8 af[TM], bfr[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off<BK>(wm * 32 * TM + i * 32 + (lane & 31), chunk));
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<BK>(wn * 32 * TN + j * 32 + (lane & 31), chunk));
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-      }
-      if (more) RIGL_W_STORE(buf ^ 1);
-      __syncthreads();
-    }
-  }
-#undef RIGL_W_LOAD
-#undef RIGL_W_STORE
-  float* out = P.OUT + (int64_t)split * P.slab_elems + (int64_t)tap * P.Cin * P.Cout;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int ci = ci0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const int co = co0 + wn * 32 * TN + j * 32 + (lane & 31);
-        if (ci < P.Cin && co < P.Cout) out[(int64_t)ci * P.Cout + co] = acc[i][j][e];
-      }
-}
-
-// wgrad, LDS-DMA + transpose-read variant.  Both operands are reduction(pixel)-major
-// in memory ([pixel][channel]) while the MFMA wants 8 consecutive k per lane, so
-// k_wgrad transposes 8x8 blocks in registers (~100 VALU per K-tile).  gfx950's
+// wgrad, LDS-DMA + transpose-read.  Both operands are reduction(pixel)-major
+// in memory ([pixel][channel]) while the MFMA wants 8 consecutive k per lane (round 1's
+// first kernel transposed 8x8 blocks in registers, ~100 VALU per K-tile).  gfx950's
 // ds_read_b64_tr_b16 does that transposition in the LDS read path: per 16-lane
 // group, lane j supplies the address of 4 consecutive channels of pixel j/4 and
 // receives channel j of the 16-channel block for pixels 0..3 (measured:
@@ -1112,54 +955,8 @@ struct ReduceArgs {
   int splits;
 };
 
-// One workgroup walks the 64-output groups bid, bid + nblk, ... (a standalone launch has one group per
-// workgroup; as the third segment of a fused backward launch a few hundred workgroups share the groups).
-// The summation order of every output is the same in both uses.
-__device__ __forceinline__ void wgrad_reduce_body(const ReduceArgs& R, unsigned char* smem, uint32_t bid, uint32_t nblk) {
-  float4 (*part)[16] = reinterpret_cast<float4 (*)[16]>(smem);      // [16][16]
-  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  const int64_t n_groups = (R.n_out + 63) / 64;
-  const bool vec = (R.slab_elems & 3) == 0;
-  const float* __restrict__ slabs = R.slabs;
-  float* __restrict__ dw = R.dw;
-  for (int64_t gidx = bid; gidx < n_groups; gidx += nblk) {
-    const int64_t i0 = gidx * 64 + col * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (vec && i0 + 3 < R.slab_elems) {
-#pragma unroll 4
-      for (int s2 = grp; s2 < R.splits; s2 += 16) {
-        const float4 v = *reinterpret_cast<const float4*>(slabs + (int64_t)s2 * R.slab_elems + i0);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-      }
-    } else {
-      for (int s2 = grp; s2 < R.splits; s2 += 16) {
-        const float* p = slabs + (int64_t)s2 * R.slab_elems;
-        if (i0 + 0 < R.slab_elems) acc.x += p[i0 + 0];
-        if (i0 + 1 < R.slab_elems) acc.y += p[i0 + 1];
-        if (i0 + 2 < R.slab_elems) acc.z += p[i0 + 2];
-        if (i0 + 3 < R.slab_elems) acc.w += p[i0 + 3];
-      }
-    }
-    part[grp][col] = acc;
-    __syncthreads();
-    if (grp == 0) {
-      float4 r = part[0][col];
-#pragma unroll
-      for (int g2 = 1; g2 < 16; ++g2) {
-        const float4 v = part[g2][col];
-        r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
-      }
-      if (i0 + 0 < R.n_out) dw[i0 + 0] = r.x;
-      if (i0 + 1 < R.n_out) dw[i0 + 1] = r.y;
-      if (i0 + 2 < R.n_out) dw[i0 + 2] = r.z;
-      if (i0 + 3 < R.n_out) dw[i0 + 3] = r.w;
-    }
-    __syncthreads();
-  }
-}
-
-// The standalone launch: one 64-output group per workgroup, same arithmetic and order as the body above
-// (kept as its own straight-line kernel: the looped body costs it 2 us per launch, 0.1 ms per ResNet-50 step).
+// One 64-output group per workgroup.  (Rounds 2-3 also ran this as a third workgroup segment of the NEXT layer's
+// backward launch -- bit-identical, +0.5 ms per step, removed.)
 __global__ __launch_bounds__(THREADS) void k_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw,
                                                            int64_t n_out, int64_t slab_elems, int splits) {
   __shared__ float4 part[16][16];
@@ -1237,29 +1034,27 @@ __global__ __launch_bounds__(THREADS) void k_wgrad_reduce_few(const float* __res
 }
 
 static void launch_wgrad_reduce(const ReduceArgs& ra, hipStream_t st) {
-  static const bool few = [] { const char* e = getenv("RIGL_WGRAD_REDUCE_FEW"); return e ? atoi(e) != 0 : true; }();
-  if (few && ra.splits <= 4)
+  if (ra.splits <= 4)
     RIGL_K_LAUNCH(k_wgrad_reduce_few<4>, dim3((unsigned)ceil_div64(ra.n_out, 256)), dim3(THREADS), 0, st, ra.slabs, ra.dw, ra.n_out, ra.slab_elems, ra.splits);
-  else if (few && ra.splits <= 8)
+  else if (ra.splits <= 8)
     RIGL_K_LAUNCH(k_wgrad_reduce_few<8>, dim3((unsigned)ceil_div64(ra.n_out, 128)), dim3(THREADS), 0, st, ra.slabs, ra.dw, ra.n_out, ra.slab_elems, ra.splits);
   else
     RIGL_K_LAUNCH(k_wgrad_reduce, dim3((unsigned)ceil_div64(ra.n_out, 64)), dim3(THREADS), 0, st, ra.slabs, ra.dw, ra.n_out, ra.slab_elems, ra.splits);
 }
 
 // Whole backward of a conv in ONE launch: the first `nw` workgroups run the weight-gradient GEMM, the
-// next `nd` the dgrad implicit GEMM, any further ones the deferred split-K reduce of the layer before.  The two are independent (both read dY) and on their own each
+// next `nd` the dgrad implicit GEMM.  The two are independent (both read dY) and on their own each
 // leaves much of the chip idle (196-784 tiles for 768 workgroup slots), so sharing a launch lets the
 // dispatcher fill the machine with whichever still has tiles -- the overlap a second stream gives,
 // without a second stream.  Same bodies, one LDS allocation (the larger of the two).
 template <int TND, bool CLSD, int TMW, int TNW, int STW>
-__global__ __launch_bounds__(THREADS) void k_bwd_fused(IgemmArgs PD, WgradArgs PW, ReduceArgs PR, uint32_t nd, uint32_t nw) {
+__global__ __launch_bounds__(THREADS) void k_bwd_fused(IgemmArgs PD, WgradArgs PW, uint32_t nd, uint32_t nw) {
   constexpr int SD = igemm_smem_bytes<2, TND, 32, 1, false, CLSD, 3>(), SW = wgrad_tr_smem_bytes<TMW, TNW, STW>();
   __shared__ __attribute__((aligned(16))) unsigned char smem[SD > SW ? SD : SW];
   // longest jobs first: a weight-gradient workgroup walks 1/splits of all pixels and runs several times as long as
   // a dgrad tile, so it must not be what is left for the tail (dgrad first: 13.85 ms per step, wgrad first: 13.74)
   if (blockIdx.x < nw) wgrad_tr_body<TMW, TNW, STW>(PW, smem, blockIdx.x, nw);
-  else if (blockIdx.x < nd + nw) igemm_body<2, TND, 32, 1, false, CLSD, 3>(PD, smem, blockIdx.x - nw, nd);
-  else wgrad_reduce_body(PR, smem, blockIdx.x - nd - nw, gridDim.x - nd - nw);   // the PREVIOUS layer's split-K reduce
+  else igemm_body<2, TND, 32, 1, false, CLSD, 3>(PD, smem, blockIdx.x - nw, nd);
 }
 
 // ------------------------------------------------------------------ small-Cin (stem) path
@@ -1390,42 +1185,20 @@ __global__ __launch_bounds__(THREADS) void k_mfma_probe(float* __restrict__ sink
 }
 
 // ------------------------------------------------------------------ dispatch
-static int conv_dma_stages() {
-  static const int stages = [] { const char* e = getenv("RIGL_CONV_STAGES"); return (e && atoi(e) == 4) ? 4 : 3; }();
-  return stages;
-}
-
 template <int MODE, bool F32, bool CLS>
-static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, int bk, bool dma, bool w4, hipStream_t st) {
+static void launch_igemm_t(const IgemmArgs& a, dim3 grid, bool wide_n, bool dma, hipStream_t st) {
   dim3 blk(THREADS);
-  if (dma && w4) {
-    if (wide_n) RIGL_K_LAUNCH((k_igemm_w4<2, 2, 32, MODE, F32, CLS, 22>), grid, blk, 0, st, a);
-    else RIGL_K_LAUNCH((k_igemm_w4<2, 1, 32, MODE, F32, CLS, 22>), grid, blk, 0, st, a);
+  if (dma) {   // LDS-DMA ring, BK = 32: 3 stages = 48 KB of LDS -> 3 workgroups per CU (the 136-VGPR limit too)
+    if (wide_n) RIGL_K_LAUNCH((k_igemm<2, 2, 32, MODE, F32, CLS, 3>), grid, blk, 0, st, a);
+    else RIGL_K_LAUNCH((k_igemm<2, 1, 32, MODE, F32, CLS, 3>), grid, blk, 0, st, a);
     return;
   }
-  if (dma) {   // LDS-DMA ring, BK = 32: 3 stages = 48 KB of LDS -> 3 workgroups per CU (the 136-VGPR limit too); 4 stages
-    // = 64 KB -> 2 per CU measured 4-7 % slower over the ResNet-50 layer set (RIGL_CONV_STAGES=4 to compare)
-    if (conv_dma_stages() == 3) {
-      if (wide_n) RIGL_K_LAUNCH((k_igemm<2, 2, 32, MODE, F32, CLS, 3>), grid, blk, 0, st, a);
-      else RIGL_K_LAUNCH((k_igemm<2, 1, 32, MODE, F32, CLS, 3>), grid, blk, 0, st, a);
-    } else {
-      if (wide_n) RIGL_K_LAUNCH((k_igemm<2, 2, 32, MODE, F32, CLS, 4>), grid, blk, 0, st, a);
-      else RIGL_K_LAUNCH((k_igemm<2, 1, 32, MODE, F32, CLS, 4>), grid, blk, 0, st, a);
-    }
-    return;
-  }
-  if (wide_n) {
-    if (bk == 64) RIGL_K_LAUNCH((k_igemm<2, 2, 64, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
-    else if (bk == 32) RIGL_K_LAUNCH((k_igemm<2, 2, 32, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
-    else RIGL_K_LAUNCH((k_igemm<2, 2, 16, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
-  } else {
-    if (bk == 64) RIGL_K_LAUNCH((k_igemm<2, 1, 64, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
-    else if (bk == 32) RIGL_K_LAUNCH((k_igemm<2, 1, 32, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
-    else RIGL_K_LAUNCH((k_igemm<2, 1, 16, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
-  }
+  // reductions narrower than 32 channels (8, 16, 24): the register-staged double buffer, BK = 16
+  if (wide_n) RIGL_K_LAUNCH((k_igemm<2, 2, 16, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
+  else RIGL_K_LAUNCH((k_igemm<2, 1, 16, MODE, F32, CLS, 2>), grid, blk, 0, st, a);
 }
 
-struct IgemmPlan { bool wide_n, dma, w4, cls, big; int bk; unsigned grid; };
+struct IgemmPlan { bool wide_n, dma, cls, big; unsigned grid; };
 
 static int num_cus();
 // The 512-thread kernel needs 72 KB of dynamic LDS: opt in once; if the runtime refuses, the plan never picks it.
@@ -1444,25 +1217,12 @@ static IgemmPlan plan_igemm(IgemmArgs& a) {
   a.fd_rw = make_fastdiv(a.RW); a.fd_rh = make_fastdiv(a.RH);
   // 128x64 tiles when the 128x128 grid has fewer tiles than CUs (7x7 layers at batch 128: 196): twice the
   // workgroups, ~5 % faster; at 392 tiles the narrower tile's lower arithmetic intensity already loses.
-  static const int narrow_below = [] { const char* e = getenv("RIGL_CONV_NARROW_BELOW"); return e ? atoi(e) : 256; }();
   const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
-  pl.wide_n = a.N > 64 && tiles128 >= narrow_below;
+  pl.wide_n = a.N > 64 && tiles128 >= 256;
   const int BM = 128;
   const int BN = pl.wide_n ? 128 : 64;
   a.tiles_n = (a.N + BN - 1) / BN;
-  int bk = a.Cred >= 64 ? 64 : (a.Cred >= 32 ? 32 : 16);
-  // short reductions (<= 4 K-tiles of 64, e.g. 1x1 convs with Cin <= 256) are latency/HBM-bound:
-  // BK = 32 halves the LDS footprint (3 workgroups per CU instead of 2); long ones keep BK = 64
-  // (measured on MI355X, batch 128: 1x1 56x56 64->256 fwd 81 -> 62 us; 3x3 512->512 65 -> 81 us).
-  if (bk == 64 && a.KH * a.KW * ((a.Cred + 63) / 64) <= 4) bk = 32;
-  static const int bk_cap = [] { const char* e = getenv("RIGL_CONV_BK"); return e ? atoi(e) : 64; }();   // tuning knobs
-  static const int use_dma = [] { const char* e = getenv("RIGL_CONV_DMA"); return e ? atoi(e) : 1; }();
-  if (bk > bk_cap && bk_cap >= 16) bk = bk_cap;
-  pl.bk = bk;
-  static const int shortk = [] { const char* e = getenv("RIGL_CONV_SHORTK"); return e ? atoi(e) : 0; }();
-  pl.dma = use_dma && a.Cred >= 32 && a.KH * a.KW * ((a.Cred + 31) / 32) > shortk;
-  static const int w4_kt = [] { const char* e = getenv("RIGL_CONV_W4_KT"); return e ? atoi(e) : 0; }();
-  pl.w4 = pl.dma && a.KH * a.KW * ((a.Cred + 31) / 32) <= w4_kt;   // K-tiles of 32
+  pl.dma = a.Cred >= 32;       // (narrower reductions: the register-staged body, BK = 16)
   pl.cls = false;
   pl.big = false;
   if (MODE == 1 && (a.sh > 1 || a.sw > 1) && a.sh <= 2 && a.sw <= 2) {
@@ -1497,7 +1257,7 @@ static IgemmPlan plan_igemm(IgemmArgs& a) {
   // RIGL_CONV_BIG=0 never, =2 wherever it is legal (testing).
   static const int big_mode = [] { const char* e = getenv("RIGL_CONV_BIG"); return e ? atoi(e) : 1; }();
   const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + 127) / 128);
-  pl.big = MODE == 0 && big_mode > 0 && big_tile_ready<MODE>() && pl.wide_n && pl.dma && !pl.w4 && a.M >= 256 &&
+  pl.big = MODE == 0 && big_mode > 0 && big_tile_ready<MODE>() && pl.wide_n && pl.dma && a.M >= 256 &&
            (big_mode == 2 || (tiles128 > 3 * (int64_t)num_cus() && tiles256 <= 2 * (int64_t)num_cus()));
   const int tiles_m = (a.M + (pl.big ? 256 : BM) - 1) / (pl.big ? 256 : BM);
   pl.grid = (unsigned)(tiles_m * a.tiles_n);
@@ -1512,8 +1272,8 @@ static void launch_igemm(const IgemmArgs& a0, hipStream_t st) {
     RIGL_K_LAUNCH((k_igemm_big<MODE, false>), dim3(pl.grid), dim3(512), (igemm_smem_bytes<2, 2, 32, MODE, false, false, 3, 4>()), st, a);
     return;
   }
-  if (pl.cls) launch_igemm_t<MODE, F32, true>(a, dim3(pl.grid), pl.wide_n, pl.bk, pl.dma, pl.w4, st);
-  else launch_igemm_t<MODE, F32, false>(a, dim3(pl.grid), pl.wide_n, pl.bk, pl.dma, pl.w4, st);
+  if (pl.cls) launch_igemm_t<MODE, F32, true>(a, dim3(pl.grid), pl.wide_n, pl.dma, st);
+  else launch_igemm_t<MODE, F32, false>(a, dim3(pl.grid), pl.wide_n, pl.dma, st);
 }
 
 static int check_desc(const RiglConvDesc* d, const char* who) {
@@ -1551,12 +1311,8 @@ static size_t pp_ksplit_workspace(const RiglConvDesc* d) {
 
 struct WgradPlan { int tm, tn, tiles_ci, tiles_co, splits; int64_t slab; };
 // DMA ring depth of the tr kernel: 3 stages for the 128x128 tile (48 KB -> 3 workgroups/CU),
-// 4 for the smaller tiles (measured per layer; RIGL_WGRAD_STAGES=3|4 forces one).
-static int wgrad_stages(int tm, int tn) {
-  static const int forced = [] { const char* e = getenv("RIGL_WGRAD_STAGES"); return e ? atoi(e) : 0; }();
-  if (forced == 3 || forced == 4) return forced;
-  return (tm == 2 && tn == 2) ? 3 : 4;
-}
+// 4 for the smaller tiles (measured per layer).
+static int wgrad_stages(int tm, int tn) { return (tm == 2 && tn == 2) ? 3 : 4; }
 static int num_cus() {
   static const int n = [] {
     int dev = 0, v = 0;
@@ -1578,9 +1334,9 @@ static WgradPlan plan_wgrad(int M, int cin, int cout, int taps, bool fused = fal
   p.tiles_co = (cout + 64 * p.tn - 1) / (64 * p.tn);
   const int64_t base = (int64_t)p.tiles_ci * p.tiles_co * taps;
   const int kt = (M + 63) / 64;
-  static const int target = [] { const char* e = getenv("RIGL_WGRAD_WGS"); return e ? atoi(e) : 0; }();
+  const int target = 0;
   const int lds = wgrad_stages(p.tm, p.tn) * 32 * 64 * (p.tm + p.tn) * 2;   // bytes of the tr kernel's DMA ring
-  static const int lds_cu = [] { const char* e = getenv("RIGL_WGRAD_LDS_KB"); return (e ? atoi(e) : 160) * 1024; }();
+  const int lds_cu = 160 * 1024;
   int occ = lds_cu / lds;
   if (occ > 4) occ = 4;
   int64_t slots = target > 0 ? target : (int64_t)num_cus() * occ;
@@ -1601,16 +1357,9 @@ static WgradPlan plan_wgrad(int M, int cin, int cout, int taps, bool fused = fal
   return p;
 }
 
-static bool wgrad_use_tr() {
-  static const bool v = [] { const char* e = getenv("RIGL_WGRAD_TR"); return e ? atoi(e) != 0 : true; }();
-  return v;
-}
-// Tiny-Cin (stem) wgrad: with the tr kernel the KH filter rows are folded into the channel axis
-// (KH*cred = 224 "channels", one tap) so the 128-channel tile is full and dY is read by 2 channel
-// tiles instead of KH = 7 taps; the register-transposing kernel keeps one tap per workgroup.
-static WgradPlan tiny_wgrad_plan(int M, int cred, int cout, int kh) {
-  return wgrad_use_tr() ? plan_wgrad(M, kh * cred, cout, 1) : plan_wgrad(M, cred, cout, kh);
-}
+// Tiny-Cin (stem) wgrad: the KH filter rows are folded into the channel axis (KH*cred = 224 "channels", one tap) so
+// the 128-channel tile is full and dY is read by 2 channel tiles instead of KH = 7 taps.
+static WgradPlan tiny_wgrad_plan(int M, int cred, int cout, int kh) { return plan_wgrad(M, kh * cred, cout, 1); }
 
 }  // namespace k1
 }  // namespace rigl
@@ -1680,7 +1429,6 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, cons
   ProfFamily prof(PROF_CONV_FWD);
   IgemmArgs a = {};
   a.C = y; a.M = d->n * d->ho * d->wo; a.N = d->cout; a.ldc = d->cout; a.STATS = stats;
-  a.nt_out = k1_nt((size_t)a.M * d->cout * 2);
   const size_t need = rigl_conv2d_workspace_bytes(d, 0);
   // (the ordinary layers' only workspace is the optional K-split scratch: without it they run unsplit)
   if ((tiny_cin(d) || small_cin(d)) && need && (!workspace || workspace_bytes < need))
@@ -1748,7 +1496,6 @@ static rigl::k1::IgemmArgs dgrad_args(const RiglConvDesc* d, const rigl_bf16* dy
                                       const rigl_bf16* addend, rigl_bf16* dx) {
   rigl::k1::IgemmArgs a = {};
   a.A = dy; a.B = w_hwio; a.C = dx; a.ADD = addend;
-  a.nt_out = rigl::k1::k1_nt((size_t)d->n * d->h * d->w * d->cin * 2);
   a.M = d->n * d->h * d->w; a.N = d->cin; a.Cred = d->cout; a.ldc = d->cin;
   a.KH = d->kh; a.KW = d->kw; a.RH = d->h; a.RW = d->w; a.GH = d->ho; a.GW = d->wo;
   a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
@@ -1842,7 +1589,7 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   const size_t need = rigl_conv2d_workspace_bytes(d, 2);
   if (need && (!workspace || workspace_bytes < need)) return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
   ProfFamily prof(PROF_CONV_WGRAD);
-  if (tune_get("pp_wgrad", -1) > 0 && !tiny_cin(d) && !small_cin(d) && pp_wgrad_legal(d)) {
+  if (RIGL_TUNE("pp_wgrad", -1) > 0 && !tiny_cin(d) && !small_cin(d) && pp_wgrad_legal(d)) {
     const PPBwdPlan pw = plan_wgrad_pp(d, 0u, 0);
     const WgradArgs aw = pp_wgrad_args(d, x, dy, pw, dw, workspace);
     if (pp_wgrad_launch(pw, aw, st)) {
@@ -1854,7 +1601,7 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
       return RIGL_OK;
     }
   }
-  if (tiny_cin(d) && stem_direct_legal(d) && tune_get("stem_wgrad", 1) != 0) {
+  if (tiny_cin(d) && stem_direct_legal(d) && RIGL_TUNE("stem_wgrad", 1) != 0) {
     // the ImageNet stem: patch and dY tile resident in LDS, both operands by transposing reads (stem.hpp)
     float* tmp = static_cast<float*>(workspace);
     float* slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)7 * 32 * 64 * 4, 256));
@@ -1867,7 +1614,7 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
     }
   }
   WgradArgs a = {};
-  a.interleave = tune_get("wgrad_il", 1);
+  a.interleave = RIGL_TUNE("wgrad_il", 1);
   a.DY = dy; a.M = d->n * d->ho * d->wo; a.Cout = d->cout;
   a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
   int64_t n_out;
@@ -1884,7 +1631,7 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
     a.X = xp; a.Cin = tg.cred; a.x_pix_stride = 4; a.KH = d->kh; a.KW = 1; a.H = tg.hp; a.W = tg.wp;
     a.Ho = d->ho; a.Wo = d->wo; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = a.pw = 0;
     a.x_bytes = (uint32_t)xp_bytes;
-    if (wgrad_use_tr()) { a.fold = tg.cred; a.Cin = d->kh * tg.cred; a.KH = 1; }   // [kh][cred] is one channel axis
+    a.fold = tg.cred; a.Cin = d->kh * tg.cred; a.KH = 1;   // [kh][cred] is one channel axis
     n_out = (int64_t)d->kh * tg.cred * d->cout;
     tiny_tmp = reinterpret_cast<float*>(ws);
     ws += align_up((size_t)n_out * 4, 256);
@@ -1909,25 +1656,10 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   const bool two_pass = p.splits > 1 || small_cin(d) || tiny_cin(d);
   a.OUT = two_pass ? reinterpret_cast<float*>(ws) : dw;
   dim3 grid((unsigned)((int64_t)p.tiles_ci * p.tiles_co * a.KH * a.KW * p.splits)), blk(THREADS);
-  const bool use_tr = wgrad_use_tr();
-  if (use_tr) {
-    if (wgrad_stages(p.tm, p.tn) == 3) {
-      if (p.tm == 2 && p.tn == 2) RIGL_K_LAUNCH((k_wgrad_tr<2, 2, 3>), grid, blk, 0, st, a);
-      else if (p.tm == 2) RIGL_K_LAUNCH((k_wgrad_tr<2, 1, 3>), grid, blk, 0, st, a);
-      else if (p.tn == 2) RIGL_K_LAUNCH((k_wgrad_tr<1, 2, 3>), grid, blk, 0, st, a);
-      else RIGL_K_LAUNCH((k_wgrad_tr<1, 1, 3>), grid, blk, 0, st, a);
-    } else {
-      if (p.tm == 2 && p.tn == 2) RIGL_K_LAUNCH((k_wgrad_tr<2, 2, 4>), grid, blk, 0, st, a);
-      else if (p.tm == 2) RIGL_K_LAUNCH((k_wgrad_tr<2, 1, 4>), grid, blk, 0, st, a);
-      else if (p.tn == 2) RIGL_K_LAUNCH((k_wgrad_tr<1, 2, 4>), grid, blk, 0, st, a);
-      else RIGL_K_LAUNCH((k_wgrad_tr<1, 1, 4>), grid, blk, 0, st, a);
-    }
-  } else {
-    if (p.tm == 2 && p.tn == 2) RIGL_K_LAUNCH((k_wgrad<2, 2>), grid, blk, 0, st, a);
-    else if (p.tm == 2) RIGL_K_LAUNCH((k_wgrad<2, 1>), grid, blk, 0, st, a);
-    else if (p.tn == 2) RIGL_K_LAUNCH((k_wgrad<1, 2>), grid, blk, 0, st, a);
-    else RIGL_K_LAUNCH((k_wgrad<1, 1>), grid, blk, 0, st, a);
-  }
+  if (wgrad_stages(p.tm, p.tn) == 3) RIGL_K_LAUNCH((k_wgrad_tr<2, 2, 3>), grid, blk, 0, st, a);
+  else if (p.tm == 2) RIGL_K_LAUNCH((k_wgrad_tr<2, 1, 4>), grid, blk, 0, st, a);
+  else if (p.tn == 2) RIGL_K_LAUNCH((k_wgrad_tr<1, 2, 4>), grid, blk, 0, st, a);
+  else RIGL_K_LAUNCH((k_wgrad_tr<1, 1, 4>), grid, blk, 0, st, a);
   if (two_pass) {
     ReduceArgs ra = {reinterpret_cast<const float*>(ws), tiny_tmp ? tiny_tmp : dw, n_out, p.slab, p.splits};
     launch_wgrad_reduce(ra, st);
@@ -1938,55 +1670,30 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   return RIGL_OK;
 }
 
-static void launch_pending_reduce(const RiglPendingReduce* pr, hipStream_t st) {
-  using namespace rigl;
-  using namespace rigl::k1;
-  ReduceArgs ra = {pr->slabs, pr->dw, pr->n_out, pr->slab_elems, pr->splits};
-  launch_wgrad_reduce(ra, st);
-}
-
-int rigl_wgrad_reduce_pending(const RiglPendingReduce* pending, rigl_stream_t stream) {
-  using namespace rigl;
-  if (!pending || pending->splits <= 0) return RIGL_OK;
-  if (!pending->slabs || !pending->dw) return fail(RIGL_EINVAL, "rigl_wgrad_reduce_pending: NULL buffer");
-  ProfFamily prof(PROF_CONV_BWD);
-  launch_pending_reduce(pending, as_stream(stream));
-  RIGL_CHECK_LAUNCH("rigl_wgrad_reduce_pending");
-  return RIGL_OK;
-}
-
 static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
                     const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
-                    const RiglPendingReduce* flush, RiglPendingReduce* defer, const RiglBnReduceFuse* bn, rigl_stream_t stream);
+                    const RiglBnReduceFuse* bn, rigl_stream_t stream);
 
-int rigl_masked_conv2d_bwd_deferred(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy,
-                                    const rigl_bf16* w_hwio, const rigl_bf16* addend, float* dw, rigl_bf16* dx,
-                                    void* workspace, size_t workspace_bytes, const RiglPendingReduce* flush,
-                                    RiglPendingReduce* defer, rigl_stream_t stream) {
-  return bwd_impl(d, x, dy, w_hwio, addend, dw, dx, workspace, workspace_bytes, flush, defer, nullptr, stream);
-}
-
-// The same launch with the batch-norm backward reductions of the tensor dX is the gradient of riding in the dgrad epilogue.
+// rigl_masked_conv2d_bwd with the batch-norm backward reductions of the tensor dX is the gradient of riding in the dgrad
+// epilogue.
 int rigl_masked_conv2d_bwd_bn(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
                               const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
-                              const RiglPendingReduce* flush, RiglPendingReduce* defer, const RiglBnReduceFuse* bn,
-                              rigl_stream_t stream) {
+                              const RiglBnReduceFuse* bn, rigl_stream_t stream) {
   if (bn && !dx) return rigl::fail(RIGL_EINVAL, "rigl_masked_conv2d_bwd_bn: the reductions ride on dX, which was not requested");
-  return bwd_impl(d, x, dy, w_hwio, addend, dw, dx, workspace, workspace_bytes, flush, defer, bn, stream);
+  return bwd_impl(d, x, dy, w_hwio, addend, dw, dx, workspace, workspace_bytes, bn, stream);
 }
 
 static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
                     const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
-                    const RiglPendingReduce* flush, RiglPendingReduce* defer, const RiglBnReduceFuse* bn, rigl_stream_t stream) {
+                    const RiglBnReduceFuse* bn, rigl_stream_t stream) {
   using namespace rigl;
   using namespace rigl::k1;
   static const bool fuse = [] { const char* e = getenv("RIGL_BWD_FUSED"); return e ? atoi(e) != 0 : true; }();
   int rc = check_desc(d, "rigl_masked_conv2d_bwd");
   if (rc) return rc;
-  if (defer) defer->splits = 0;
-  const bool have_flush = flush && flush->splits > 0;
-  if (have_flush && (!flush->slabs || !flush->dw)) return fail(RIGL_EINVAL, "rigl_masked_conv2d_bwd: NULL buffer in the pending reduce");
   hipStream_t st = as_stream(stream);
+  const bool whole = dx && x && dy && w_hwio && dw;        // both gradients asked for, every operand there
+  const size_t need = rigl_conv2d_workspace_bytes(d, 2);
   // A layer's dX must come from the same kernel whichever entry point computes it (rigl_masked_conv2d_dgrad or this
   // one): the ping-pong body accumulates in another order than the igemm body of the shared launch, so layers whose
   // dgrad has a ping-pong plan run wgrad and dgrad as two launches.
@@ -1996,139 +1703,90 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
     dgrad_pp = plan_pp<1>(ap).variant != 0;
   }
   // The big-M 1x1 layers: dX and dW in ONE pass over dY (bwd1x1.hpp), one slab per workgroup, then the reduce
-  if (dx && x && dy && w_hwio && dw && !bn && bwd1x1_kind(d)) {
-    const size_t need = rigl_conv2d_workspace_bytes(d, 2);
+  if (whole && !bn && bwd1x1_kind(d) && bwd1x1_ready(d)) {
     if (need && (!workspace || workspace_bytes < need))
       return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
-    if (have_flush) { ProfFamily pf(PROF_CONV_BWD); launch_pending_reduce(flush, st); }
     ProfFamily prof(PROF_CONV_BWD);
     if (launch_bwd1x1(d, x, dy, w_hwio, addend, dx, static_cast<float*>(workspace), st)) {
       const int64_t n_out = (int64_t)d->cin * d->cout;
-      if (defer) {
-        defer->slabs = static_cast<const float*>(workspace); defer->dw = dw; defer->n_out = n_out;
-        defer->slab_elems = n_out; defer->splits = bwd1x1_splits();
-      } else {
-        ReduceArgs ra = {static_cast<const float*>(workspace), dw, n_out, n_out, bwd1x1_splits()};
-        launch_wgrad_reduce(ra, st);
-      }
+      ReduceArgs ra = {static_cast<const float*>(workspace), dw, n_out, n_out, bwd1x1_splits()};
+      launch_wgrad_reduce(ra, st);
       RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");
       return RIGL_OK;
     }
   }
   // The shared launch on the 8-wave ping-pong bodies ("pp_bwd"): layers whose weight gradient has 256-channel tiles and
-  // whose dgrad is a stride-1 long reduction.
-  if (tune_get("pp_bwd", -1) != 0 && dx && x && dy && w_hwio && dw && !bn && !tiny_cin(d) && !small_cin(d) && pp_wgrad_legal(d)) {
+  // whose dgrad is a long reduction.
+  if (RIGL_TUNE("pp_bwd", -1) != 0 && whole && !bn && !tiny_cin(d) && !small_cin(d) && pp_wgrad_legal(d)) {
     IgemmArgs ad = dgrad_args(d, dy, w_hwio, addend, dx);
-    const int dvar = tune_get("pp_dgrad", -1) >= 0 ? PP_NONE : pp_bwd_dgrad_variant(ad);   // (a forced stand-alone dgrad tile wins)
+    const int dvar = RIGL_TUNE("pp_dgrad", -1) >= 0 ? PP_NONE : pp_bwd_dgrad_variant(ad);   // (a forced stand-alone dgrad tile wins)
     if (dvar != PP_NONE && pp_legal<1>(ad, dvar)) {
-      int bm, bn;
-      pp_dims(dvar, bm, bn);
+      int bm, bn2;
+      pp_dims(dvar, bm, bn2);
       const bool strided = pp_strided(ad);
       const int tiles_m = strided ? pp_fill_classes(ad, bm) : (ad.M + bm - 1) / bm;
-      const unsigned nd = (unsigned)(tiles_m * (ad.N / bn));
+      const unsigned nd = (unsigned)(tiles_m * (ad.N / bn2));
       // dgrad workgroup length in 256x256-tile K-tile units (a parity class visits about taps / (sh * sw) of the taps)
-      const int kt_d = (int)((int64_t)d->kh * d->kw * (d->cout / 64) * bm * bn / (256 * 256) / (d->stride_h * d->stride_w));
+      const int kt_d = (int)((int64_t)d->kh * d->kw * (d->cout / 64) * bm * bn2 / (256 * 256) / (d->stride_h * d->stride_w));
       const PPBwdPlan pw = plan_wgrad_pp(d, nd, kt_d);
-      const size_t need = rigl_conv2d_workspace_bytes(d, 2);
       if (need && (!workspace || workspace_bytes < need))
         return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
-      if (have_flush && need && flush->slabs == static_cast<const float*>(workspace))
-        return fail(RIGL_EINVAL, "rigl_masked_conv2d_bwd: the pending reduce still reads this workspace");
       ProfFamily prof(PROF_CONV_BWD);
       const WgradArgs aw = pp_wgrad_args(d, x, dy, pw, dw, workspace);
       ad.fd_rw = make_fastdiv(ad.RW); ad.fd_rh = make_fastdiv(ad.RH);
-      ad.tiles_n = ad.N / bn;
-      // the layer before left its split-K reduce for this launch: a third segment that runs in the launch's tail
-      ReduceArgs pr = {nullptr, nullptr, 0, 0, 0};
-      unsigned nr = 0;
-      if (have_flush) {
-        pr.slabs = flush->slabs; pr.dw = flush->dw; pr.n_out = flush->n_out; pr.slab_elems = flush->slab_elems; pr.splits = flush->splits;
-        const int64_t pairs = ceil_div64(ceil_div64(flush->n_out, 64), 2);
-        nr = (unsigned)(pairs < (int64_t)num_cus() ? pairs : (int64_t)num_cus());
-      }
-      if (pp_bwd_launch(dvar, strided, ad, aw, pw, pr, nr, st)) {
+      ad.tiles_n = ad.N / bn2;
+      if (pp_bwd_launch(dvar, strided, ad, aw, pw, st)) {
         if (pw.splits > 1) {
-          if (defer) {
-            defer->slabs = static_cast<const float*>(workspace); defer->dw = dw; defer->n_out = pw.slab;
-            defer->slab_elems = pw.slab; defer->splits = pw.splits;
-          } else {
-            ReduceArgs ra = {static_cast<const float*>(workspace), dw, pw.slab, pw.slab, pw.splits};
-            launch_wgrad_reduce(ra, st);
-          }
+          ReduceArgs ra = {static_cast<const float*>(workspace), dw, pw.slab, pw.slab, pw.splits};
+          launch_wgrad_reduce(ra, st);
         }
         RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");
         return RIGL_OK;
       }
     }
   }
-  if (fuse && !dgrad_pp && dx && x && dy && w_hwio && dw && !tiny_cin(d) && !small_cin(d) && (d->cin % 8) == 0 && (d->cout % 8) == 0 &&
-      wgrad_use_tr() && conv_dma_stages() == 3) {
+  if (fuse && !dgrad_pp && whole && !tiny_cin(d) && !small_cin(d) && (d->cin % 8) == 0 && (d->cout % 8) == 0) {
     IgemmArgs ad = dgrad_args(d, dy, w_hwio, addend, dx);
     rc = attach_bn(ad, d, bn);
     if (rc) return rc;
     const IgemmPlan pd = plan_igemm<1>(ad);
     WgradArgs aw = {};
-    aw.interleave = tune_get("wgrad_il", 1);
+    aw.interleave = RIGL_TUNE("wgrad_il", 1);
     aw.DY = dy; aw.M = d->n * d->ho * d->wo; aw.Cout = d->cout;
     aw.dy_bytes = (uint32_t)((size_t)aw.M * d->cout * 2);
     aw.X = x; aw.Cin = d->cin; aw.x_pix_stride = d->cin; aw.KH = d->kh; aw.KW = d->kw; aw.H = d->h; aw.W = d->w;
     aw.Ho = d->ho; aw.Wo = d->wo; aw.sh = d->stride_h; aw.sw = d->stride_w; aw.ph = d->pad_top; aw.pw = d->pad_left;
     aw.x_bytes = (uint32_t)((size_t)d->n * d->h * d->w * d->cin * 2);
     const WgradPlan p = plan_wgrad(aw.M, aw.Cin, aw.Cout, aw.KH * aw.KW, true);
-    const int st_default = (p.tm == 2 && p.tn == 2) ? 3 : 4;
-    // Launched alone back to back, a large short-reduction (HBM-bound) dgrad -- the 56x56 / 28x28 1x1 "reduce"
-    // convs -- is 9-28 % slower when it shares the launch, the other layers 3-10 % faster; inside the training
-    // step sharing always won (8688 vs 8567 images/s on one box), so the selective rule is off by default.
-    const int dgrad_ktiles = d->kh * d->kw * ((d->cout + 31) / 32);
-    static const bool selective = [] { const char* e = getenv("RIGL_BWD_FUSE_SELECTIVE"); return e ? atoi(e) != 0 : false; }();
-    const bool pays = !selective || !(pd.grid > 1536u && dgrad_ktiles <= 8);
-    if (pays && pd.dma && !pd.w4 && wgrad_stages(p.tm, p.tn) == st_default) {
-      const size_t need = rigl_conv2d_workspace_bytes(d, 2);
+    // (launched alone back to back, a large short-reduction dgrad -- the 56x56 / 28x28 1x1 "reduce" convs -- is 9-28 %
+    // slower when it shares the launch, the other layers 3-10 % faster; inside the training step sharing always won)
+    if (pd.dma) {
       if (need && (!workspace || workspace_bytes < need))
         return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
-      if (have_flush && need && flush->slabs == static_cast<const float*>(workspace))
-        return fail(RIGL_EINVAL, "rigl_masked_conv2d_bwd: the pending reduce still reads this workspace");
       ProfFamily prof(PROF_CONV_BWD);
       aw.tiles_ci = p.tiles_ci; aw.tiles_co = p.tiles_co; aw.splits = p.splits; aw.slab_elems = p.slab;
       const bool two_pass = p.splits > 1;
       aw.OUT = two_pass ? static_cast<float*>(workspace) : dw;
       const unsigned nd = pd.grid, nw = (unsigned)((int64_t)p.tiles_ci * p.tiles_co * aw.KH * aw.KW * p.splits);
-      // the layer before left its split-K reduce for this launch: a third segment of a few hundred workgroups
-      ReduceArgs pr = {nullptr, nullptr, 0, 0, 0};
-      unsigned nr = 0;
-      if (have_flush) {
-        pr.slabs = flush->slabs; pr.dw = flush->dw; pr.n_out = flush->n_out; pr.slab_elems = flush->slab_elems; pr.splits = flush->splits;
-        const int64_t groups = ceil_div64(flush->n_out, 64);
-        nr = (unsigned)(groups < 3 * (int64_t)num_cus() ? groups : 3 * (int64_t)num_cus());
-      }
-      const dim3 grid(nd + nw + nr), blk(THREADS);
+      const dim3 grid(nd + nw), blk(THREADS);
 #define RIGL_FUSED(TND, CLSD)                                                                                          \
       {                                                                                                                \
-        if (p.tm == 2 && p.tn == 2) RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 2, 2, 3>), grid, blk, 0, st, ad, aw, pr, nd, nw); \
-        else if (p.tm == 2) RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 2, 1, 4>), grid, blk, 0, st, ad, aw, pr, nd, nw);      \
-        else if (p.tn == 2) RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 1, 2, 4>), grid, blk, 0, st, ad, aw, pr, nd, nw);      \
-        else RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 1, 1, 4>), grid, blk, 0, st, ad, aw, pr, nd, nw);                     \
+        if (p.tm == 2 && p.tn == 2) RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 2, 2, 3>), grid, blk, 0, st, ad, aw, nd, nw); \
+        else if (p.tm == 2) RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 2, 1, 4>), grid, blk, 0, st, ad, aw, nd, nw);          \
+        else if (p.tn == 2) RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 1, 2, 4>), grid, blk, 0, st, ad, aw, nd, nw);          \
+        else RIGL_K_LAUNCH((k_bwd_fused<TND, CLSD, 1, 1, 4>), grid, blk, 0, st, ad, aw, nd, nw);                         \
       }
       if (pd.wide_n) { if (pd.cls) RIGL_FUSED(2, true) else RIGL_FUSED(2, false) }
       else { if (pd.cls) RIGL_FUSED(1, true) else RIGL_FUSED(1, false) }
 #undef RIGL_FUSED
       if (two_pass) {
         const int64_t n_out = (int64_t)d->kh * d->kw * d->cin * d->cout;
-        if (defer) {           // the next backward launch (or rigl_wgrad_reduce_pending) finishes dW
-          defer->slabs = static_cast<const float*>(workspace); defer->dw = dw; defer->n_out = n_out;
-          defer->slab_elems = p.slab; defer->splits = p.splits;
-        } else {
-          ReduceArgs ra = {static_cast<const float*>(workspace), dw, n_out, p.slab, p.splits};
-          launch_wgrad_reduce(ra, st);
-        }
+        ReduceArgs ra = {static_cast<const float*>(workspace), dw, n_out, p.slab, p.splits};
+        launch_wgrad_reduce(ra, st);
       }
       RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");
       return RIGL_OK;
     }
-  }
-  if (have_flush) {
-    ProfFamily prof(PROF_CONV_BWD);
-    launch_pending_reduce(flush, st);
   }
   rc = rigl_masked_conv2d_wgrad(d, x, dy, dw, workspace, workspace_bytes, stream);
   if (rc || !dx) return rc;
@@ -2136,14 +1794,13 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
 }
 
 // Whole backward of one masked conv in one call: dW (dense) and, when dx is given, dX (+ addend).
-// Ordinary layers run both GEMMs in ONE launch (k_bwd_fused: the split-K weight-gradient workgroups first, then the dgrad
-// tiles) followed by the split-K reduce; the tiny-/small-Cin paths (extra repack
-// kernels, no dX for the stem) and non-default tuning knobs fall back to the two separate launches.
+// Ordinary layers run both GEMMs in ONE launch (k_bwd_fused / k_bwd_pp: the longer-running workgroups first) followed by
+// the split-K reduce; the tiny-/small-Cin paths (extra repack kernels, no dX for the stem) fall back to the two
+// separate launches.
 int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
                            const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
                            rigl_stream_t stream) {
-  return rigl_masked_conv2d_bwd_deferred(d, x, dy, w_hwio, addend, dw, dx, workspace, workspace_bytes, nullptr, nullptr,
-                                         stream);
+  return bwd_impl(d, x, dy, w_hwio, addend, dw, dx, workspace, workspace_bytes, nullptr, stream);
 }
 
 

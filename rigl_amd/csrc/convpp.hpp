@@ -16,15 +16,14 @@
 // A K-tile lives in LDS as four PIECES: A0 / A1 = the first / second half of every wave's rows, B0 / B1 = the first /
 // second half of every wave's columns ([row][64] bf16 = 128-byte rows, XOR-swizzled 16-byte chunks; the swizzle is
 // applied on the DMA's SOURCE side because `buffer_load ... lds` writes lane-linear).  A wave multiplies a K-tile
-// quadrant by quadrant, (A0,B0) (A0,B1) (A1,B1) (A1,B0), in PH phases (template):
-//   PH = 4  one quadrant per phase, two K-tile stages; every phase re-fills one dead piece:
-//           tile t phase 0: B1(t+1)   1: A1(t+1)   2: A0(t+2)   3: B0(t+2)
-//   PH = 2  two quadrants per phase (twice the MFMAs between barriers), two stages:
+// quadrant by quadrant, (A0,B0) (A0,B1) (A1,B1) (A1,B0), in PH phases (template; the one-quadrant-per-phase form
+// PH = 4 of round 3 measured 5-35 % slower on every tile and is gone):
+//   PH = 2  two quadrants per phase (16 MFMAs between barriers on the 128x64 wave tiles), two stages:
 //           tile t phase A (reads A0 B0 B1): A1(t+1)      phase B (reads A1): A0(t+2) B0(t+2) B1(t+2)
 //   PH = 1  the whole K-tile per phase (for the 64x64 wave tiles), three stages: tile t re-fills the stage of tile t-1
 //           with tile t+2.
-// A piece is issued >= 2 phases after its slot's last read (PH = 4), or in the phase right after it when the reading
-// segment ends with `s_waitcnt lgkmcnt(0)` BEFORE its barrier (PH = 2, 1) -- the two wave groups run one barrier apart,
+// A piece is issued in the phase right after its slot's last read, whose reading segment ends with
+// `s_waitcnt lgkmcnt(0)` BEFORE its barrier -- the two wave groups run one barrier apart,
 // so a read and a re-fill one barrier apart would race otherwise.  The covering `s_waitcnt vmcnt(N)` sits at the end of
 // the read segment of the phase BEFORE the reading phase (every wave's wait precedes, by a barrier, every wave's read --
 // the stagger makes "wait and read in the same phase" a race), N = the loads of the (at most four) younger pieces.
@@ -33,7 +32,7 @@
 
 template <int WM, int WN, int TM, int TN, int PH>
 struct PPGeom {
-  static_assert(PH == 4 || PH == 2 || PH == 1, "phases per K-tile");
+  static_assert(PH == 2 || PH == 1, "phases per K-tile");
   static constexpr int NST = PH == 1 ? 3 : 2;                      // K-tile stages in LDS
   static_assert(WM * WN == 8, "eight waves");
   static_assert(TM % 2 == 0 && TN % 2 == 0, "a wave tile splits into 2 x 2 quadrants");
@@ -252,7 +251,7 @@ __device__ __forceinline__ void pp_igemm_body(const IgemmArgs& P, unsigned char*
             bsrc_[j][ks], af[(ab_) + i][ks], acc[(ha_) * QM + i][(hb_) * QN + j], 0, 0, 0);
   // loads that may stay in flight behind a wait = the youngest pieces of the issue order (any four consecutive pieces
   // are two A and two B halves)
-  constexpr int W4 = 2 * NA + 2 * NB, W2 = NA + NB, W1 = NA;
+  constexpr int W4 = 2 * NA + 2 * NB, W1 = NA;
 
   if (KT > 0) {        // (a parity class without a reachable tap -- 1x1 / 2: three of four -- only writes zeros)
 #include "convpp_loop.inc"
@@ -372,7 +371,7 @@ __device__ __forceinline__ void pp_igemm_body(const IgemmArgs& P, unsigned char*
           const uint4 q = addv[it];
           v.x = add_bf16x2(v.x, q.x); v.y = add_bf16x2(v.y, q.y); v.z = add_bf16x2(v.z, q.z); v.w = add_bf16x2(v.w, q.w);
         }
-        store16(C + (int64_t)m * P.ldc + ncol, v, P.nt_out);
+        store16(C + (int64_t)m * P.ldc + ncol, v);
       }
     }
   }
@@ -536,8 +535,7 @@ __device__ __forceinline__ void pp_wgrad_body(const WgradArgs& P, unsigned char*
     _Pragma("unroll") for (int i = 0; i < QM; ++i)                                                       \
       acc[(ha_) * QM + i][(hb_)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                              \
           af[(ab_) + i][ks], bsrc_[0][ks], acc[(ha_) * QM + i][(hb_)], 0, 0, 0);
-  constexpr int W4 = 2 * NA + 2 * NB, W2 = NA + NB, W1 = NA;
-  (void)W2;
+  constexpr int W4 = 2 * NA + 2 * NB, W1 = NA;
 #include "convpp_loop.inc"
 #undef PP_READ_A
 #undef PP_READ_B
@@ -583,65 +581,11 @@ __global__ __launch_bounds__(512) void k_wgrad_pp(WgradArgs P) {
   pp_wgrad_body<PH>(P, smem_pp, blockIdx.x, gridDim.x);
 }
 
-// The split-K reduce of the layer BEFORE (rigl_masked_conv2d_bwd_deferred) as a third segment of 512-thread workgroups:
-// the two halves of a workgroup each run wgrad_reduce_body's 256-thread arithmetic on their own 64-output group (same
-// summation order as k_wgrad_reduce: bit-identical dW), barriers shared.
-__device__ __forceinline__ void pp_reduce_body(const ReduceArgs& R, unsigned char* smem, uint32_t bid, uint32_t nblk) {
-  const int half = threadIdx.x >> 8, t = threadIdx.x & 255;
-  float4 (*part)[16] = reinterpret_cast<float4 (*)[16]>(smem + half * 16 * 16 * sizeof(float4));
-  const int col = t & 15, grp = t >> 4;
-  const int64_t n_groups = (R.n_out + 63) / 64;
-  const bool vec = (R.slab_elems & 3) == 0;
-  const float* __restrict__ slabs = R.slabs;
-  float* __restrict__ dw = R.dw;
-  const int64_t iters = (n_groups + 2 * (int64_t)nblk - 1) / (2 * (int64_t)nblk);
-  for (int64_t it = 0; it < iters; ++it) {
-    const int64_t gidx = (it * nblk + bid) * 2 + half;
-    const bool live = gidx < n_groups;
-    const int64_t i0 = gidx * 64 + col * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) {
-      if (vec && i0 + 3 < R.slab_elems) {
-#pragma unroll 4
-        for (int s2 = grp; s2 < R.splits; s2 += 16) {
-          const float4 v = *reinterpret_cast<const float4*>(slabs + (int64_t)s2 * R.slab_elems + i0);
-          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
-      } else {
-        for (int s2 = grp; s2 < R.splits; s2 += 16) {
-          const float* p = slabs + (int64_t)s2 * R.slab_elems;
-          if (i0 + 0 < R.slab_elems) acc.x += p[i0 + 0];
-          if (i0 + 1 < R.slab_elems) acc.y += p[i0 + 1];
-          if (i0 + 2 < R.slab_elems) acc.z += p[i0 + 2];
-          if (i0 + 3 < R.slab_elems) acc.w += p[i0 + 3];
-        }
-      }
-    }
-    part[grp][col] = acc;
-    __syncthreads();
-    if (live && grp == 0) {
-      float4 r = part[0][col];
-#pragma unroll
-      for (int g2 = 1; g2 < 16; ++g2) {
-        const float4 v = part[g2][col];
-        r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
-      }
-      if (i0 + 0 < R.n_out) dw[i0 + 0] = r.x;
-      if (i0 + 1 < R.n_out) dw[i0 + 1] = r.y;
-      if (i0 + 2 < R.n_out) dw[i0 + 2] = r.z;
-      if (i0 + 3 < R.n_out) dw[i0 + 3] = r.w;
-    }
-    __syncthreads();
-  }
-}
-
 template <int WMD, int WND, int TMD, int TND, int PHD, bool CLSD = false>
-__global__ __launch_bounds__(512) void k_bwd_pp(IgemmArgs PD, WgradArgs PW, ReduceArgs PR, uint32_t nd, uint32_t nw, uint32_t wgrad_first) {
+__global__ __launch_bounds__(512) void k_bwd_pp(IgemmArgs PD, WgradArgs PW, uint32_t nd, uint32_t nw, uint32_t wgrad_first) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_pp[];
-  // longest jobs first: whichever body has the longer reduction per workgroup takes the low block indices; the reduce
-  // workgroups of the previous layer (if any) come last and run in the launch's tail
+  // longest jobs first: whichever body has the longer reduction per workgroup takes the low block indices
   const uint32_t b = blockIdx.x;
-  if (b >= nd + nw) { pp_reduce_body(PR, smem_pp, b - nd - nw, gridDim.x - nd - nw); return; }
   const bool is_w = wgrad_first ? b < nw : b >= nd;
   if (is_w) {
     pp_wgrad_body<2>(PW, smem_pp, wgrad_first ? b : b - nd, nw);
@@ -731,7 +675,7 @@ static bool pp_legal(const IgemmArgs& a, int variant) {
 // Which ping-pong tile the shared backward launch gives this layer's dgrad (PP_NONE: the layer's backward stays on the
 // igemm / tr bodies).  `a` = the dgrad GEMM (N = cin, Cred = cout, gathered tensor = dY).
 static int pp_bwd_dgrad_variant(const IgemmArgs& a) {
-  const int pp_bwd = tune_get("pp_bwd", -1);
+  const int pp_bwd = RIGL_TUNE("pp_bwd", -1);
   if (pp_bwd == 0) return PP_NONE;
   const int64_t m_out = (int64_t)(a.M / (a.RH * a.RW)) * a.GH * a.GW;
   // the weight gradient that shares the launch has 256-channel tiles: cin (= N here) and cout (= Cred) multiples of 256
@@ -741,7 +685,7 @@ static int pp_bwd_dgrad_variant(const IgemmArgs& a) {
   // longest parity class, ceil(KH / sh) x ceil(KW / sw) taps); 256x256 dgrad tiles where they give at least ~1/3 of the
   // CUs a tile (a strided dgrad counts the tiles of ONE class), the 128-row tiles below that
   const int kt_d = ((a.KH + a.sh - 1) / a.sh) * ((a.KW + a.sw - 1) / a.sw) * (a.Cred / 64);
-  if (kt_d < tune_get("pp_bwd_min_kt", 16)) return PP_NONE;     // (8-tile reductions measured neutral to slightly slower)
+  if (kt_d < RIGL_TUNE("pp_bwd_min_kt", 16)) return PP_NONE;     // (8-tile reductions measured neutral to slightly slower)
   const int64_t rows = a.M / (a.sh * a.sw);
   return ((rows + 255) / 256) * (a.N / 256) >= 90 ? PP_256x256 : PP_128x256;
 }
@@ -749,7 +693,7 @@ static int pp_bwd_dgrad_variant(const IgemmArgs& a) {
 template <int MODE>
 static PPPlan plan_pp(const IgemmArgs& a) {
   PPPlan p = {PP_NONE, 0u, 0, 0};
-  const int forced = tune_get(MODE == 0 ? "pp_fwd" : "pp_dgrad", -1);
+  const int forced = MODE == 0 ? RIGL_TUNE("pp_fwd", -1) : RIGL_TUNE("pp_dgrad", -1);
   int v = PP_NONE;
   if (forced >= 0) v = forced;
   else if (MODE == 0) {
@@ -780,7 +724,7 @@ static PPPlan plan_pp(const IgemmArgs& a) {
 // split.  Forward only: a layer's dX must have the same bits from the stand-alone dgrad and from the shared backward
 // launch, which does not split (its weight-gradient workgroups already fill the chip).
 static inline bool pp_ksplit_ok(const IgemmArgs& a, const PPPlan& p) {
-  if (!p.variant || tune_get("pp_ksplit", 1) == 0) return false;
+  if (!p.variant || RIGL_TUNE("pp_ksplit", 1) == 0) return false;
   const int kt = a.KH * a.KW * (a.Cred / 64);
   return 2 * (int64_t)p.grid <= (int64_t)num_cus() && kt >= 48;
 }
@@ -791,9 +735,7 @@ static bool launch_pp(const PPPlan& p, const IgemmArgs& a0, hipStream_t st) {
   a.fd_rw = make_fastdiv(a.RW); a.fd_rh = make_fastdiv(a.RH);
   a.tiles_n = a.N / p.bn;
   const dim3 grid(MODE == 0 && a.ksplit == 2 ? 2 * p.grid : p.grid);
-  // phases per K-tile: the 128x64 wave tiles run 2 (16 MFMAs between barriers; "pp_ph" = 4 selects one quadrant per
-  // phase), the 64x64 wave tiles 1 with three stages ("pp_ph" = 4 selects the four-phase, two-stage form)
-  const int ph = tune_get("pp_ph", 0);
+  // phases per K-tile: the 128x64 wave tiles run 2 (16 MFMAs between barriers), the 64x64 wave tiles 1 with three stages
   if constexpr (MODE == 1) {
     if (pp_strided(a)) {
       pp_fill_classes(a, p.bm);
@@ -807,14 +749,10 @@ static bool launch_pp(const PPPlan& p, const IgemmArgs& a0, hipStream_t st) {
     }
   }
   switch (p.variant) {
-    case PP_256x256:
-      return ph == 4 ? pp_launch_one<2, 4, 4, 2, 4, MODE>(grid, a, st) : pp_launch_one<2, 4, 4, 2, 2, MODE>(grid, a, st);
-    case PP_128x256:
-      return ph == 4 ? pp_launch_one<2, 4, 2, 2, 4, MODE>(grid, a, st) : pp_launch_one<2, 4, 2, 2, 1, MODE>(grid, a, st);
-    case PP_256x128:
-      return ph == 4 ? pp_launch_one<4, 2, 2, 2, 4, MODE>(grid, a, st) : pp_launch_one<4, 2, 2, 2, 1, MODE>(grid, a, st);
-    case PP_512x128:
-      return ph == 4 ? pp_launch_one<4, 2, 4, 2, 4, MODE>(grid, a, st) : pp_launch_one<4, 2, 4, 2, 2, MODE>(grid, a, st);
+    case PP_256x256: return pp_launch_one<2, 4, 4, 2, 2, MODE>(grid, a, st);
+    case PP_128x256: return pp_launch_one<2, 4, 2, 2, 1, MODE>(grid, a, st);
+    case PP_256x128: return pp_launch_one<4, 2, 2, 2, 1, MODE>(grid, a, st);
+    case PP_512x128: return pp_launch_one<4, 2, 4, 2, 2, MODE>(grid, a, st);
     default: return false;
   }
 }
@@ -843,7 +781,7 @@ static inline int pp_wgrad_max_splits(const RiglConvDesc* d) {
   const int64_t base = (int64_t)d->kh * d->kw * (d->cin / 256) * (d->cout / 256);
   const int64_t dw_bytes = (int64_t)d->kh * d->kw * d->cin * d->cout * 4;
   int64_t s = kt_all / 4;
-  const int64_t by_slots = (2 * (int64_t)num_cus() + base - 1) / base, by_bytes = ((int64_t)tune_get("pp_slab_mb", 40) << 20) / dw_bytes;
+  const int64_t by_slots = (2 * (int64_t)num_cus() + base - 1) / base, by_bytes = ((int64_t)RIGL_TUNE("pp_slab_mb", 40) << 20) / dw_bytes;
   if (s > by_slots) s = by_slots;
   if (s > by_bytes) s = by_bytes;
   return (int)(s < 1 ? 1 : s);
@@ -879,7 +817,7 @@ static PPBwdPlan plan_wgrad_pp(const RiglConvDesc* d, unsigned nd, int kt_d) {
 static WgradArgs pp_wgrad_args(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const PPBwdPlan& p, float* dw,
                                void* workspace) {
   WgradArgs a = {};
-  a.interleave = tune_get("wgrad_il", 1);
+  a.interleave = RIGL_TUNE("wgrad_il", 1);
   a.X = x; a.DY = dy; a.M = d->n * d->ho * d->wo; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw;
   a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_top; a.pw = d->pad_left;
   a.tiles_ci = p.tiles_ci; a.tiles_co = p.tiles_co; a.splits = p.splits; a.slab_elems = p.slab;
@@ -900,29 +838,27 @@ static bool pp_wgrad_launch(const PPBwdPlan& p, const WgradArgs& aw, hipStream_t
   return true;
 }
 template <int WMD, int WND, int TMD, int TND, int PHD, bool CLSD>
-static bool pp_bwd_launch_one(const IgemmArgs& ad, const WgradArgs& aw, const ReduceArgs& pr, unsigned nr, unsigned nd, unsigned nw,
-                              bool wgrad_first, hipStream_t st) {
+static bool pp_bwd_launch_one(const IgemmArgs& ad, const WgradArgs& aw, unsigned nd, unsigned nw, bool wgrad_first, hipStream_t st) {
   constexpr int SM_D = PPGeom<WMD, WND, TMD, TND, PHD>::SMEM, SM_W = PPGeom<2, 4, 4, 2, 2>::SMEM, SM = SM_D > SM_W ? SM_D : SM_W;
   static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_pp<WMD, WND, TMD, TND, PHD, CLSD>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM) == hipSuccess;
   if (!ready) return false;
-  RIGL_K_LAUNCH((k_bwd_pp<WMD, WND, TMD, TND, PHD, CLSD>), dim3(nd + nw + nr), dim3(512), SM, st, ad, aw, pr, nd, nw, (uint32_t)(wgrad_first ? 1u : 0u));
+  RIGL_K_LAUNCH((k_bwd_pp<WMD, WND, TMD, TND, PHD, CLSD>), dim3(nd + nw), dim3(512), SM, st, ad, aw, nd, nw, (uint32_t)(wgrad_first ? 1u : 0u));
   return true;
 }
 // dvar = the dgrad tile (256 output columns: the weight gradient's 256-channel tiles imply cin % 256 == 0), strided =
 // parity-class dgrad
-static bool pp_bwd_launch(int dvar, bool strided, const IgemmArgs& ad, const WgradArgs& aw, const PPBwdPlan& pw, const ReduceArgs& pr,
-                          unsigned nr, hipStream_t st) {
+static bool pp_bwd_launch(int dvar, bool strided, const IgemmArgs& ad, const WgradArgs& aw, const PPBwdPlan& pw, hipStream_t st) {
   if (strided) {
     switch (dvar) {
-      case PP_256x256: return pp_bwd_launch_one<2, 4, 4, 2, 2, true>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
-      case PP_128x256: return pp_bwd_launch_one<2, 4, 2, 2, 1, true>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
+      case PP_256x256: return pp_bwd_launch_one<2, 4, 4, 2, 2, true>(ad, aw, pw.nd, pw.nw, pw.wgrad_first, st);
+      case PP_128x256: return pp_bwd_launch_one<2, 4, 2, 2, 1, true>(ad, aw, pw.nd, pw.nw, pw.wgrad_first, st);
       default: return false;
     }
   }
   switch (dvar) {
-    case PP_256x256: return pp_bwd_launch_one<2, 4, 4, 2, 2, false>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
-    case PP_128x256: return pp_bwd_launch_one<2, 4, 2, 2, 1, false>(ad, aw, pr, nr, pw.nd, pw.nw, pw.wgrad_first, st);
+    case PP_256x256: return pp_bwd_launch_one<2, 4, 4, 2, 2, false>(ad, aw, pw.nd, pw.nw, pw.wgrad_first, st);
+    case PP_128x256: return pp_bwd_launch_one<2, 4, 2, 2, 1, false>(ad, aw, pw.nd, pw.nw, pw.wgrad_first, st);
     default: return false;
   }
 }

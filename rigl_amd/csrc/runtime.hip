@@ -1,5 +1,6 @@
 // Error channel, version, and the optional HIP-event profiler of the C ABI.
 #include <ctype.h>
+#include <atomic>
 #include <mutex>
 #include <stdlib.h>
 #include <string.h>
@@ -27,28 +28,47 @@ int fail(int code, const char* fmt, ...) {
 }
 
 // ---- development knobs ------------------------------------------------------
-struct Knob { char key[32]; int value; bool set; };
+struct Knob { char key[32]; int value; bool set; bool env_set; int env_value; };
 static std::mutex g_tune_mu;
 static std::vector<Knob> g_knobs;
+// Bumped by every rigl_tune_set / rigl_tune_unset: call sites keep (generation, value) in a static TuneSite and only
+// take the mutex and scan the table again after a change (the scan ran several times per conv / BN launch).
+static std::atomic<uint64_t> g_tune_gen{1};
 
-// A knob never set by rigl_tune_set reads the environment variable RIGL_<KEY IN UPPER CASE> once (so that
-// subprocess-per-setting test runners can select kernels the way they always did), else the caller's default.
-int tune_get(const char* key, int dflt) {
-  std::lock_guard<std::mutex> l(g_tune_mu);
-  for (const Knob& k : g_knobs)
-    if (strncmp(k.key, key, sizeof(k.key)) == 0) return k.set ? k.value : dflt;
+uint64_t tune_generation() { return g_tune_gen.load(std::memory_order_acquire); }
+
+static Knob* find_or_add_knob(const char* key) {
+  for (Knob& k : g_knobs)
+    if (strncmp(k.key, key, sizeof(k.key)) == 0) return &k;
   Knob k;
   memset(&k, 0, sizeof(k));
   strncpy(k.key, key, sizeof(k.key) - 1);
+  // A knob never set by rigl_tune_set reads the environment variable RIGL_<KEY IN UPPER CASE> once (so that
+  // subprocess-per-setting test runners can select kernels the way they always did), else the caller's default.
   char env[48] = "RIGL_";
   size_t n = 5;
   for (const char* c = key; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)toupper((unsigned char)*c);
   env[n] = 0;
   const char* e = getenv(env);
-  k.set = e != nullptr && *e != 0;
-  k.value = k.set ? atoi(e) : 0;
+  k.env_set = e != nullptr && *e != 0;
+  k.env_value = k.env_set ? atoi(e) : 0;
   g_knobs.push_back(k);
-  return k.set ? k.value : dflt;
+  return &g_knobs.back();
+}
+
+int tune_get(const char* key, int dflt) {
+  std::lock_guard<std::mutex> l(g_tune_mu);
+  const Knob* k = find_or_add_knob(key);
+  return k->set ? k->value : (k->env_set ? k->env_value : dflt);
+}
+
+int tune_cached(TuneSite& site, const char* key, int dflt) {
+  const uint64_t g = tune_generation();
+  if (site.gen.load(std::memory_order_acquire) == g) return site.value.load(std::memory_order_relaxed);
+  const int v = tune_get(key, dflt);
+  site.value.store(v, std::memory_order_relaxed);
+  site.gen.store(g, std::memory_order_release);
+  return v;
 }
 
 // ---- profiler ---------------------------------------------------------------
@@ -135,15 +155,22 @@ const char* rigl_last_error(void) { return rigl::g_err; }
 
 int rigl_tune_set(const char* key, int32_t value) {
   if (!key || !*key || strlen(key) >= sizeof(rigl::Knob::key)) return rigl::fail(RIGL_EINVAL, "rigl_tune_set: bad key");
+  if (value == INT32_MIN) return rigl_tune_unset(key);
   std::lock_guard<std::mutex> l(rigl::g_tune_mu);
-  for (rigl::Knob& k : rigl::g_knobs)
-    if (strcmp(k.key, key) == 0) { k.value = value; k.set = true; return RIGL_OK; }
-  rigl::Knob k;
-  memset(&k, 0, sizeof(k));
-  strncpy(k.key, key, sizeof(k.key) - 1);
-  k.value = value;
-  k.set = true;
-  rigl::g_knobs.push_back(k);
+  rigl::Knob* k = rigl::find_or_add_knob(key);
+  k->value = value;
+  k->set = true;
+  rigl::g_tune_gen.fetch_add(1, std::memory_order_acq_rel);
+  return RIGL_OK;
+}
+
+// Back to "never set": the knob reads its RIGL_<KEY> environment variable again, else every call site's own default.
+int rigl_tune_unset(const char* key) {
+  if (!key || !*key || strlen(key) >= sizeof(rigl::Knob::key)) return rigl::fail(RIGL_EINVAL, "rigl_tune_unset: bad key");
+  std::lock_guard<std::mutex> l(rigl::g_tune_mu);
+  rigl::Knob* k = rigl::find_or_add_knob(key);
+  k->set = false;
+  rigl::g_tune_gen.fetch_add(1, std::memory_order_acq_rel);
   return RIGL_OK;
 }
 

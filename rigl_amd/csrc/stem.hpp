@@ -26,7 +26,6 @@ struct StemArgs {
   float* STATS;          // [tiles * 2][2][64] or NULL
   int N, H, W, Ho, Wo, pt;
   int tiles_h, tiles_w, tiles;
-  int nt;                // output rows with non-temporal stores (knob "stem_nt")
 };
 
 // wp[co][r][kw' * 4 + c]  <-  w_ohwi[co][(r * 7 + kw' - 1) * 3 + c]   (0 for kw' = 0 and c = 3)
@@ -172,7 +171,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_stem_fwd(StemArgs P) {
         const int row = (h * 4 + p4) * 32 + (tid >> 3);
         const uint4 v = *reinterpret_cast<const uint4*>(ostage + row * STEM_OROW + chunk * 16);
         const int64_t m = ((int64_t)n * P.Ho + oh0 + (row >> 4)) * P.Wo + ow0 + (row & 15);
-        store16(P.Y + m * 64 + chunk * 8, v, P.nt);
+        store16(P.Y + m * 64 + chunk * 8, v);
         if (P.STATS) {
           const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -236,7 +235,6 @@ struct StemWgradArgs {
   int N, H, W, Ho, Wo, pt;
   int tiles_h, tiles_w, tiles;
   uint32_t dy_bytes;
-  int nt;                // dY tiles fetched with the non-temporal hint (knob "stem_wnt")
 };
 constexpr int STEMW_PROWS = 21, STEMW_PATCH = STEMW_PROWS * STEM_PW * 8;     // 8 064 B
 constexpr int STEMW_DY = 128 * 128;                                          // 16 384 B
@@ -282,8 +280,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_stem_wgrad(StemWgradArgs P) {
       const int i_ = q * 4 + wave, px_ = i_ * 8 + (lane >> 3);                                            \
       const int64_t m_ = ((int64_t)(n_) * P.Ho + (oh0_) + (px_ >> 4)) * P.Wo + (ow0_) + (px_ & 15);       \
       const int off_ = (int)((uint32_t)m_ * 128u + (uint32_t)(((lane & 7) ^ dual_swz<128>(px_)) << 4));   \
-      if (P.nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (__attribute__((address_space(3))) void*)((buf_) + i_ * 1024), 16, off_, 0, 0, 2); \
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (__attribute__((address_space(3))) void*)((buf_) + i_ * 1024), 16, off_, 0, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (__attribute__((address_space(3))) void*)((buf_) + i_ * 1024), 16, off_, 0, 0, 0); \
     }                                                                                                     \
   }
 
@@ -366,7 +363,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_stem_wgrad(StemWgradArgs P) {
 static inline bool stem_direct_legal(const RiglConvDesc* d) {
   return d->kh == 7 && d->kw == 7 && d->stride_h == 2 && d->stride_w == 2 && d->cin == 3 && d->cout == 64 && d->pad_left == 3 &&
          d->pad_top >= 0 && d->pad_top <= 3 && (d->ho % 16) == 0 && (d->wo % 16) == 0 && (d->w % 4) == 0 &&
-         tune_get("stem_direct", 1) != 0;
+         RIGL_TUNE("stem_direct", 1) != 0;
 }
 static bool launch_stem_fwd(const RiglConvDesc* d, const rigl_bf16* x, const uint16_t* wp, rigl_bf16* y, float* stats, hipStream_t st) {
   static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -376,7 +373,6 @@ static bool launch_stem_fwd(const RiglConvDesc* d, const rigl_bf16* x, const uin
   a.X = x; a.WP = wp; a.Y = y; a.STATS = stats;
   a.N = d->n; a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo; a.pt = d->pad_top;
   a.tiles_h = d->ho / 16; a.tiles_w = d->wo / 16; a.tiles = d->n * a.tiles_h * a.tiles_w;
-  a.nt = tune_get("stem_nt", 0);
   const int grid = a.tiles < 2 * num_cus() ? a.tiles : 2 * num_cus();
   RIGL_K_LAUNCH(k_stem_fwd, dim3((unsigned)grid), dim3(THREADS), STEM_SMEM, st, a);
   return true;
@@ -399,7 +395,6 @@ static bool launch_stem_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const r
   a.N = d->n; a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo; a.pt = d->pad_top;
   a.tiles_h = d->ho / 8; a.tiles_w = d->wo / 16; a.tiles = d->n * a.tiles_h * a.tiles_w;
   a.dy_bytes = (uint32_t)((size_t)d->n * d->ho * d->wo * 64 * 2);
-  a.nt = tune_get("stem_wnt", 0);
   RIGL_K_LAUNCH(k_stem_wgrad, dim3((unsigned)stem_wgrad_grid(d)), dim3(THREADS), STEMW_SMEM, st, a);
   return true;
 }

@@ -160,9 +160,6 @@ class GradSync:
 
   def _launch(self, lo, hi):
     if hi > lo:
-      if self.graph.G.is_cuda:
-        from rigl_amd import ops  # pylint: disable=import-outside-toplevel
-        ops.join_side_stream(self.graph.G.device)   # weight gradients may come from the side stream
       self._stamp(lo, hi - lo)
       self._handles.append(dist.all_reduce(self.graph.G[lo:hi], group=self.group, async_op=True))
 
@@ -179,8 +176,6 @@ class GradSync:
     if not parts:
       return
     if len(parts) == 2 and g.G.is_cuda and dist.get_backend(self.group) == 'nccl':
-      from rigl_amd import ops  # pylint: disable=import-outside-toplevel
-      ops.join_side_stream(g.G.device)
       self._stamp(parts[0][0], sum(h - lo for lo, h in parts))
       try:
         with dist._coalescing_manager(group=self.group, device=g.G.device, async_ops=True) as cm:   # pylint: disable=protected-access

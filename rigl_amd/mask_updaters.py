@@ -185,8 +185,6 @@ class MaskUpdater:
     g.zero_other_grads()
     loss = self._loss_fn(self.val_x, self.val_y)
     loss.backward()
-    ops.flush_pending_wgrad(g.device)
-    ops.join_side_stream(g.device)      # weight gradients may have been produced on the side stream
     sync = getattr(self._optimizer, '_grad_sync', None)
     if sync is not None:
       sync.all_reduce(g)

@@ -16,7 +16,6 @@ from rigl_amd._lib import (ConvDesc, PackLayer, PruneRegrowLayer,
                            PruneRegrowParams, RiglError, check)
 
 _workspaces = {}
-_retired_workspaces = []
 
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
@@ -49,31 +48,6 @@ def _req(t, dtype, name, allow_none=False):
     raise ValueError('%s must be contiguous' % name)
 
 
-# RIGL_WGRAD_STREAM=1: weight-gradient GEMMs go to a second HIP stream and overlap the dX chain
-# (measured +4.3 % images/s on ResNet-50 at N = 1).  Off by default: under concurrency every
-# kernel's own duration stretches, so per-launch timings (roofline.achieved, rocprof averages)
-# stop describing the kernels, and the multi-GPU path could not be exercised with it here.
-_SIDE_WGRAD = os.environ.get('RIGL_WGRAD_STREAM', '0') == '1'
-_side_streams = {}
-
-
-def side_stream(device):
-  """Second stream per device for the weight-gradient GEMMs (they do not feed the dX chain)."""
-  key = torch.device(device).index or 0
-  st = _side_streams.get(key)
-  if st is None:
-    st = _side_streams[key] = torch.cuda.Stream(device=device)
-  return st
-
-
-def join_side_stream(device):
-  """Makes the current stream wait for everything queued on the side stream."""
-  key = torch.device(device).index or 0
-  st = _side_streams.get(key)
-  if st is not None:
-    torch.cuda.current_stream(device).wait_stream(st)
-
-
 # Bumped whenever a scratch buffer is (re)allocated: a captured HIP graph holds the OLD buffer's address, so
 # train.GraphedStep drops its graphs when the generation it captured under is no longer current (ADVICE r2).
 WORKSPACE_GENERATION = 0
@@ -85,14 +59,13 @@ def workspace(nbytes, device, tag=''):
   key = (torch.device(device).index or 0, tag)
   ws = _workspaces.get(key)
   if ws is None or ws.numel() < nbytes:
-    old = ws
-    ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8,
-                     device=device)
+    # grow geometrically (at most O(log) reallocations per user); the outgrown buffer is simply released -- kernels already
+    # enqueued on it are safe (the caching allocator is stream-ordered) and train.GraphedStep compares WORKSPACE_GENERATION
+    # before EVERY replay, so a captured graph never runs against a released buffer
+    grown = max(int(nbytes), 1 << 20, (ws.numel() * 3 // 2) if ws is not None else 0)
+    ws = torch.empty(grown, dtype=torch.uint8, device=device)
     _workspaces[key] = ws
     WORKSPACE_GENERATION += 1
-    if old is not None:
-      # keep the outgrown buffer alive: graphs captured before the growth may still replay once before they notice
-      _retired_workspaces.append(old)
   return ws
 
 
@@ -420,27 +393,6 @@ def conv_wgrad(d, x, dy, dw=None, force_ref=False):
   return dw
 
 
-# RIGL_WGRAD_DEFER=1 hands every layer's split-K reduce to the next backward launch (as a third
-# workgroup segment) instead of launching it right after its own.  Measured neutral on ResNet-50
-# (the reduce workgroups still run in the launch's tail; 14.35 vs 14.36 ms/step), so it is opt-in.
-_DEFER = os.environ.get('RIGL_WGRAD_DEFER', '0') == '1'
-_pending = {}        # device index -> [PendingReduce, workspace tag, done_callback]
-
-
-def flush_pending_wgrad(device=None):
-  """Runs the split-K reduce a backward launch left for its successor (the last layer of a
-  backward pass has none).  Called after backward and before anything reads the gradients."""
-  keys = list(_pending) if device is None else [torch.device(device).index or 0]
-  for key in keys:
-    ent = _pending.pop(key, None)
-    if ent is None:
-      continue
-    pr, _tag, done = ent
-    check(_lib.load().rigl_wgrad_reduce_pending(C.byref(pr), _stream()))
-    if done is not None:
-      done()
-
-
 def dgrad_stats_parts(d):
   """Row tiles of this layer's dgrad kernel = rows of the batch-norm partials its epilogue can leave
   (0: the layer's dgrad has no such epilogue)."""
@@ -451,22 +403,18 @@ def dgrad_stats_parts(d):
 
 
 def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None, bn_fuse=None):
-  """dW (into ``dw``, dense fp32) and -- when ``need_dx`` -- dX (+ ``addend``) of
-  one conv with a single host transition and, for ordinary layers, a single launch
-  (rigl_masked_conv2d_bwd_deferred) followed by the split-K reduce that completes dW.
-  With RIGL_WGRAD_DEFER=1 that reduce is handed to the NEXT conv_bwd call, which runs it
-  as a third segment of its own launch; ``flush_pending_wgrad`` finishes the last one.
-  ``on_dw_ready`` is called once dW's reduce has been enqueued (now, or when the next
-  call / the flush picks it up).  Returns dX or None.
+  """dW (into ``dw``, dense fp32) and -- when ``need_dx`` -- dX (+ ``addend``) of one conv with a single host
+  transition and, for ordinary layers, a single launch (rigl_masked_conv2d_bwd) followed by the split-K reduce that
+  completes dW.  ``on_dw_ready`` is called once dW's last kernel has been enqueued (the data-parallel exchange launches
+  its buckets from there).  Returns dX or None.
   ``bn_fuse`` = dict(x=, saved=, relu=, relu_bits=) of the batch norm whose output this conv read: its backward
   reductions are computed in the dgrad epilogue (rigl_masked_conv2d_bwd_bn) and returned as
   ``bn_fuse['partials']`` (fp32 [parts, 2, Cin]) for bn_bwd; left unset where the layer's kernels cannot."""
   if bn_fuse is not None:
     bn_fuse.pop('partials', None)
-    if not (need_dx and not _SIDE_WGRAD and mfma_supported(d) and mfma_dgrad_supported(d) and dgrad_stats_parts(d) > 0):
+    if not (need_dx and mfma_supported(d) and mfma_dgrad_supported(d) and dgrad_stats_parts(d) > 0):
       bn_fuse = None
   if not (mfma_supported(d) and (not need_dx or mfma_dgrad_supported(d))):
-    flush_pending_wgrad(x.device)
     conv_wgrad(d, x, dy, dw)
     if on_dw_ready is not None:
       on_dw_ready()
@@ -477,38 +425,18 @@ def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None, 
   _req(addend, torch.bfloat16, 'addend', allow_none=True)
   lib = _lib.load()
   _count_macs('wgrad_macs', d)
-  if need_dx and not _SIDE_WGRAD:        # (the side-stream path goes through conv_dgrad, which counts)
+  if need_dx:
     _count_macs('dgrad_macs', d)
   need = getattr(d, '_ws_wgrad', None)
   if need is None:
     need = d._ws_wgrad = lib.rigl_conv2d_workspace_bytes(C.byref(d), 2)
-  if _SIDE_WGRAD:
-    # wgrad on the side stream (own workspace), dgrad on the main one: the two overlap
-    flush_pending_wgrad(x.device)
-    main, side = torch.cuda.current_stream(x.device), side_stream(x.device)
-    side.wait_stream(main)
-    ws = workspace(need, x.device, 'side') if need else None
-    check(lib.rigl_masked_conv2d_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws),
-                                       ws.numel() if ws is not None else 0, C.c_void_p(side.cuda_stream)))
-    x.record_stream(side)
-    dy.record_stream(side)
-    # only now is dW's producer enqueued: a bucket launched from this callback joins the side stream first
-    # (GradSync._launch), so the collective is ordered after the weight-gradient kernel, never before it
-    if on_dw_ready is not None:
-      on_dw_ready()
-    return conv_dgrad(d, dy, w_hwio, addend=addend) if need_dx else None
-  key = x.device.index or 0
-  prev = _pending.pop(key, None)
-  # slabs are double-buffered: the layer before may still be waiting for its reduce
-  tag = 'wgB' if (prev is not None and prev[1] == 'wgA') else 'wgA'
-  ws = workspace(need, x.device, tag) if need else None
+  ws = workspace(need, x.device, 'wg') if need else None
   dx = None
   if need_dx:
     _req(w_hwio, torch.bfloat16, 'w_hwio')
     dx = torch.empty((d.n, d.h, d.w, d.cin), dtype=torch.bfloat16, device=dy.device)
     if addend is not None and addend.numel() != dx.numel():
       raise ValueError('addend must have the shape of dx')
-  mine = _lib.PendingReduce() if _DEFER else None
   bn = None
   if bn_fuse is not None:
     bx, saved = bn_fuse['x'], bn_fuse['saved']
@@ -524,13 +452,8 @@ def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None, 
     bn_fuse['partials'] = part
   check(lib.rigl_masked_conv2d_bwd_bn(
       C.byref(d), _ptr(x), _ptr(dy), _ptr(w_hwio), _ptr(addend), _ptr(dw), _ptr(dx), _ptr(ws),
-      ws.numel() if ws is not None else 0, C.byref(prev[0]) if prev is not None else None,
-      C.byref(mine) if mine is not None else None, C.byref(bn) if bn is not None else None, _stream()))
-  if prev is not None and prev[2] is not None:
-    prev[2]()                              # the previous layer's dW is now complete in stream order
-  if mine is not None and mine.splits > 0:
-    _pending[key] = [mine, tag, on_dw_ready]
-  elif on_dw_ready is not None:
+      ws.numel() if ws is not None else 0, C.byref(bn) if bn is not None else None, _stream()))
+  if on_dw_ready is not None:
     on_dw_ready()
   return dx
 
@@ -846,6 +769,11 @@ def softmax_xent(logits, labels, label_smoothing=0.0, grad_scale=None, want_grad
 def tune_set(key, value):
   """Process-wide kernel-selection knob (rigl_tune_set); descriptors cache plan-dependent sizes, so make new ones."""
   check(_lib.load().rigl_tune_set(key.encode(), int(value)))
+
+
+def tune_unset(key):
+  """Back to the knob's RIGL_<KEY> environment variable / built-in default (rigl_tune_unset)."""
+  check(_lib.load().rigl_tune_unset(key.encode()))
 
 
 def tune_get(key, default=-1):

@@ -79,8 +79,6 @@ class GradientDescentOptimizer(Optimizer):
     if loss is not None and self._backward_done_for is not loss:
       g.zero_other_grads()
       loss.backward()
-      ops.flush_pending_wgrad(g.device)   # the last layer's split-K reduce has no successor launch to ride on
-      ops.join_side_stream(g.device)      # weight gradients may have been produced on the side stream
       self._backward_done_for = loss
       if self._grad_sync is not None:
         self._grad_sync.all_reduce(g)
@@ -228,8 +226,9 @@ class GraphedStep:
     self.replays = 0
     self.eager_steps = 0
     self._ws_gen = ops.WORKSPACE_GENERATION
-    self._misses = 0
-    self._warmup_steps = warmup
+    self._last_key = None      # learning-rate key of the previous ordinary step and how many steps it has been stable
+    self._stable = 0
+    self._stable_needed = 1    # capture at the second consecutive ordinary step with the same learning rate
 
   def _is_update(self):
     o = self._opt
@@ -248,18 +247,22 @@ class GraphedStep:
       return self._eager()
     key = _lr_value(self._inner._lr, self._gs)                   # pylint: disable=protected-access
     if self._ws_gen != ops.WORKSPACE_GENERATION:
-      # an eager step (a mask update, typically) outgrew a scratch buffer after the capture: the graphs point at the old
-      # one -- drop them and capture again (the old buffers stay allocated, so nothing was overwritten meanwhile)
+      # a scratch buffer was (re)allocated since the graphs were captured (an eager mask update outgrew one, typically):
+      # EVERY cached graph may point at the old buffer -- drop them all and capture again.  Checked before every replay,
+      # so no graph is ever replayed against a freed buffer (ops.workspace keeps nothing alive for them).
       self._graphs.clear()
       self._ws_gen = ops.WORKSPACE_GENERATION
     ent = self._graphs.get(key)
     if ent is None:
-      self._misses += 1
-      if self._misses > 8 + self._warmup_steps:
-        #  many steps in a row without one replay: the learning rate changes every step (warm-up, cosine), so a
-        # graph keyed on its value is never reused -- stop capturing and run plain eager steps on the current stream
-        self._eager_only = True
-        self._graphs.clear()
+      #  a learning rate that changes every step (linear warm-up, cosine) never reuses a graph keyed on its
+      # value: while the key keeps changing, run plain eager steps and do not capture; once it has been stable for
+      # `_stable_needed` consecutive steps (the constant plateaus of a piecewise schedule), capture again.
+      if key == self._last_key:
+        self._stable += 1
+      else:
+        self._stable = 0
+        self._last_key = key
+      if self._stable < self._stable_needed:
         return self._eager()
       if self._warmup > 0:                                         # allocator / workspace caches / descriptors settle first
         self._warmup -= 1
@@ -272,19 +275,25 @@ class GraphedStep:
       torch.cuda.synchronize()
       if self._is_update() or _lr_value(self._inner._lr, self._gs) != key:   # pylint: disable=protected-access
         return out                                                 # the next iteration is not an ordinary one at this lr: capture later
+      gen0 = ops.WORKSPACE_GENERATION
       step1 = self._gs.value
       graph = torch.cuda.CUDAGraph()
       with torch.cuda.graph(graph):
         loss = self._loss_fn()
         self._opt.minimize(loss, self._gs)                         # capture enqueues nothing; undo its host side effect:
       self._gs.value = step1
+      if gen0 != ops.WORKSPACE_GENERATION or gen0 != self._ws_gen:
+        # a buffer grew during the pre-capture step or the capture itself: graphs cached under other learning rates are
+        # stale, and this one may hold both addresses -- keep none, the next call captures on settled buffers
+        self._graphs.clear()
+        self._ws_gen = ops.WORKSPACE_GENERATION
+        return out
       if len(self._graphs) >= 16:
         self._graphs.pop(next(iter(self._graphs)))                 # bound the cache (piecewise-constant schedules have few values)
       self._graphs[key] = (graph, loss)
-      self._ws_gen = ops.WORKSPACE_GENERATION
       return out
     graph, loss = ent
-    self._misses = 0
+    self._last_key, self._stable = key, self._stable_needed
     graph.replay()
     self._gs.value += 1
     self._inner.graph.shadows_dirty = True                         # the replayed update rewrote the weights

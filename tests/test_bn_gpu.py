@@ -151,7 +151,7 @@ def test_bn_bwd_reductions_in_the_dgrad_epilogue(case):
   try:
     _bn_bwd_reductions_case(case)
   finally:
-    ops.tune_set('pp_bwd', -1)
+    ops.tune_unset('pp_bwd')
 
 
 def _bn_bwd_reductions_case(case):
@@ -179,10 +179,8 @@ def _bn_bwd_reductions_case(case):
   assert ops.dgrad_stats_parts(d) > 0
   dw0, dw1 = torch.empty_like(w), torch.empty_like(w)
   dx0 = ops.conv_bwd(d, y, dy, hwio, dw0, need_dx=True, addend=addend)
-  ops.flush_pending_wgrad()
   req = dict(x=x_bn, saved=saved, relu=relu, relu_bits=bits)
   dx1 = ops.conv_bwd(d, y, dy, hwio, dw1, need_dx=True, addend=addend, bn_fuse=req)
-  ops.flush_pending_wgrad()
   assert req.get('partials') is not None and req['partials'].shape == (ops.dgrad_stats_parts(d), 2, Cin)
   assert torch.equal(dx0, dx1) and torch.equal(dw0, dw1)
   dg0, db0, dg1, db1 = [torch.empty(Cin, device=DEV) for _ in range(4)]
@@ -337,7 +335,6 @@ def test_bottleneck_with_projection_shortcut_fused_equals_unfused():
     dy = torch.randn(y.shape, generator=gen, device=DEV).to(torch.bfloat16)
     y.backward(dy)
     from rigl_amd import ops
-    ops.flush_pending_wgrad()
     res.append((y.detach().clone(), x.grad.clone(), g.G.clone()))
   gnn._BN_PAIR_FUSED = True
   (y1, dx1, G1), (y0, dx0, G0) = res

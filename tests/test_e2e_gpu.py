@@ -330,8 +330,6 @@ def test_resnet50_every_conv_in_situ_and_loss_vs_cpu_oracle(rn50):
 
   def bwd(ctx, dy, _dpart=None):
     out = bwd0(ctx, dy)
-    ops.flush_pending_wgrad(dy.device)     # dW's split-K reduce normally rides on the next layer's launch
-    ops.join_side_stream(dy.device)        # RIGL_WGRAD_STREAM=1: dW is produced on the side stream
     ctx.rec.update(dy=dy.detach().clone(), dx=None if out[0] is None else out[0].detach().clone(),
                    dw=ctx.lv.weights.grad.detach().clone())
     return out
@@ -347,8 +345,6 @@ def test_resnet50_every_conv_in_situ_and_loss_vs_cpu_oracle(rn50):
 
   def fbwd(ctx, dy, dalias, _dpart=None):
     out = fbwd0(ctx, dy, dalias)
-    ops.flush_pending_wgrad(dy.device)
-    ops.join_side_stream(dy.device)
     ctx.rec.update(dy=dy.detach().clone(), dx=out[0].detach().clone(), dw=ctx.lv.weights.grad.detach().clone(),
                    dadd=None if dalias is None else dalias.detach().clone())
     return out

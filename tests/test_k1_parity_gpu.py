@@ -32,7 +32,6 @@ PP_SETTINGS = [
     {'RIGL_PP_FWD': '2', 'RIGL_PP_DGRAD': '2'},                                  # 128x256 (one phase, three stages)
     {'RIGL_PP_FWD': '3', 'RIGL_PP_DGRAD': '3'},                                  # 256x128
     {'RIGL_PP_FWD': '4', 'RIGL_PP_DGRAD': '4'},                                  # 512x128
-    {'RIGL_PP_FWD': '1', 'RIGL_PP_DGRAD': '2', 'RIGL_PP_PH': '4'},               # the four-phase schedule of both wave tiles
     {'RIGL_PP_FWD': '0', 'RIGL_PP_DGRAD': '0'},                                  # the igemm body everywhere
     {'RIGL_PP_KSPLIT': '0'},                                                     # no K split of the few-tile forwards (on by default)
 ]
@@ -46,7 +45,7 @@ def test_small_shapes(env):
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
-@pytest.mark.parametrize('env', PP_SETTINGS[:6])
+@pytest.mark.parametrize('env', PP_SETTINGS[:5])
 def test_pingpong_edge_shapes(env):
   """1 .. 36 K-tiles (every prologue / tail branch of the ring), ragged row tiles, stride-2 forwards, TF-SAME asymmetric
   padding, 128- / 256-wide column tiles -- each ping-pong tile forced wherever it is legal, against the fp64 reference."""
@@ -56,8 +55,7 @@ def test_pingpong_edge_shapes(env):
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
 @pytest.mark.parametrize('env', PP_SETTINGS[:3] + PP_SETTINGS[4:5] + [
-    {'RIGL_BWD1X1_256X64': '1', 'RIGL_BWD1X1_WGS': '1'},     # single-pass 1x1 backward: the third shape class, the 7-deep ring
-    {'RIGL_BWD1X1': '0', 'RIGL_STEM_DIRECT': '0', 'RIGL_WGRAD_IL': '0'},   # round-2 paths of those layers
+    {'RIGL_BWD1X1': '0', 'RIGL_STEM_DIRECT': '0', 'RIGL_WGRAD_IL': '0', 'RIGL_C3X3': '0'},   # the generic bodies on the layers with kernels of their own
 ])
 def test_resnet50_layer_shapes_at_batch_128(env):
   """All distinct ResNet-50 conv shapes at the benchmarked per-GPU batch: fwd, fwd + statistics,

@@ -82,7 +82,6 @@ def main():
         t_w = timeit(lambda: ops.conv_wgrad(d, x, dy, dw), a.iters)
         # dgrad + wgrad as the training step runs them: one launch (rigl_masked_conv2d_bwd)
         t_b = timeit(lambda: ops.conv_bwd(d, x, dy, w, dw, need_dx=Cin % 8 == 0), a.iters)
-        ops.flush_pending_wgrad()
         seen[key] = (t_f, t_d, t_w, t_b)
         del x, dy, w, y, dx, dw
       except Exception as e:  # pylint: disable=broad-except

@@ -58,7 +58,6 @@ def main():
       ops.bn_bwd(xbn, None, dx, gamma, saved, True, dg, db, partials=part)
     print('%-5s conv_bwd %6.1f us | with reductions %6.1f us | bn_bwd %6.1f us | bn_bwd given partials %6.1f us' %
           (name, timeit(plain), timeit(fused), timeit(bn_plain), timeit(bn_fused)), flush=True)
-    ops.flush_pending_wgrad()
 
 
 if __name__ == '__main__':

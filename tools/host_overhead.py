@@ -46,7 +46,6 @@ def main():
   def fb():
     out = bn(conv(x, True), True, relu=True)
     out.float().sum().backward()
-    ops.flush_pending_wgrad()
   t(fb, 'conv + BN fwd + bwd (incl. sum/cast)')
   t(lambda: ops._stream(), 'ops._stream()')
   t(lambda: torch.empty(2, 4, 4, 16, device=dev, dtype=torch.bfloat16), 'torch.empty')

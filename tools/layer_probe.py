@@ -60,7 +60,6 @@ def main():
       def f():
         ops.conv_bwd(d, x, dy, w, dw, need_dx=True)
       r.append('bwd %6.1f' % timeit(f))
-      ops.flush_pending_wgrad()
     out.append(' '.join(r))
   print(' | '.join(out), flush=True)
 

@@ -89,8 +89,7 @@ def bwd_rows(a, rep, name, B, H, W, Cin, Cout, k, s, pt, pl, Ho, Wo, macs, x, dy
         dw = torch.empty(n, dtype=torch.float32, device=DEV)
         if ps == 'bwd':
           dx = ops.conv_bwd(d, x, dy, hwio, dw, need_dx=has_dx, addend=add if has_dx else None)
-          ops.flush_pending_wgrad()
-          run = lambda: (ops.conv_bwd(d, x, dy, hwio, dw, need_dx=has_dx, addend=add if has_dx else None), ops.flush_pending_wgrad())
+          run = lambda: (ops.conv_bwd(d, x, dy, hwio, dw, need_dx=has_dx, addend=add if has_dx else None))
         else:
           ops.conv_wgrad(d, x, dy, dw)
           dx = None
@@ -110,7 +109,6 @@ def bwd_rows(a, rep, name, B, H, W, Cin, Cout, k, s, pt, pl, Ho, Wo, macs, x, dy
         dw2 = torch.empty_like(dw)
         if ps == 'bwd':
           ops.conv_bwd(d, x, dy, hwio, dw2, need_dx=has_dx, addend=add if has_dx else None)
-          ops.flush_pending_wgrad()
         else:
           ops.conv_wgrad(d, x, dy, dw2)
         if not torch.equal(dw.view(torch.int32), dw2.view(torch.int32)):

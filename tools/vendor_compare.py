@@ -47,7 +47,6 @@ def main():
       r = dict(ours_fwd=timeit(lambda: ops.conv_fwd(d, x, w, y), a.iters),
                ours_dgrad=timeit(lambda: ops.conv_dgrad(d, dy, w, dx), a.iters),
                ours_wgrad=timeit(lambda: ops.conv_wgrad(d, x, dy, dw), a.iters))
-      ops.flush_pending_wgrad()
       # MIOpen: NCHW-shaped channels_last views of the same NHWC memory, OIHW-shaped channels_last weights
       xv, dyv = x.permute(0, 3, 1, 2), dy.permute(0, 3, 1, 2)
       wv = torch.randn(Cout, Cin, k, k, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
