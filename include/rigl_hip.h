@@ -142,7 +142,10 @@ int rigl_prune_regrow(const RiglPruneRegrowLayer* layers /* host */,
  * (out_counts[2]) resp. n_prune (out_counts[1]) entries are the selected ones,
  * the entries behind them are the rest of the tensor in the same order.  The
  * tensor is updated exactly as by rigl_prune_regrow.  A test / inspection
- * entry point: one stable 33-bit radix sort of the whole tensor per list.   */
+ * entry point: one stable 33-bit radix sort of the whole tensor per list.
+ * ORDER: the update (weights, mask, momentum) is enqueued FIRST, the two sorts
+ * after it; if enqueueing a sort fails the call returns an error with the
+ * tensor already updated and out_idx1 / out_idx2 undefined.                 */
 size_t rigl_prune_regrow_selections_workspace_bytes(int64_t n);
 int rigl_prune_regrow_selections(const RiglPruneRegrowLayer* layer /* host */,
                                  const RiglPruneRegrowParams* params,
@@ -542,6 +545,18 @@ int rigl_softmax_xent(int32_t rows, int32_t classes, const rigl_bf16* logits,
 #define RIGL_PROF_KINDS 8
 int rigl_prof_enable(int32_t on);
 int rigl_prof_collect(double* ms_per_kind /*[8]*/, int64_t* launches /*[8]*/);
+/* The same events one by one, in launch order (instead of rigl_prof_collect,
+ * which consumes them too): kind as above; tag = (h, w, cin, cout, kh, stride_h)
+ * of the conv descriptor the launch belongs to (zeros for K2 / K3 / pack); ms =
+ * that dispatch's own duration.  Writes at most `cap` records, returns the
+ * number of recorded launches in *n_launches (the rest is dropped).  For the
+ * per-layer IN-STEP table of tools/instep_table.py.    */
+typedef struct RiglProfLaunch {
+  int32_t kind;
+  int32_t tag[6];
+  float ms;
+} RiglProfLaunch;
+int rigl_prof_collect_launches(RiglProfLaunch* out /* host */, int64_t cap, int64_t* n_launches);
 
 /* Measurement aid (the MFMA peak "re-measured on the box"):
  * enqueues blocks x 4 waves, each issuing iters x 8 independent

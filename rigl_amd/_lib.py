@@ -73,6 +73,11 @@ class RandomItem(C.Structure):
               ('dist', C.c_int32), ('scale', C.c_float), ('shift', C.c_float)]
 
 
+class ProfLaunch(C.Structure):
+  """RiglProfLaunch: one timed K1 / K2 / K3 dispatch."""
+  _fields_ = [('kind', C.c_int32), ('tag', C.c_int32 * 6), ('ms', C.c_float)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/rigl_hip.h
 _P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -140,6 +145,7 @@ SIGNATURES = {
     'rigl_softmax_xent': (C.c_int, [_I32, _I32, _P, _P, _F, _F, _P, _P, _P]),
     'rigl_prof_enable': (C.c_int, [_I32]),
     'rigl_prof_collect': (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64)]),
+    'rigl_prof_collect_launches': (C.c_int, [C.POINTER(ProfLaunch), _I64, C.POINTER(_I64)]),
     'rigl_probe_mfma_bf16': (C.c_int, [_I32, _I32, _P, _P]),
     'rigl_tune_set': (C.c_int, [C.c_char_p, _I32]),
     'rigl_tune_get': (_I32, [C.c_char_p, _I32]),

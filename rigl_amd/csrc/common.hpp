@@ -55,6 +55,7 @@ void prof_end(int kind, hipStream_t s);
 hipEvent_t prof_get_event();
 void prof_add_pair(int kind, hipEvent_t a, hipEvent_t b);
 int& prof_current_kind();
+void prof_set_tag(const RiglConvDesc* d);      // the conv descriptor the following K1 launches of this thread belong to
 struct ProfFamily {
   int prev;
   explicit ProfFamily(int k) : prev(prof_current_kind()) { prof_current_kind() = k; }

@@ -1426,6 +1426,7 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, cons
     return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_fwd_stats: stats buffer %zu floats < %zu", stats_floats,
                 (size_t)rigl_conv2d_stats_parts(d) * 2 * d->cout);
   hipStream_t st = as_stream(stream);
+  prof_set_tag(d);
   ProfFamily prof(PROF_CONV_FWD);
   IgemmArgs a = {};
   a.C = y; a.M = d->n * d->ho * d->wo; a.N = d->cout; a.ldc = d->cout; a.STATS = stats;
@@ -1550,6 +1551,7 @@ static int dgrad_impl(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf1
   if (!dy || !w_hwio || !dx) return fail(RIGL_EINVAL, "rigl_masked_conv2d_dgrad: NULL tensor");
   if ((d->cin % 8) || (d->cout % 8)) return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_dgrad: cin/cout %% 8 != 0 (use the reference kernel)");
   hipStream_t st = as_stream(stream);
+  prof_set_tag(d);
   ProfFamily prof(PROF_CONV_DGRAD);
   if (!bn && bwd1x1_kind(d)) {
     // the big-M 1x1 layers: dX from the single-pass backward kernel (without its weight-gradient half), so that it has
@@ -1588,6 +1590,7 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
   hipStream_t st = as_stream(stream);
   const size_t need = rigl_conv2d_workspace_bytes(d, 2);
   if (need && (!workspace || workspace_bytes < need)) return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
+  prof_set_tag(d);
   ProfFamily prof(PROF_CONV_WGRAD);
   if (RIGL_TUNE("pp_wgrad", -1) > 0 && !tiny_cin(d) && !small_cin(d) && pp_wgrad_legal(d)) {
     const PPBwdPlan pw = plan_wgrad_pp(d, 0u, 0);
@@ -1692,6 +1695,7 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
   int rc = check_desc(d, "rigl_masked_conv2d_bwd");
   if (rc) return rc;
   hipStream_t st = as_stream(stream);
+  prof_set_tag(d);
   const bool whole = dx && x && dy && w_hwio && dw;        // both gradients asked for, every operand there
   const size_t need = rigl_conv2d_workspace_bytes(d, 2);
   // A layer's dX must come from the same kernel whichever entry point computes it (rigl_masked_conv2d_dgrad or this

@@ -74,7 +74,7 @@ int tune_cached(TuneSite& site, const char* key, int dflt) {
 // ---- profiler ---------------------------------------------------------------
 // Event pairs are recorded on the launch stream, so the measured interval is
 // the device-side duration of exactly the kernels launched in between.
-struct EvPair { hipEvent_t a, b; int kind; };
+struct EvPair { hipEvent_t a, b; int kind; int tag[6]; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<EvPair> g_pending;
@@ -92,9 +92,22 @@ static hipEvent_t get_event() {
 }
 
 hipEvent_t prof_get_event() { return get_event(); }
+static thread_local int t_tag[6] = {0, 0, 0, 0, 0, 0};
+void prof_set_tag(const RiglConvDesc* d) {
+  if (d) { t_tag[0] = d->h; t_tag[1] = d->w; t_tag[2] = d->cin; t_tag[3] = d->cout; t_tag[4] = d->kh; t_tag[5] = d->stride_h; }
+  else for (int i = 0; i < 6; ++i) t_tag[i] = 0;
+}
+static EvPair make_pair(int kind, hipEvent_t a, hipEvent_t b) {
+  EvPair p;
+  p.a = a; p.b = b; p.kind = kind;
+  const bool conv = kind == PROF_CONV_FWD || kind == PROF_CONV_DGRAD || kind == PROF_CONV_WGRAD || kind == PROF_CONV_BWD ||
+                    kind == PROF_DEPTHWISE;
+  for (int i = 0; i < 6; ++i) p.tag[i] = conv ? t_tag[i] : 0;
+  return p;
+}
 void prof_add_pair(int kind, hipEvent_t a, hipEvent_t b) {
   std::lock_guard<std::mutex> l(g_prof_mu);
-  g_pending.push_back({a, b, kind});
+  g_pending.push_back(make_pair(kind, a, b));
 }
 int& prof_current_kind() {
   static thread_local int k = PROF_CONV_FWD;
@@ -114,7 +127,7 @@ void prof_end(int kind, hipStream_t s) {
   if (!b) return;
   (void)hipEventRecord(b, s);
   std::lock_guard<std::mutex> l(g_prof_mu);
-  g_pending.push_back({a, b, kind});
+  g_pending.push_back(make_pair(kind, a, b));
 }
 
 }  // namespace rigl
@@ -200,6 +213,32 @@ int rigl_prof_collect(double* ms_per_kind, int64_t* launches) {
     rigl::g_pool.push_back(p.a);
     rigl::g_pool.push_back(p.b);
   }
+  return RIGL_OK;
+}
+
+int rigl_prof_collect_launches(RiglProfLaunch* out, int64_t cap, int64_t* n_launches) {
+  if (!n_launches || (cap > 0 && !out)) return rigl::fail(RIGL_EINVAL, "rigl_prof_collect_launches: NULL output");
+  std::vector<rigl::EvPair> pend;
+  {
+    std::lock_guard<std::mutex> l(rigl::g_prof_mu);
+    pend.swap(rigl::g_pending);
+  }
+  int64_t n = 0;
+  for (auto& p : pend) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      if (n < cap) {
+        out[n].kind = p.kind;
+        for (int i = 0; i < 6; ++i) out[n].tag[i] = p.tag[i];
+        out[n].ms = ms;
+      }
+      ++n;
+    }
+    std::lock_guard<std::mutex> l(rigl::g_prof_mu);
+    rigl::g_pool.push_back(p.a);
+    rigl::g_pool.push_back(p.b);
+  }
+  *n_launches = n;
   return RIGL_OK;
 }
 

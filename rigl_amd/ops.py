@@ -800,6 +800,15 @@ def prof_enable(on=True):
   check(_lib.load().rigl_prof_enable(int(bool(on))))
 
 
+def prof_collect_launches(cap=1 << 16):
+  """[(kind name, (h, w, cin, cout, k, stride), ms)] of every timed dispatch since the last collect, in launch order
+  (rigl_prof_collect_launches; consumes the events like prof_collect)."""
+  arr = (_lib.ProfLaunch * cap)()
+  n = C.c_int64(0)
+  check(_lib.load().rigl_prof_collect_launches(arr, cap, C.byref(n)))
+  return [(_lib.PROF_KINDS[arr[i].kind], tuple(arr[i].tag), float(arr[i].ms)) for i in range(min(n.value, cap))]
+
+
 def prof_collect():
   """{kind: (milliseconds, launches)} accumulated since the last collect."""
   ms = (C.c_double * len(_lib.PROF_KINDS))()
