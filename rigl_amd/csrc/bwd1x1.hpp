@@ -190,10 +190,22 @@ __global__ __launch_bounds__(THREADS) void k_bwd1x1(Bwd1x1Args P) {
     } else {
       wait_vmcnt<0>();
     }
+    // this wave's dX tile of the previous iteration (ds_write, read by OTHER waves in B1_FLUSH below) must have reached
+    // the LDS before the barrier releases them: a raw s_barrier does not wait for LDS writes (round 4: dX wrong in ~1 run
+    // of 10 at batch 128 -- the __syncthreads() this loop avoids, to keep the DMA in flight, had implied this wait)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    // The counted waits above assume THIS program order of the vector-memory operations of an iteration: stage DMA, the
+    // stores of the previous tile, the addend loads of this tile.  Nothing else orders them for the compiler (round 4:
+    // with the branches of a removed knob gone it hoisted the addend loads above the DMA issue, the wait then left one
+    // DMA piece of the tile being read in flight, and dX + addend was wrong in 1 run of 4) -- so the order is pinned.
     if (kt + NST - 1 < KT) B1_ISSUE(kt + NST - 1, (kt + NST - 1) % NST);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     if (kt > 0) B1_FLUSH(kt - 1, !DXDB);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     const unsigned char* Ys = smem + (kt % NST) * STAGE;
     const unsigned char* Xs = Ys + Y_BYTES;
     if (P.ADD) {
@@ -204,6 +216,8 @@ __global__ __launch_bounds__(THREADS) void k_bwd1x1(Bwd1x1Args P) {
         addv[q] = p0 + row < P.M ? *reinterpret_cast<const uint4*>(P.ADD + (int64_t)(p0 + row) * CI + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
       }
     }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     // ---- dX tile: D[ci][px] = W-fragment x dY-fragment --------------------------------------------------------------------
     f32x4 acc1[CFW];
 #pragma unroll

@@ -1297,6 +1297,7 @@ static inline int kpad(const RiglConvDesc* d) { return (d->kh * d->kw * d->cin +
 #include "convpp.hpp"
 #include "bwd1x1.hpp"
 #include "stem.hpp"
+#include "c3x3.hpp"
 
 // Scratch of the K-split ping-pong forward (convpp.hpp: pp_ksplit_ok): two fp32 partial tiles + a counter per tile.
 static size_t pp_ksplit_workspace(const RiglConvDesc* d) {
@@ -1401,6 +1402,8 @@ size_t rigl_conv2d_workspace_bytes(const RiglConvDesc* d, int32_t which) {
     if (npp > need) need = npp;
     const size_t n11 = align_up(bwd1x1_workspace(d), 256);     // ... and the single-pass 1x1 backward one slab per workgroup
     if (n11 > need) need = n11;
+    const size_t n33 = align_up(c3x3_wgrad_workspace(d), 256);  // ... as do the slab-resident 3x3 kernels (c3x3.hpp)
+    if (n33 > need) need = n33;
     return need;
   }
   return 0;
@@ -1410,6 +1413,7 @@ int32_t rigl_conv2d_stats_parts(const RiglConvDesc* d) {
   if (!d || d->cout <= 0 || (d->cout % 8)) return 0;
   const int64_t M = (int64_t)d->n * d->ho * d->wo;
   using namespace rigl::k1;
+  if (c3x3_use(d)) return c3x3_stats_parts(d);     // c3x3.hpp: one partial per tile of TH rows x the image width
   return (int32_t)((M + 127) / 128);     // one partial per 128-row output tile
 }
 
@@ -1471,6 +1475,11 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, cons
     a.b_row_stride = d->kh * d->kw * d->cin; a.b_tap_stride = d->cin;
     a.a_bytes = (uint32_t)((size_t)d->n * d->h * d->w * d->cin * 2);
     a.b_bytes = (uint32_t)((size_t)d->kh * d->kw * d->cin * d->cout * 2);
+    if (c3x3_use(d)) {                         // 3x3, 64 -> 64: input patch resident in LDS, filter in registers (c3x3.hpp)
+      launch_c3x3<false>(d, x, w_ohwi, nullptr, y, stats, st);
+      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
+      return RIGL_OK;
+    }
     const PPPlan pp = plan_pp<0>(a);           // long reductions: the 8-wave ping-pong body
     if (pp.variant && pp_ksplit_ok(a, pp) && workspace && workspace_bytes >= need && need) {
       a.ksplit = 2;
@@ -1514,6 +1523,7 @@ int32_t rigl_conv2d_dgrad_stats_parts(const RiglConvDesc* d) {
   if (!d || check_desc(d, "rigl_conv2d_dgrad_stats_parts")) return 0;
   if ((d->cin % 8) || (d->cout % 8)) return 0;
   if (bwd1x1_kind(d)) return 0;               // the single-pass 1x1 backward has no reduction epilogue
+  if (c3x3_use(d)) return 0;                  // nor has the slab-resident 3x3 dgrad
   IgemmArgs a = dgrad_args(d, nullptr, nullptr, nullptr, nullptr);
   if (plan_pp<1>(a).variant) return 0;        // the ping-pong dgrad has no reduction epilogue
   const IgemmPlan pl = plan_igemm<1>(a);
@@ -1561,6 +1571,11 @@ static int dgrad_impl(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf1
       return RIGL_OK;
     }
   }
+  if (!bn && c3x3_use(d)) {
+    launch_c3x3<true>(d, dy, w_hwio, addend, dx, nullptr, st);
+    RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
+    return RIGL_OK;
+  }
   IgemmArgs a = dgrad_args(d, dy, w_hwio, addend, dx);
   rc = attach_bn(a, d, bn);
   if (rc) return rc;
@@ -1603,6 +1618,15 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
       RIGL_CHECK_LAUNCH("rigl_masked_conv2d_wgrad");
       return RIGL_OK;
     }
+  }
+  if (c3x3_use(d)) {
+    // 3x3, 64 -> 64: X patch and dY tile resident in LDS, nine taps per wave (c3x3.hpp), one slab per workgroup
+    float* slabs = static_cast<float*>(workspace);
+    launch_c3x3_wgrad(d, x, dy, slabs, st);
+    ReduceArgs ra = {slabs, dw, (int64_t)9 * 64 * 64, (int64_t)9 * 64 * 64, c3x3_wgrad_geom(d).grid};
+    launch_wgrad_reduce(ra, st);
+    RIGL_CHECK_LAUNCH("rigl_masked_conv2d_wgrad");
+    return RIGL_OK;
   }
   if (tiny_cin(d) && stem_direct_legal(d) && RIGL_TUNE("stem_wgrad", 1) != 0) {
     // the ImageNet stem: patch and dY tile resident in LDS, both operands by transposing reads (stem.hpp)
@@ -1718,6 +1742,19 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
       RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");
       return RIGL_OK;
     }
+  }
+  // 3x3, 64 -> 64 (c3x3.hpp): weight gradient (+ reduce) and dgrad are launches of their own, each on resident patches
+  if (whole && !bn && c3x3_use(d)) {
+    if (need && (!workspace || workspace_bytes < need))
+      return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
+    ProfFamily prof(PROF_CONV_BWD);
+    float* slabs = static_cast<float*>(workspace);
+    launch_c3x3_wgrad(d, x, dy, slabs, st);
+    ReduceArgs ra = {slabs, dw, (int64_t)9 * 64 * 64, (int64_t)9 * 64 * 64, c3x3_wgrad_geom(d).grid};
+    launch_wgrad_reduce(ra, st);
+    launch_c3x3<true>(d, dy, w_hwio, addend, dx, nullptr, st);
+    RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");
+    return RIGL_OK;
   }
   // The shared launch on the 8-wave ping-pong bodies ("pp_bwd"): layers whose weight gradient has 256-channel tiles and
   // whose dgrad is a long reduction.

