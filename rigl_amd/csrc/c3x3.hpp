@@ -6,22 +6,30 @@
 // On the generic bodies these layers sat at 4.7-5.1x their roofline bound: with N = 64 columns the igemm
 // tile is 128x64, its K loop 18 tiles of 32, and every input pixel is fetched NINE times from L2 -- 462 MB of L2 -> LDS
 // traffic per layer at ~8 TB/s = the 57 us the forward took.  Here the input is fetched ONCE:
-//   forward / dgrad (k_c3x3): a workgroup owns TH output rows x the full width of one image.  Its input patch ((TH + 2)
-//     rows x (W + 2) pixels x 64 channels, zero border by out-of-range DMA lanes) goes HBM -> LDS by LDS-DMA in one burst and
-//     is indexed LINEARLY, q = row * (W + 2) + column, so that filter tap (dr, dc) of output pixel q is patch pixel
-//     q + dr * (W + 2) + dc -- a constant LDS offset; an M-tile of the implicit GEMM is 32 consecutive q (the two halo
-//     columns per row are computed and dropped: 3.4 % at W = 56).  The 3x3x64 filter of a wave's 32 output channels
-//     is REGISTER-RESIDENT (36 MFMA A-fragments = 144 VGPRs), so the K loop holds only ds_read_b128 of activation
-//     fragments (16-byte chunks XORed with (q >> 1) & 7: conflict-free at every tap shift, any 16 lanes of a read group
-//     differ in q mod 16) and v_mfma_f32_32x32x16_bf16.  4 waves = 2 channel halves x 2 M-tile parities; 2 workgroups
-//     per CU cover each other's load phase.  dgrad is the same kernel on dY with the filter read flipped and transposed
-//     from the HWIO shadow (dx[p][ci] = sum dy[p + 1 - tap][co] w[tap][ci][co]).
-//   weight gradient (k_c3x3_wgrad): persistent workgroups walk tiles of TH = 4 rows; the X patch and the dY tile (same
-//     linear indexing, its two surplus columns zero) are resident, both operands come out of ds_read_b64_tr_b16 (the
-//     reduction index is the pixel), a wave keeps the nine taps of its 32 x 32 block of dW in 144 accumulator registers
-//     and reads ONE dY fragment for nine MFMAs.  One [9][64][64] fp32 slab per workgroup, launch_wgrad_reduce finishes.
+//   forward / dgrad (k_c3x3): PERSISTENT workgroups, one per CU (512 threads), walk tiles of TH output rows x the full
+//     width of one image.  A tile's input patch ((TH + 2) rows x (W + 2) pixels x 64 channels, zero border by out-of-range
+//     DMA lanes) goes HBM -> LDS by LDS-DMA and is indexed LINEARLY, q = row * (W + 2) + column, so that filter tap
+//     (dr, dc) of output pixel q is patch pixel q + dr * (W + 2) + dc -- a constant LDS offset; an M-tile of the implicit
+//     GEMM is 32 consecutive q (the two halo columns per row are computed and dropped: 3.4 % at W = 56).  Two patch
+//     buffers: the pieces of the NEXT tile's patch are issued between the M-tiles of this one.  The 3x3x64 filter of a
+//     wave's 32 output channels is REGISTER-RESIDENT (36 MFMA A-fragments = 144 VGPRs, copied once per workgroup through
+//     LDS), so the K loop holds only ds_read_b128 of activation fragments (16-byte chunks XORed with (q >> 1) & 7:
+//     conflict-free at every tap shift, any 16 lanes of a read group differ in q mod 16) and v_mfma_f32_32x32x16_bf16,
+//     the four fragments of tap t + 1 requested above the MFMAs of tap t.  8 waves = 2 channel halves x 4 M-tile phases.
+//     dgrad is the same kernel on dY with the filter read flipped and transposed from the HWIO shadow
+//     (dx[p][ci] = sum dy[p + 1 - tap][co] w[tap][ci][co]).
+//   weight gradient (k_c3x3_wgrad): persistent, one 8-wave workgroup per CU, tiles of TH = 4 rows in two LDS stages (X
+//     patch + dY tile, same linear indexing, dY's two surplus columns zero); both operands come out of
+//     ds_read_b64_tr_b16 (the reduction index is the pixel), the two waves of a SIMD keep the nine taps (5 + 4) of one
+//     32 x 32 block of dW in accumulator registers and read ONE dY fragment per k-step.  One [9][64][64] fp32 slab per
+//     workgroup, launch_wgrad_reduce finishes.
 // Epilogues as in the other bodies: bf16 outputs staged per wave through LDS and stored as 16 bytes per lane, batch-norm
-// statistics of the bf16 outputs (one partial per TILE here: rigl_conv2d_stats_parts), the dgrad addend.
+// statistics of the bf16 outputs (one partial per WORKGROUP here: rigl_conv2d_stats_parts), the dgrad addend.
+// Measured at batch 128 (56x56, gpurun r4e-r4l; kernels alone, us): forward 60 -> 39 (what moved it: the filter through
+// LDS instead of 288 uncoalesced fragment loads per workgroup, 10 000 -> 7 400 cycles of prologue; reads ahead of the
+// MFMAs, 51 -> 43; statistics once per workgroup instead of an xor tree per tile, -4 000 cycles per tile; per tile now
+// ~11 000 cycles of M-tiles + ~2 700 of waiting for the piece-issuing waves, against 8 064 cycles of MFMA on the busiest
+// SIMD), dgrad 72 -> 42, weight gradient 92 -> 47 + 7 (reduce), one-call backward 133 -> 98; in the step K1 -0.19 ms.
 #pragma once
 
 struct C3Args {
@@ -49,7 +57,8 @@ constexpr int C3_RED_BYTES = 8 * 2 * 32 * 4;         // statistics scratch [8 wa
 
 // The whole reduction (9 taps x 64 channels) of one M-tile: 36 ds_read_b128 + 36 MFMAs, no control flow.  The four
 // fragments of tap t + 1 are requested before the MFMAs of tap t (the compiler's own schedule read one fragment, waited,
-// multiplied: with the filter taking 144 of the 256 registers it never ran reads ahead).
+// multiplied: with the filter taking 144 of the 256 registers it never ran reads ahead).  (Per-tap fragment offsets kept
+// in nine more registers instead of the ~4 VALU per read below spilled 22-37 registers and cost 18 us: measured, dropped.)
 __device__ __forceinline__ void c3_ktile(const unsigned char* const patch, const bf16x8 (&wf)[9][4], const int qa, const int PW,
                                          const int hi, f32x16& acc) {
   bf16x8 xf[2][4];
@@ -283,80 +292,126 @@ struct C3WArgs {
   FastDiv fd_pw, fd_th;
 };
 
-__global__ __launch_bounds__(THREADS, 2) void k_c3x3_wgrad(C3WArgs P) {
+// 8 waves: wave = tg * 4 + (cit * 2 + cot): the 32 x 32 block (cit, cot) of dW for the taps of group tg (0: taps 0..4, 1:
+// taps 5..8) -- the two waves of a SIMD (w, w + 4) carry the nine taps of one block between them.  Persistent, one
+// workgroup per CU; two LDS stages (X patch + dY tile each): the next tile's pieces are issued one per k-step while this
+// tile is multiplied (the first version -- 4 waves, one stage, two workgroups per CU -- loaded, then multiplied).
+template <int TG>
+__device__ __forceinline__ void c3w_tile(const unsigned char* const xp, const unsigned char* const yp, const int KS,
+                                         const int (&a_off)[5], const int y_off, f32x16 (&acc)[5]) {
+  constexpr int NT = TG ? 4 : 5;
+  // a k-step is 16 pixels = 2048 bytes further; the second half of a fragment's 8 pixels 4 pixels = 512 bytes further
+  // (neither changes bit 1 of the pixel index, so the swizzled offsets a_off / y_off hold for every k-step)
+  bf16x8 bfr[2], af[2][NT];
+#define C3W_READ(kk_, buf_)                                                                              \
+  {                                                                                                      \
+    const unsigned char* const xk_ = xp + (kk_) * 2048;                                                  \
+    const unsigned char* const yk_ = yp + (kk_) * 2048;                                                  \
+    bfr[buf_] = lds_read_tr_pair(yk_ + y_off, yk_ + y_off + 512);                                        \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) af[buf_][t] = lds_read_tr_pair(xk_ + a_off[t], xk_ + a_off[t] + 512); \
+  }
+  C3W_READ(0, 0);
+  for (int kk = 0; kk < KS; kk += 2) {
+    if (kk + 1 < KS) C3W_READ(kk + 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][t], bfr[0], acc[t], 0, 0, 0);
+    if (kk + 1 < KS) {
+      if (kk + 2 < KS) C3W_READ(kk + 2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][t], bfr[1], acc[t], 0, 0, 0);
+    }
+  }
+#undef C3W_READ
+}
+
+__global__ __launch_bounds__(C3_THREADS, 2) void k_c3x3_wgrad(C3WArgs P) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_c3[];
-  unsigned char* const xp = smem_c3;
-  unsigned char* const yp = smem_c3 + P.x_px * 128;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cit = wave >> 1, cot = wave & 1;           // this wave's 32 x 32 block of every tap's dW
+  const int tg = wave >> 2, cit = (wave >> 1) & 1, cot = wave & 1;
   const int PW = P.PW;
+  const int stage_bytes = (P.x_px + P.kp) * 128;
   const __amdgpu_buffer_rsrc_t rsrcX = make_rsrc(P.X, P.x_bytes), rsrcY = make_rsrc(P.DY, P.dy_bytes);
-
   // transposing fragment reads (the k_wgrad_tr recipe): lane (g, j) of a 16-pixel k-step: pixel 8 * (g >> 1) + (j >> 2)
   // (+ 4 for the second read), 16-byte chunk 2 * (g & 1) + ((j >> 1) & 1) of the fragment's four, bytes (j & 1) * 8; the
   // row's 64-byte quads are XORed with bit 1 of the pixel index on the DMA's source side
   const int g = lane >> 4, j16 = lane & 15;
   const int t_pix = 8 * (g >> 1) + (j16 >> 2), t_chunk = 2 * (g & 1) + ((j16 >> 1) & 1), t_half = (j16 & 1) * 8;
-#define C3_TR_ADDR(base_, pix_, tile_) ((base_) + (pix_) * 128 + ((((tile_) * 4 + t_chunk) ^ ((((pix_) >> 1) & 1) << 2)) << 4) + t_half)
-
-  f32x16 acc[9];
+#define C3_TR_OFF(pix_, tile_) ((pix_) * 128 + ((((tile_) * 4 + t_chunk) ^ ((((pix_) >> 1) & 1) << 2)) << 4) + t_half)
+  int a_off[5];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < 5; ++t) {
+    const int tap = (tg ? 5 : 0) + (t < (tg ? 4 : 5) ? t : 0);
+    a_off[t] = C3_TR_OFF(t_pix + (tap / 3) * PW + (tap % 3), cit);
+  }
+  const int y_off = C3_TR_OFF(t_pix, cot);
+#undef C3_TR_OFF
+  const int n_xi = P.x_px >> 3, n_pieces = n_xi + (P.kp >> 3);
+  const int npx = (P.TH + 2) * PW;
+
+  // pieces of a stage: 0 .. n_xi - 1 the X patch, then the dY tile; a wave takes every 8th
+  int q_i = 1 << 30, q_n = 0, q_h0 = 0, q_rows = 0;
+  unsigned char* q_dst = smem_c3;
+#define C3W_BEGIN(t_, buf_)                                                                              \
+  {                                                                                                      \
+    q_n = fdiv((t_), P.fd_th); q_h0 = ((t_) - q_n * P.tiles_h) * P.TH;                                   \
+    q_rows = P.H - q_h0 < P.TH ? P.H - q_h0 : P.TH;                                                      \
+    q_dst = smem_c3 + (buf_) * stage_bytes; q_i = wave;                                                  \
+  }
+#define C3W_ISSUE_ONE()                                                                                  \
+  {                                                                                                      \
+    if (q_i < n_pieces) {                                                                                \
+      const bool isx_ = q_i < n_xi;                                                                      \
+      const int px = (isx_ ? q_i : q_i - n_xi) * 8 + (lane >> 3), slot = lane & 7;                       \
+      const int chunk = slot ^ (((px >> 1) & 1) << 2);                                                   \
+      const int pr = fdiv(px, P.fd_pw), pc = px - pr * PW;                                               \
+      const int h = isx_ ? q_h0 - 1 + pr : q_h0 + pr, w = isx_ ? pc - 1 : pc;                            \
+      const bool ok = isx_ ? (px < npx && (unsigned)h < (unsigned)P.H && (unsigned)w < (unsigned)P.W)    \
+                           : (pr < q_rows && pc < P.W);                                                  \
+      const int off = ((q_n * P.H + h) * P.W + w) * 64 + chunk * 8;                                      \
+      const int boff = ok ? (int)((uint32_t)off * 2u) : (int)OOB;                                        \
+      if (isx_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (__attribute__((address_space(3))) void*)(q_dst + q_i * 1024), 16, boff, 0, 0, 0); \
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (__attribute__((address_space(3))) void*)(q_dst + q_i * 1024), 16, boff, 0, 0, 0); \
+      q_i += 8;                                                                                          \
+    }                                                                                                    \
+  }
+  f32x16 acc[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-  const int n_xi = P.x_px >> 3, n_yi = P.kp >> 3;
-  for (int tile = blockIdx.x; tile < P.tiles; tile += gridDim.x) {
-    const int n = fdiv(tile, P.fd_th), th = tile - n * P.tiles_h;
-    const int h0 = th * P.TH;
-    const int rows = P.H - h0 < P.TH ? P.H - h0 : P.TH;
-    __syncthreads();                                   // the previous tile's fragments are read
-    const int npx = (P.TH + 2) * PW;
-    for (int i = wave; i < n_xi; i += 4) {
-      const int px = i * 8 + (lane >> 3), slot = lane & 7;
-      const int chunk = slot ^ (((px >> 1) & 1) << 2);
-      const int pr = fdiv(px, P.fd_pw), pc = px - pr * PW;
-      const int h = h0 - 1 + pr, w = pc - 1;
-      const bool ok = px < npx && (unsigned)h < (unsigned)P.H && (unsigned)w < (unsigned)P.W;
-      const int off = ((n * P.H + h) * P.W + w) * 64 + chunk * 8;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (__attribute__((address_space(3))) void*)(xp + i * 1024), 16,
-                                               ok ? (int)((uint32_t)off * 2u) : (int)OOB, 0, 0, 0);
-    }
-    for (int i = wave; i < n_yi; i += 4) {
-      const int q = i * 8 + (lane >> 3), slot = lane & 7;
-      const int chunk = slot ^ (((q >> 1) & 1) << 2);
-      const int r = fdiv(q, P.fd_pw), c = q - r * PW;
-      const bool ok = r < rows && c < P.W;             // the two surplus columns of a row and the rows behind the tile: zeros
-      const int off = ((n * P.H + h0 + r) * P.W + c) * 64 + chunk * 8;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (__attribute__((address_space(3))) void*)(yp + i * 1024), 16,
-                                               ok ? (int)((uint32_t)off * 2u) : (int)OOB, 0, 0, 0);
-    }
+  int tile = blockIdx.x;
+  if (tile < P.tiles) { C3W_BEGIN(tile, 0); while (q_i < n_pieces) C3W_ISSUE_ONE(); }
+  const int KS = P.kp >> 4;
+  for (int it = 0; tile < P.tiles; ++it, tile += gridDim.x) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int KS = P.kp >> 4;
-#pragma unroll 1
-    for (int kk = 0; kk < KS; ++kk) {
-      const int p0 = kk * 16 + t_pix;
-      const bf16x8 bfr = lds_read_tr_pair(C3_TR_ADDR(yp, p0, cot), C3_TR_ADDR(yp, p0 + 4, cot));
+    __builtin_amdgcn_s_barrier();                      // stage `it & 1` landed everywhere; every wave is done with the other
+    asm volatile("" ::: "memory");
+    const bool more = tile + (int)gridDim.x < P.tiles;
+    if (more) { C3W_BEGIN(tile + (int)gridDim.x, (it + 1) & 1); while (q_i < n_pieces) C3W_ISSUE_ONE(); }
+    const unsigned char* const xp = smem_c3 + (it & 1) * stage_bytes;
+    const unsigned char* const yp = xp + P.x_px * 128;
+    if (tg == 0) c3w_tile<0>(xp, yp, KS, a_off, y_off, acc);
+    else c3w_tile<1>(xp, yp, KS, a_off, y_off, acc);
+  }
+#undef C3W_BEGIN
+#undef C3W_ISSUE_ONE
+  // the workgroup's partial dW -> its slab: D row (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) = ci, column lane & 31 = co
+  float* const out = P.SLAB + (int64_t)blockIdx.x * (9 * 64 * 64);
+  const int t0 = tg ? 5 : 0, nt = tg ? 4 : 5;
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int px = p0 + (tap / 3) * PW + (tap % 3);
-        const bf16x8 af = lds_read_tr_pair(C3_TR_ADDR(xp, px, cit), C3_TR_ADDR(xp, px + 4, cit));
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[tap], 0, 0, 0);
+  for (int t = 0; t < 5; ++t) {
+    if (t < nt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = cit * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), co = cot * 32 + (lane & 31);
+        out[((t0 + t) * 64 + ci) * 64 + co] = acc[t][e];
       }
     }
   }
-#undef C3_TR_ADDR
-  // the workgroup's partial dW -> its slab: D row (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) = ci, column lane & 31 = co
-  float* const out = P.SLAB + (int64_t)blockIdx.x * (9 * 64 * 64);
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int ci = cit * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), co = cot * 32 + (lane & 31);
-      out[(tap * 64 + ci) * 64 + co] = acc[tap][e];
-    }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
@@ -400,7 +455,7 @@ static bool c3x3_ready() {
 }
 static bool c3x3_wgrad_ready() {
   static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_c3x3_wgrad),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2) == hipSuccess;
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
   return ready;
 }
 // Does this layer run on the kernels of this file?  ONE decision for every entry point (a layer's dX has the same bits from
@@ -433,7 +488,7 @@ struct C3WGeom { int th, tiles_h, kp, x_px, smem, grid; };
 static C3WGeom c3x3_wgrad_geom(const RiglConvDesc* d) {
   C3WGeom g = {0, 0, 0, 0, 0, 0};
   const int pw = d->w + 2;
-  const int budget_px = (160 * 1024 / 2 - 1024) / 128;
+  const int budget_px = (160 * 1024 / 2) / 128;        // one of two stages
   for (int th = d->h; th >= 1; --th) {
     const int kp = (th * pw + 15) / 16 * 16;
     const int x_px = (kp + 2 * pw + 2 + 7) / 8 * 8;
@@ -441,9 +496,9 @@ static C3WGeom c3x3_wgrad_geom(const RiglConvDesc* d) {
   }
   if (!g.th) return g;
   g.tiles_h = (d->h + g.th - 1) / g.th;
-  g.smem = (g.x_px + g.kp) * 128;
+  g.smem = 2 * (g.x_px + g.kp) * 128;
   const int tiles = d->n * g.tiles_h;
-  g.grid = tiles < 2 * num_cus() ? tiles : 2 * num_cus();
+  g.grid = tiles < num_cus() ? tiles : num_cus();      // persistent: one workgroup per CU
   return g;
 }
 static inline size_t c3x3_wgrad_workspace(const RiglConvDesc* d) {
@@ -457,5 +512,5 @@ static void launch_c3x3_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const r
   a.kp = g.kp; a.x_px = g.x_px;
   a.x_bytes = a.dy_bytes = (uint32_t)((size_t)d->n * d->h * d->w * 64 * 2);
   a.fd_pw = make_fastdiv(a.PW); a.fd_th = make_fastdiv(a.tiles_h);
-  RIGL_K_LAUNCH(k_c3x3_wgrad, dim3((unsigned)g.grid), dim3(THREADS), (unsigned)g.smem, st, a);
+  RIGL_K_LAUNCH(k_c3x3_wgrad, dim3((unsigned)g.grid), dim3(C3_THREADS), (unsigned)g.smem, st, a);
 }
