@@ -84,6 +84,21 @@ C3_CASES = [
 ]
 
 
+# The "expand" 1x1 GEMM kernel (x1x1.hpp): reductions of 64 / 128 / 256 channels, forward (cout >= 4 cin) and dgrad
+# (cin >= 4 cout); one and several 128-row tiles per persistent workgroup, ragged last tiles
+X1_CASES = [
+    (16, 56, 56, 64, 256, 1, 1, 0, 0, 56, 56),     # K = 64: the whole filter resident, 392 tiles on 256 workgroups
+    (130, 23, 19, 64, 256, 1, 1, 0, 0, 23, 19),    # ... 56 810 rows: ragged last tile, two tiles on most workgroups
+    (64, 28, 28, 128, 512, 1, 1, 0, 0, 28, 28),    # K = 128: four chunks of 128 columns per tile
+    (50, 13, 17, 128, 512, 1, 1, 0, 0, 13, 17),    # ... 11 050 rows: fewer tiles than CUs, ragged
+    (200, 14, 14, 256, 1024, 1, 1, 0, 0, 14, 14),  # K = 256: sixteen chunks of 64 columns, 307 tiles
+    (16, 56, 56, 256, 64, 1, 1, 0, 0, 56, 56),     # dgrad is the expand GEMM (256 <- 64)
+    (64, 28, 28, 512, 128, 1, 1, 0, 0, 28, 28),    # ... 512 <- 128
+    (200, 14, 14, 1024, 256, 1, 1, 0, 0, 14, 14),  # ... 1024 <- 256
+    (60, 14, 14, 256, 2048, 1, 1, 0, 0, 14, 14),   # wider than the kernel's LDS statistics array allows: the generic body
+]
+
+
 def _c3_tile_rows(H, W):
   """Tile height of the c3x3.hpp forward (c3x3_geom restated): the most rows whose patch + zero tail fit the 544-pixel
   LDS budget of one of the two patch buffers, one fewer where that divides H."""
@@ -169,10 +184,16 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
       rows = 128                                     # one partial per 128 output rows, whatever the tile
       c3 = (k == 3 and stride == 1 and Cin == 64 and Cout == 64 and pt == 1 and pl == 1 and
             part.shape[0] != (yf.shape[0] + rows - 1) // rows)
+      x1 = (k == 1 and stride == 1 and Cin in (64, 128, 256) and Cout >= 4 * Cin and
+            part.shape[0] != (yf.shape[0] + rows - 1) // rows)
       stem_direct = (k == 7 and stride == 2 and Cin == 3 and Cout == 64 and pl == 3 and Ho % 16 == 0 and Wo % 16 == 0 and
                      W % 4 == 0 and ops.tune_get('stem_direct', 1) != 0)
       blk = None
-      if c3:
+      if x1:
+        # x1x1.hpp: one partial per persistent workgroup (two column halves per 128-row tile) -- the totals above are the
+        # whole check
+        assert part.shape[0] <= 2 * ((yf.shape[0] + rows - 1) // rows), 'x1x1: more statistics parts than work units'
+      elif c3:
         # c3x3.hpp: one partial per persistent workgroup (rigl_conv2d_stats_parts says how many), each the sum over the
         # tiles that workgroup walked -- the totals above are the whole check
         th = _c3_tile_rows(H, W)
@@ -221,11 +242,11 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
 
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument('--set', default='small', choices=['small', 'pp', 'stem', 'c3', 'resnet50'])
+  ap.add_argument('--set', default='small', choices=['small', 'pp', 'stem', 'c3', 'x1', 'resnet50'])
   ap.add_argument('--batch', type=int, default=128)
   ap.add_argument('--only', type=int, default=-1)
   a = ap.parse_args()
-  cases = {'small': SMALL_CASES, 'pp': PP_CASES, 'stem': STEM_CASES, 'c3': C3_CASES}.get(a.set) or resnet50_shapes(a.batch)
+  cases = {'small': SMALL_CASES, 'pp': PP_CASES, 'stem': STEM_CASES, 'c3': C3_CASES, 'x1': X1_CASES}.get(a.set) or resnet50_shapes(a.batch)
   worst, n = 0.0, 0
   for i, c in enumerate(cases):
     if a.only >= 0 and i != a.only:
