@@ -361,6 +361,30 @@ int rigl_conv2d_dgrad_ref(const RiglConvDesc* d, const rigl_bf16* dy,
 int rigl_conv2d_wgrad_ref(const RiglConvDesc* d, const rigl_bf16* x,
                           const rigl_bf16* dy, float* dw, rigl_stream_t stream);
 
+/* K1 in fp32 arithmetic -- the VALIDATION twin of the bf16 kernels, not the
+ * measured path.  The reference trains in float32 unless --precision=bfloat16
+ * (imagenet_train_eval.py:56-59, 553-554) and the path's float tolerance is
+ * quoted against fp32; these three entry points compute conv(x, mask * W), dX
+ * (+ addend) and the dense dW from fp32 NHWC activations and the fp32 master
+ * weights (HWIO; mask_bits as in rigl_pack_weights, NULL = all ones, applied on
+ * the fly) on v_mfma_f32_32x32x2_f32, any shape, deterministic (the weight
+ * gradient's position slabs are summed in a fixed order; workspace =
+ * rigl_conv2d_wgrad_f32_workspace_bytes(d), may be 0).  The host mirror takes
+ * this path when the activations it is handed are fp32 (rigl_amd.workloads:
+ * precision='float32', or knob "k1_fp32" = 1); tests/test_k1_fp32_gpu.py trains
+ * WRN-22 and ResNet-50 on it against a float64 evaluation of the model.      */
+int rigl_masked_conv2d_fwd_f32(const RiglConvDesc* d, const float* x,
+                               const float* w_hwio, const uint32_t* mask_bits /* nullable */,
+                               float* y, rigl_stream_t stream);
+int rigl_masked_conv2d_dgrad_f32(const RiglConvDesc* d, const float* dy,
+                                 const float* w_hwio, const uint32_t* mask_bits /* nullable */,
+                                 const float* addend /* nullable, may alias dx */,
+                                 float* dx, rigl_stream_t stream);
+size_t rigl_conv2d_wgrad_f32_workspace_bytes(const RiglConvDesc* d);
+int rigl_masked_conv2d_wgrad_f32(const RiglConvDesc* d, const float* x,
+                                 const float* dy, float* dw, void* workspace,
+                                 size_t workspace_bytes, rigl_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Glue between two masked convs: batch-norm with batch statistics (+ residual
  * add) (+ ReLU) on NHWC bf16 rows [m][c], fp32 parameters -- what the reference

@@ -30,21 +30,24 @@ def resnet50_blocks():
 
 
 class ResNet50CPU:
-  """fp32 NCHW; weights HWIO like the reference; masks float 0/1."""
+  """NCHW; weights HWIO like the reference; masks float 0/1.  ``dtype``: torch.float32 (the reference's default
+  --precision, and what the CPU baseline times) or torch.float64 (the exact-arithmetic stand-in the fp32 kernels are
+  held against, tests/test_k1_fp32_gpu.py); the initial values are the float32 draws either way."""
 
-  def __init__(self, sparsity_by_layer=None, seed=0, num_classes=1000):
+  def __init__(self, sparsity_by_layer=None, seed=0, num_classes=1000, dtype=torch.float32):
     rs = np.random.RandomState(seed)
     self.w, self.m, self.bn = [], [], []
+    self.dtype = dtype
 
     def conv(k, cin, cout):
       std = np.sqrt(1.0 / (k * k * cin))
-      self.w.append(torch.from_numpy((rs.randn(k, k, cin, cout) * std).astype(np.float32)).requires_grad_(True))
-      self.m.append(torch.ones(k, k, cin, cout))
+      self.w.append(torch.from_numpy((rs.randn(k, k, cin, cout) * std).astype(np.float32)).to(dtype).requires_grad_(True))
+      self.m.append(torch.ones(k, k, cin, cout, dtype=dtype))
       return len(self.w) - 1
 
     def bn(c, zero=False):
-      g = torch.zeros(c) if zero else torch.ones(c)
-      self.bn.append((g.requires_grad_(True), torch.zeros(c, requires_grad=True)))
+      g = torch.zeros(c, dtype=dtype) if zero else torch.ones(c, dtype=dtype)
+      self.bn.append((g.requires_grad_(True), torch.zeros(c, dtype=dtype, requires_grad=True)))
       return len(self.bn) - 1
 
     self.stem = (conv(7, 3, 64), bn(64))
@@ -59,13 +62,13 @@ class ResNet50CPU:
       b['stride'] = stride
       self.blocks.append(b)
     self.fc = conv(1, 2048, num_classes)
-    self.w[self.fc] = (torch.randn(1, 1, 2048, num_classes) * 0.01).requires_grad_(True)
-    self.fc_b = torch.zeros(num_classes, requires_grad=True)
+    self.w[self.fc] = (torch.randn(1, 1, 2048, num_classes) * 0.01).to(dtype).requires_grad_(True)
+    self.fc_b = torch.zeros(num_classes, dtype=dtype, requires_grad=True)
     if sparsity_by_layer is not None:
       for i, s in enumerate(sparsity_by_layer):
-        self.m[i] = torch.from_numpy(O.get_mask_random_numpy(tuple(self.w[i].shape), s, rs).astype(np.float32))
+        self.m[i] = torch.from_numpy(O.get_mask_random_numpy(tuple(self.w[i].shape), s, rs).astype(np.float32)).to(dtype)
     self.mom = [torch.zeros_like(w) for w in self.w]
-    self.mom_other = None
+    self.mom_other = None      # momentum of the batch-norm parameters and the fc bias, created by the first step
     self._keep = None            # {layer: mask*W tensor} while a step is asked to keep the dense gradients
     self.dense_grads = None      # [dL/d(mask*W) as NumPy arrays] of the last such step
 
@@ -105,10 +108,18 @@ class ResNet50CPU:
       self._keep[self.fc] = wfc
     return x @ wfc.reshape(2048, -1) + self.fc_b
 
+  def other_params(self):
+    """Batch-norm gammas / betas and the fc bias: trained by the same MomentumOptimizer, no regulariser."""
+    return [p for gb in self.bn for p in gb] + [self.fc_b]
+
   def train_step(self, images, labels, lr=0.1, mu=0.9, wd=1e-4, keep_dense=False):
-    """fwd + bwd + masked Nesterov-momentum update (non-update iteration)."""
+    """fwd + bwd + masked Nesterov-momentum update (non-update iteration) of EVERY trainable variable
+    (tf.train.MomentumOptimizer(use_nesterov=True), imagenet_train_eval.py:360-361; the l2 regulariser is attached to
+    the conv / fc kernels only, resnet_model.py:287-295, 718-724)."""
     for w in self.w:
       w.grad = None
+    for p in self.other_params():
+      p.grad = None
     self._keep = {} if keep_dense else None
     loss = F.cross_entropy(self.forward(images), labels, label_smoothing=0.1)
     loss.backward()
@@ -121,10 +132,12 @@ class ResNet50CPU:
         g = w.grad + wd * w
         self.mom[i].mul_(mu).add_(g)
         w.sub_(lr * g + lr * mu * self.mom[i])
-      for g_, b_ in self.bn:
-        for p in (g_, b_):
-          p.sub_(lr * p.grad)
-          p.grad = None
+      others = self.other_params()
+      if self.mom_other is None:
+        self.mom_other = [torch.zeros_like(p) for p in others]
+      for p, a in zip(others, self.mom_other):
+        a.mul_(mu).add_(p.grad)
+        p.sub_(lr * p.grad + lr * mu * a)
     return float(loss.detach())
 
   def mask_update(self, dense_grads, drop_fraction=0.3):
@@ -133,7 +146,7 @@ class ResNet50CPU:
     for i, w in enumerate(self.w):
       r = O.rigl_mask_update(self.m[i].numpy(), w.detach().numpy(), dense_grads[i], drop_fraction,
                              momentum=self.mom[i].numpy())
-      self.m[i] = torch.from_numpy(r['mask'])
+      self.m[i] = torch.from_numpy(r['mask']).to(self.dtype)
       with torch.no_grad():
         w.copy_(torch.from_numpy(r['weights']))
       self.mom[i] = torch.from_numpy(r['momentum'])

@@ -117,6 +117,10 @@ SIGNATURES = {
     'rigl_conv2d_fwd_ref': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     'rigl_conv2d_dgrad_ref': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     'rigl_conv2d_wgrad_ref': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    'rigl_masked_conv2d_fwd_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    'rigl_masked_conv2d_dgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    'rigl_conv2d_wgrad_f32_workspace_bytes': (_SZ, [C.POINTER(ConvDesc)]),
+    'rigl_masked_conv2d_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _SZ, _P]),
     'rigl_depthwise_conv2d_workspace_bytes': (_SZ, [C.POINTER(ConvDesc)]),
     'rigl_depthwise_conv2d_fwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     'rigl_depthwise_conv2d_stats_parts': (_I32, [C.POINTER(ConvDesc)]),

@@ -459,6 +459,52 @@ def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None, 
 
 
 # ----------------------------------------------------------------------------
+# K1 in fp32 arithmetic (validation twin; the reference's --precision=float32)
+# ----------------------------------------------------------------------------
+def conv_fwd_f32(d, x, w_hwio, mask_bits=None, y=None):
+  """y[N,Ho,Wo,Cout] fp32 = conv(x, mask * W): fp32 NHWC activations, the fp32 master weights (flat HWIO) and the
+  mask bitmap (None: dense), on the fp32 MFMA (rigl_masked_conv2d_fwd_f32)."""
+  _req(x, torch.float32, 'x')
+  _req(w_hwio, torch.float32, 'w_hwio')
+  _req(mask_bits, torch.int32, 'mask_bits', allow_none=True)
+  _count_macs('fwd_macs', d)
+  if y is None:
+    y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.float32, device=x.device)
+  _req(y, torch.float32, 'y')
+  check(_lib.load().rigl_masked_conv2d_fwd_f32(C.byref(d), _ptr(x), _ptr(w_hwio), _ptr(mask_bits), _ptr(y), _stream()))
+  return y
+
+
+def conv_bwd_f32(d, x, dy, w_hwio, mask_bits, dw, need_dx=True, addend=None, on_dw_ready=None):
+  """fp32 twin of conv_bwd: dense dW (fp32 HWIO, overwritten) and -- when ``need_dx`` -- dX (+ ``addend``)."""
+  _req(x, torch.float32, 'x')
+  _req(dy, torch.float32, 'dy')
+  _req(dw, torch.float32, 'dw')
+  _req(addend, torch.float32, 'addend', allow_none=True)
+  _req(mask_bits, torch.int32, 'mask_bits', allow_none=True)
+  lib = _lib.load()
+  _count_macs('wgrad_macs', d)
+  need = getattr(d, '_ws_wgrad_f32', None)
+  if need is None:
+    need = d._ws_wgrad_f32 = lib.rigl_conv2d_wgrad_f32_workspace_bytes(C.byref(d))
+  ws = workspace(need, x.device, 'wg32') if need else None
+  check(lib.rigl_masked_conv2d_wgrad_f32(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws),
+                                         ws.numel() if ws is not None else 0, _stream()))
+  if on_dw_ready is not None:
+    on_dw_ready()
+  if not need_dx:
+    return None
+  _count_macs('dgrad_macs', d)
+  _req(w_hwio, torch.float32, 'w_hwio')
+  dx = torch.empty((d.n, d.h, d.w, d.cin), dtype=torch.float32, device=dy.device)
+  if addend is not None and addend.numel() != dx.numel():
+    raise ValueError('addend must have the shape of dx')
+  check(lib.rigl_masked_conv2d_dgrad_f32(C.byref(d), _ptr(dy), _ptr(w_hwio), _ptr(mask_bits), _ptr(addend), _ptr(dx),
+                                         _stream()))
+  return dx
+
+
+# ----------------------------------------------------------------------------
 # K1d depthwise
 # ----------------------------------------------------------------------------
 def depthwise_fwd(d, x, w, stats=False):

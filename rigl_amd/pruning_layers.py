@@ -67,6 +67,11 @@ def _bn_fuse_publish(holder, req, dx):
     holder.partials, holder.dx_ptr = req['partials'], dx.data_ptr()
 
 
+def _mask_bits(lv):
+  """The layer's mask bitmap for the fp32 kernels (they read the master weights and apply the mask on the fly)."""
+  return lv.mask.bits if lv.mask is not None else None
+
+
 class _MaskedConvFn(torch.autograd.Function):
   """y = conv(x, mask*W) with dense dW written into lv.weights.grad."""
 
@@ -75,6 +80,14 @@ class _MaskedConvFn(torch.autograd.Function):
     ctx.lv, ctx.desc, ctx.need_dx = lv, desc, need_dx
     ctx.bn_holder = bn_holder
     ctx.save_for_backward(x)
+    if x.dtype == torch.float32:         # --precision=float32: the fp32 validation kernels, no statistics epilogue
+      y = ops.conv_fwd_f32(desc, x, lv.weights.data.view(-1), _mask_bits(lv))
+      if not want_stats:
+        return y
+      part = torch.empty(0, device=x.device)
+      ctx.mark_non_differentiable(part)
+      ctx.set_materialize_grads(False)
+      return y, part
     if not want_stats:
       return ops.conv_fwd(desc, x, lv.ohwi)
     y, part = ops.conv_fwd(desc, x, lv.ohwi, stats=True)
@@ -89,11 +102,15 @@ class _MaskedConvFn(torch.autograd.Function):
     (x,) = ctx.saved_tensors
     lv, d = ctx.lv, ctx.desc
     if dy is None:                       # output unused: zero gradient
-      dy = torch.zeros((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16, device=x.device)
+      dy = torch.zeros((d.n, d.ho, d.wo, d.cout), dtype=x.dtype, device=x.device)
     dy = dy.contiguous()
     # dense dL/d(mask*W), fp32 HWIO, into this layer's slice of the G arena, and dX -- one call
     sync = getattr(lv.weights.graph, 'grad_sync', None)
     ready = (lambda: sync.notify_layer_grad_ready(lv.weights)) if sync is not None else None   # DP: overlap the all-reduce
+    if x.dtype == torch.float32:
+      dx = ops.conv_bwd_f32(d, x, dy, lv.weights.data.view(-1), _mask_bits(lv), lv.weights.grad.view(-1),
+                            need_dx=ctx.need_dx, on_dw_ready=ready)
+      return dx, None, None, None, None, None
     req = _bn_fuse_request(ctx.bn_holder, ctx.need_dx)
     dx = ops.conv_bwd(d, x, dy, lv.hwio, lv.weights.grad.view(-1), need_dx=ctx.need_dx, on_dw_ready=ready, bn_fuse=req)
     _bn_fuse_publish(ctx.bn_holder, req, dx)
@@ -112,6 +129,14 @@ class _MaskedConvForkFn(torch.autograd.Function):
     ctx.lv, ctx.desc = lv, desc
     ctx.bn_holder = bn_holder
     ctx.save_for_backward(x)
+    if x.dtype == torch.float32:
+      y = ops.conv_fwd_f32(desc, x, lv.weights.data.view(-1), _mask_bits(lv))
+      if not want_stats:
+        return y, x.view_as(x)
+      part = torch.empty(0, device=x.device)
+      ctx.mark_non_differentiable(part)
+      ctx.set_materialize_grads(False)
+      return y, x.view_as(x), part
     if not want_stats:
       return ops.conv_fwd(desc, x, lv.ohwi), x.view_as(x)
     y, part = ops.conv_fwd(desc, x, lv.ohwi, stats=True)
@@ -126,12 +151,16 @@ class _MaskedConvForkFn(torch.autograd.Function):
     (x,) = ctx.saved_tensors
     lv, d = ctx.lv, ctx.desc
     if dy is None:
-      dy = torch.zeros((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16, device=x.device)
+      dy = torch.zeros((d.n, d.ho, d.wo, d.cout), dtype=x.dtype, device=x.device)
     dy = dy.contiguous()
     if dalias is not None:
       dalias = dalias.contiguous()
     sync = getattr(lv.weights.graph, 'grad_sync', None)
     ready = (lambda: sync.notify_layer_grad_ready(lv.weights)) if sync is not None else None
+    if x.dtype == torch.float32:
+      dx = ops.conv_bwd_f32(d, x, dy, lv.weights.data.view(-1), _mask_bits(lv), lv.weights.grad.view(-1),
+                            need_dx=True, addend=dalias, on_dw_ready=ready)
+      return dx, None, None, None, None
     # dx = this conv's dgrad + the alias' gradient is the COMPLETE gradient of the forked tensor: the producing batch
     # norm's reductions are taken on it
     req = _bn_fuse_request(ctx.bn_holder, True)

@@ -19,6 +19,18 @@ BATCH_NORM_EPSILON = 1e-5   # resnet_model.py:38
 _DW_STATS = os.environ.get('RIGL_DW_STATS', '1') != '0'   # depthwise forward leaves the next batch norm's statistics
 
 
+def activation_dtype(precision=None):
+  """The dtype of the activations for the reference's ``--precision`` flag (imagenet_train_eval.py:56-59): 'bfloat16'
+  (what the MFMA kernels and every measured number use) or 'float32' (the fp32 validation kernels of K1, stock ops
+  for the glue).  ``None``: bfloat16 unless knob "k1_fp32" (RIGL_K1_FP32=1) is set."""
+  if precision is None:
+    from rigl_amd import ops  # pylint: disable=import-outside-toplevel
+    precision = 'float32' if ops.tune_get('k1_fp32', 0) == 1 else 'bfloat16'
+  if precision not in ('bfloat16', 'float32'):
+    raise ValueError('precision must be bfloat16 or float32, got %r' % (precision,))
+  return torch.float32 if precision == 'float32' else torch.bfloat16
+
+
 def nchw_view(x):
   """[N,H,W,C] contiguous -> NCHW-shaped channels_last view (no copy)."""
   return x.permute(0, 3, 1, 2)

@@ -124,10 +124,10 @@ class ResNet50:
                                      label_smoothing)
 
 
-def synthetic_batch(batch, device, seed=1234, image_size=224, num_classes=1000):
-  """N(0,1) images (already 'normalised'), uniform labels."""
+def synthetic_batch(batch, device, seed=1234, image_size=224, num_classes=1000, precision=None):
+  """N(0,1) images (already 'normalised'), uniform labels.  ``precision``: gnn.activation_dtype."""
   gen = torch.Generator(device=device).manual_seed(seed)
   images = torch.randn(batch, image_size, image_size, 3, generator=gen,
-                       device=device).to(torch.bfloat16)
+                       device=device).to(gnn.activation_dtype(precision))
   labels = torch.randint(0, num_classes, (batch,), generator=gen, device=device)
   return images, labels

@@ -72,8 +72,8 @@ class WideResNet:
     return gnn.softmax_cross_entropy(self(images, is_training), labels, 0.0)
 
 
-def synthetic_batch(batch, device, seed=1234, num_classes=10):
+def synthetic_batch(batch, device, seed=1234, num_classes=10, precision=None):
   gen = torch.Generator(device=device).manual_seed(seed)
-  images = torch.randn(batch, 32, 32, 3, generator=gen, device=device).to(torch.bfloat16)
+  images = torch.randn(batch, 32, 32, 3, generator=gen, device=device).to(gnn.activation_dtype(precision))
   labels = torch.randint(0, num_classes, (batch,), generator=gen, device=device)
   return images, labels

@@ -1,0 +1,341 @@
+"""K1 in fp32 arithmetic (VERDICT r3 missing #3): the reference trains in float32 unless --precision=bfloat16
+(imagenet_train_eval.py:56-59, 553-554) and the path's float tolerance reads "loss / gradients within 1e-5 (fp32)".
+
+The bf16-operand MFMA kernels can show that only per kernel, relative to sum |a||b| (tests/test_k1_parity_gpu.py); the
+whole-model checks of the bf16 path are necessarily loose (tests/test_e2e_gpu.py: 2e-2 on the loss).  Here the SAME
+host code -- pruning_layers' autograd bridge, the models, the optimizer kernels -- runs with fp32 activations, which
+routes every masked conv / fc through the fp32 kernels of rigl_amd/csrc/conv_f32.hip (v_mfma_f32_32x32x2_f32; mask
+applied to the fp32 master weights on the fly), and
+
+  * each kernel is compared with a float64 convolution of the same operands (4e-6 of max |ref|: reductions of up to 10^5 terms), and
+  * WRN-22 (BASELINE config 2) and ResNet-50 (configs 1 / 3, batch 8) are TRAINED for three steps (forward, backward,
+    masked Nesterov update of every variable) beside a float64 evaluation of the same model -- for ResNet-50 that is
+    oracle/resnet_cpu.py's ResNet50CPU(dtype=float64) -- holding the loss to 1e-5 relative and every layer's DENSE dW
+    to 1e-5 (WRN-22) / 5e-5 (ResNet-50) relative (per layer: max |dW - ref| <= tol * max |ref|) at each of the
+    three steps.  Measured: loss 3e-8 .. 8e-8; dW worst layer 1.1e-6 (WRN-22), 2.5e-5 .. 3.8e-5 (ResNet-50).
+
+Two facts about what a whole-network gradient comparison in fp32 can show, both measured with NO kernel of this repo
+involved (tools/fp32_noise_floor.py: stock torch-CPU float32 against float64 on oracle/resnet_cpu.py, batch 8):
+
+  1. A ReLU network's gradient is discontinuous where a pre-activation crosses zero.  Activations agree to 1e-5
+     between float32 and float64, so among the 10^7 ReLU inputs of ResNet-50 a handful land on the other side of zero;
+     each flips one element of the mask the gradient is multiplied with and the layers below inherit it.  Measured:
+     dL/d(block output) agrees to 1.8e-7 above the last ReLU and to 2e-3 right below it; every conv layer's dW ends up
+     1 % (l2) off, the fully connected layer (above all ReLUs) 3e-6.  Max-pooling's arg max does the same to the stem.
+     Two correct float32 implementations therefore never agree to 1e-5 on these gradients unless they are compared ON
+     THE SAME LINEAR PIECE of the network -- which is what this test does: the ReLU signs and max-pool selections the
+     device run took are recorded and the float64 twin is evaluated with those decisions (_Decisions).  The twin's own
+     values at the flipped elements are within rounding of zero, so the loss is unaffected (it agrees to 1e-8).
+  2. On the same piece, stock float32 still sits 2.6e-5 .. 4.3e-5 (worst layer, three steps) from float64 on ResNet-50:
+     batch norm's backward subtracts two per-channel means from the incoming gradient, which amplifies the rounding
+     of whatever produced it (worst at batch 8 on the 7 x 7 maps: 392 values per channel).  1e-5 on every layer is below
+     what float32 arithmetic delivers on THIS model -- the fp32 path here lands on the same floor as stock float32, so
+     the ResNet-50 bound is 5e-5; WRN-22 (batch 64) holds 1e-5 with a factor 9 to spare.  The figures are printed.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+import torch.nn.functional as F  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL_LOSS = 1e-5
+TOL_DW_WRN22 = 1e-5      # measured 1.0e-6 .. 1.1e-6 (worst layer, three steps)
+TOL_DW_RESNET50 = 5e-5   # measured 2.5e-5 .. 3.8e-5; stock torch float32 on the same model: 2.6e-5 .. 4.3e-5 (docstring, 2.)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the three kernels, one layer at a time
+# ----------------------------------------------------------------------------------------------------------------------
+# (n, h, w, cin, cout, k, stride, pad_top/left, ho, wo)
+KERNEL_CASES = [
+    (2, 224, 224, 3, 64, 7, 2, 3, 112, 112),       # ImageNet stem, fixed padding 3
+    (4, 56, 56, 64, 64, 3, 1, 1, 56, 56),
+    (4, 56, 56, 256, 128, 1, 1, 0, 56, 56),
+    (4, 56, 56, 128, 128, 3, 2, 1, 28, 28),        # v1.5 strided 3x3, fixed padding
+    (4, 56, 56, 256, 512, 1, 2, 0, 28, 28),        # strided projection
+    (8, 7, 7, 512, 512, 3, 1, 1, 7, 7),
+    (8, 1, 1, 2048, 1000, 1, 1, 0, 1, 1),          # final_dense
+    (16, 32, 32, 3, 16, 3, 1, 1, 32, 32),          # CIFAR stem
+    (16, 32, 32, 16, 32, 3, 2, 0, 16, 16),         # TF SAME at stride 2: the extra pixel at the end
+    (128, 1, 1, 64, 10, 1, 1, 0, 1, 1),            # 10-class logits
+    (100, 1, 1, 784, 300, 1, 1, 0, 1, 1),          # MNIST MLP
+    (100, 1, 1, 300, 100, 1, 1, 0, 1, 1),          # reduction 300 = 37.5 x 8: the quad loader's tail
+    (3, 9, 11, 20, 40, 3, 1, 1, 9, 11),            # ragged everything (cin % 8 = 4: the scalar loader)
+]
+
+
+def _ref_conv64(d, x, wm, dy, addend):
+  """float64 conv2d / its two gradients of the same operands on the CPU (x NHWC, wm = mask * W in HWIO)."""
+  n, h, w, cin, cout, k, stride, pad, ho, wo = d
+  x64 = x.double().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+  w64 = wm.double().cpu().permute(3, 2, 0, 1).contiguous().requires_grad_(True)
+  pb = max((ho - 1) * stride + k - h - pad, 0)
+  pr = max((wo - 1) * stride + k - w - pad, 0)
+  y = F.conv2d(F.pad(x64, (pad, pr, pad, pb)), w64, stride=stride)[:, :, :ho, :wo]
+  y.backward(dy.double().cpu().permute(0, 3, 1, 2))
+  dx = x64.grad.permute(0, 2, 3, 1)
+  if addend is not None:
+    dx = dx + addend.double().cpu()
+  return y.detach().permute(0, 2, 3, 1), dx, w64.grad.permute(2, 3, 1, 0)
+
+
+@pytest.mark.parametrize('case', KERNEL_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_fp32_kernels_vs_float64(case):
+  from rigl_amd import ops
+  n, h, w, cin, cout, k, stride, pad, ho, wo = case
+  gen = torch.Generator(device=DEV).manual_seed(sum(case))
+  x = torch.randn(n, h, w, cin, generator=gen, device=DEV)
+  dy = torch.randn(n, ho, wo, cout, generator=gen, device=DEV)
+  wt = torch.randn(k, k, cin, cout, generator=gen, device=DEV) / np.sqrt(k * k * cin)
+  mask = (torch.rand(k, k, cin, cout, generator=gen, device=DEV) < 0.3).float()
+  addend = torch.randn(n, h, w, cin, generator=gen, device=DEV)
+  bits = ops.mask_pack(mask)
+  d = ops.conv_desc(n, h, w, cin, cout, k, k, stride, pad, pad, ho, wo)
+  for mb, wm in ((bits, wt * mask), (None, wt)):
+    y = ops.conv_fwd_f32(d, x, wt.view(-1), mb)
+    dw = torch.full((wt.numel(),), float('nan'), device=DEV)
+    dx = ops.conv_bwd_f32(d, x, dy, wt.view(-1), mb, dw, need_dx=True, addend=addend)
+    dw2 = torch.full((wt.numel(),), float('nan'), device=DEV)
+    assert ops.conv_bwd_f32(d, x, dy, wt.view(-1), mb, dw2, need_dx=False) is None
+    torch.cuda.synchronize()
+    yr, dxr, dwr = _ref_conv64(case, x, wm, dy, addend)
+    for name, got, ref in (('y', y, yr), ('dx', dx, dxr), ('dw', dw.view(k, k, cin, cout), dwr)):
+      err = float((got.double().cpu() - ref).abs().max())
+      assert err <= 4e-6 * float(ref.abs().max()), (name, mb is not None, err, float(ref.abs().max()))
+    assert torch.equal(dw, dw2)                          # deterministic, and independent of the dgrad call
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# three training steps of a whole network beside its float64 twin
+# ----------------------------------------------------------------------------------------------------------------------
+class _Decisions:
+  """The non-smooth choices of one forward pass -- ReLU signs, max-pool arg max -- recorded from the device run (whose
+  glue ops are the stock torch ones in this mode, rigl_amd/workloads/nn.py) and imposed on the float64 twin."""
+
+  def __init__(self):
+    self.tape = []
+    self._relu, self._pool = F.relu, F.max_pool2d
+
+  def _set(self, relu, pool):
+    F.relu, F.max_pool2d = relu, pool
+
+  def record(self):
+    def relu(t):
+      out = self._relu(t)
+      m = out > 0
+      self.tape.append(('relu', (m.permute(0, 3, 1, 2) if m.dim() == 4 else m).cpu()))   # device tensors are NHWC
+      return out
+
+    def pool(t, *args, **kw):
+      out, idx = self._pool(t, *args, return_indices=True, **kw)
+      self.tape.append(('pool', idx.cpu().contiguous(), t.shape[-1]))
+      return out
+    self._set(relu, pool)
+    return self
+
+  def replay(self):
+    def relu(t):
+      kind, m = self.tape.pop(0)
+      assert kind == 'relu' and m.shape == t.shape, (kind, m.shape, t.shape)
+      return t * m.to(t.dtype)
+
+    def pool(t, *args, **kw):
+      kind, idx, width = self.tape.pop(0)
+      assert kind == 'pool'
+      idx = (idx // width) * t.shape[-1] + idx % width          # the twin may have padded the plane explicitly
+      return t.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+    self._set(relu, pool)
+    return self
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *exc):
+    self._set(self._relu, self._pool)
+    return False
+
+
+class _Float64Twin:
+  """float64 CPU copies of every trainable variable of a graph (keyed by variable name), the masks, and the update
+  rule of train.MomentumOptimizer(use_nesterov=True) (TF ApplyMomentum; g = mask * dense + wd * W for masked
+  kernels, dense + wd * W for dense kernels, plain for batch-norm parameters and biases)."""
+
+  def __init__(self, g):
+    from rigl_amd import variables as V
+    self.V = V
+    self.p, self.a, self.meta = {}, {}, {}
+    for v in g.trainable_variables():
+      self.p[v.name] = v.data.detach().double().cpu().clone().requires_grad_(True)
+      self.a[v.name] = torch.zeros_like(self.p[v.name])
+      self.meta[v.name] = (v.kind, v.weight_decay)
+    self.mask = {l.weights.name: (l.mask.data.double().cpu().reshape(l.weights.shape) if l.mask is not None else None)
+                 for l in g.layers}
+    self.kept = {}
+
+  def kernel(self, layer):
+    """mask * W as a tensor whose gradient is RigL's dense gradient."""
+    w = self.p[layer.weights.name]
+    m = self.mask[layer.weights.name]
+    wm = w * m if m is not None else w * 1.0
+    wm.retain_grad()
+    self.kept[layer.scope] = wm
+    return wm
+
+  def var(self, v):
+    return self.p[v.name]
+
+  def step(self, loss, lr, mu):
+    for p in self.p.values():
+      p.grad = None
+    loss.backward()
+    dense = {k: t.grad.detach().clone() for k, t in self.kept.items()}
+    self.kept = {}
+    with torch.no_grad():
+      for name, p in self.p.items():
+        kind, wd = self.meta[name]
+        g = p.grad if kind == self.V.KIND_OTHER else p.grad + wd * p     # p.grad already carries the mask factor
+        self.a[name].mul_(mu).add_(g)
+        p.sub_(lr * g + lr * mu * self.a[name])
+    return dense
+
+
+def _same_conv64(x, w_hwio, stride):
+  k = w_hwio.shape[0]
+  if k == 3:
+    h, w = x.shape[2], x.shape[3]
+    th = max((-(-h // stride) - 1) * stride + 3 - h, 0)
+    tw = max((-(-w // stride) - 1) * stride + 3 - w, 0)
+    x = F.pad(x, (tw // 2, tw - tw // 2, th // 2, th - th // 2))
+  return F.conv2d(x, w_hwio.permute(3, 2, 0, 1), stride=stride)
+
+
+def _wrn_loss64(model, twin, x_nchw, labels):
+  """rigl/cifar_resnet/resnet_model.py:70-235 from stock ops in float64 (the twin of workloads.wide_resnet)."""
+
+  def bn_relu(bn, t):
+    return F.relu(F.batch_norm(t, None, None, twin.var(bn.gamma), twin.var(bn.beta), True, 0.1, bn.eps))
+
+  net = _same_conv64(x_nchw, twin.kernel(model.stem), 1)
+  for b in model.blocks:
+    skip = net
+    net = bn_relu(b['bn_a'], net)
+    if 'skip' in b:
+      skip = _same_conv64(net, twin.kernel(b['skip']), b['skip'].strides[0])
+    net = _same_conv64(net, twin.kernel(b['conv1']), b['conv1'].strides[0])
+    net = bn_relu(b['bn_b'], net)
+    net = _same_conv64(net, twin.kernel(b['conv2']), 1)
+    net = net + skip
+  net = bn_relu(model.final_bn, net)
+  logits = net.mean(dim=(2, 3)) @ twin.kernel(model.logits) + twin.var(model.logits.bias)
+  return F.cross_entropy(logits, labels)
+
+
+def _compare(step, loss, ref_loss, layers, ref_dense, report, tol_dw):
+  rel = abs(loss - ref_loss) / abs(ref_loss)
+  report.append('step %d  loss %.9f  float64 %.9f  rel %.2e' % (step, loss, ref_loss, rel))
+  assert rel <= TOL_LOSS, report[-1]
+  errs = []
+  for l in layers:
+    dw = l.weights.grad.detach().double().cpu().reshape(l.weights.shape)
+    r = ref_dense[l.scope].reshape(dw.shape)
+    assert float(r.abs().max()) > 0, l.scope
+    errs.append((float((dw - r).abs().max() / r.abs().max()), l.scope))
+  report.append('        dense dW, max |dW - float64| / max |float64| per layer: worst %.2e (%s), median %.2e'
+                % (max(errs) + (sorted(e for e, _ in errs)[len(errs) // 2],)))
+  print(report[-2] + '\n' + report[-1], flush=True)
+  assert max(errs)[0] <= tol_dw, (step, max(errs))
+
+
+def test_wrn22_three_training_steps_in_fp32_vs_float64():
+  from rigl_amd import sparse_utils, train, variables as V
+  from rigl_amd.workloads import wide_resnet
+  g = V.reset_default_graph(DEV)
+  model = wide_resnet.WideResNet(g, depth=22, width=1)
+  np.random.seed(0)
+  sparse_utils.get_mask_init_fn(g.get_masks(), 'erdos_renyi_kernel', 0.8, {})()
+  gen = torch.Generator(device=DEV).manual_seed(3)
+  for mod in g.modules.values():
+    if hasattr(mod, 'gamma'):
+      mod.gamma.data.copy_(1.0 + 0.2 * torch.randn(mod.channels, generator=gen, device=DEV))
+      mod.beta.data.copy_(0.1 * torch.randn(mod.channels, generator=gen, device=DEV))
+  lr, mu = 0.1, 0.9
+  opt = train.MomentumOptimizer(lr, mu, use_nesterov=True, graph=g)
+  gs = g.get_or_create_global_step()
+  x, y = wide_resnet.synthetic_batch(64, DEV, precision='float32')
+  assert x.dtype == torch.float32
+  twin = _Float64Twin(g)
+  x64, y64 = x.double().cpu().permute(0, 3, 1, 2).contiguous(), y.cpu()
+  report = []
+  for step in range(3):
+    with _Decisions().record() as dec:
+      loss = model.loss(x, y)
+    assert loss.dtype == torch.float32
+    gv = opt.compute_gradients(loss)
+    torch.cuda.synchronize()
+    with dec.replay():
+      ref_loss = _wrn_loss64(model, twin, x64, y64)
+    assert not dec.tape
+    ref_dense = twin.step(ref_loss, lr, mu)
+    _compare(step, float(loss.detach()), float(ref_loss.detach()), g.layers, ref_dense, report, TOL_DW_WRN22)
+    opt.apply_gradients(gv, gs)
+
+
+def test_resnet50_three_training_steps_in_fp32_vs_float64_oracle():
+  from oracle.resnet_cpu import ResNet50CPU
+  from rigl_amd import sparse_utils, train, variables as V
+  from rigl_amd.workloads import resnet50
+  g = V.reset_default_graph(DEV)
+  model = resnet50.ResNet50(g)
+  np.random.seed(0)
+  sparse_utils.get_mask_init_fn(g.get_masks(), 'erdos_renyi_kernel', 0.8, {})()
+  lr, mu, wd = 0.01, 0.9, 1e-4
+  assert {v.weight_decay for v in g.trainable_variables() if v.kind != V.KIND_OTHER} == {wd}
+  cpu = ResNet50CPU(seed=0, dtype=torch.float64)
+  assert len(cpu.w) == len(g.layers) == 54
+  with torch.no_grad():
+    for i, l in enumerate(g.layers):
+      shape = l.weights.shape if len(l.weights.shape) == 4 else (1, 1) + tuple(l.weights.shape)
+      cpu.w[i].copy_(l.weights.data.double().cpu().reshape(shape))
+      cpu.m[i] = (l.mask.data.double().cpu().reshape(shape) if l.mask is not None else torch.ones(shape, dtype=torch.float64))
+  # gamma = 0 on the last batch norm of every block would switch the residual branches off at step 0
+  for v in g.variables.values():
+    if v.name.endswith('bn3/gamma:0'):
+      v.data.fill_(0.5)
+  for b in cpu.blocks:
+    cpu.bn[b['c3'][1]][0].data.fill_(0.5)
+  opt = train.MomentumOptimizer(lr, mu, use_nesterov=True, graph=g)
+  gs = g.get_or_create_global_step()
+  x, y = resnet50.synthetic_batch(8, DEV, precision='float32')
+  x64, y64 = x.double().cpu().permute(0, 3, 1, 2).contiguous(), y.cpu()
+  torch.set_num_threads(min(torch.get_num_threads(), 32))
+  report = []
+  for step in range(3):
+    with _Decisions().record() as dec:
+      loss = model.loss(x, y, label_smoothing=0.1)
+    assert loss.dtype == torch.float32
+    gv = opt.compute_gradients(loss)
+    torch.cuda.synchronize()
+    with dec.replay():
+      ref_loss = cpu.train_step(x64, y64, lr=lr, mu=mu, wd=wd, keep_dense=True)
+    assert not dec.tape
+    ref_dense = {l.scope: torch.from_numpy(cpu.dense_grads[i]) for i, l in enumerate(g.layers)}
+    _compare(step, float(loss.detach()), ref_loss, g.layers, ref_dense, report, TOL_DW_RESNET50)
+    opt.apply_gradients(gv, gs)
+
+
+def test_bf16_path_is_untouched_by_the_precision_switch():
+  """precision=None follows knob "k1_fp32" (off by default): the measured path stays bf16."""
+  from rigl_amd import ops
+  from rigl_amd.workloads import nn as gnn, resnet50
+  ops.tune_unset('k1_fp32')
+  assert gnn.activation_dtype() == torch.bfloat16
+  assert resnet50.synthetic_batch(1, DEV, image_size=32)[0].dtype == torch.bfloat16
+  ops.tune_set('k1_fp32', 1)
+  try:
+    assert resnet50.synthetic_batch(1, DEV, image_size=32)[0].dtype == torch.float32
+  finally:
+    ops.tune_unset('k1_fp32')
+  with pytest.raises(ValueError):
+    gnn.activation_dtype('float16')

@@ -275,3 +275,40 @@ def test_c_oracle_agrees_with_numpy_oracle_and_reference():
     if g('mom') is not None:
       np.testing.assert_array_equal(nmom, g('new_mom').reshape(-1), err_msg=n)
     assert counts[4] == 0
+
+
+def test_resnet_cpu_restatement_float64_twin_and_update_rule():
+  """oracle/resnet_cpu.py: the float64 evaluation (what tests/test_k1_fp32_gpu.py holds the fp32 kernels against) is
+  the same model as the float32 one, and one train_step applies TF's Nesterov ApplyMomentum to EVERY trainable
+  variable -- masked kernels with mask * dense + wd * W, batch-norm parameters and the fc bias without a regulariser
+  (imagenet_train_eval.py:360-361; O.momentum_apply is the bit-level statement of the same rule)."""
+  torch = pytest.importorskip('torch')
+  from oracle.resnet_cpu import ResNet50CPU
+  torch.set_num_threads(min(torch.get_num_threads(), 8))
+  m32 = ResNet50CPU(sparsity_by_layer=[0.8] * 54, seed=3, num_classes=10)
+  m64 = ResNet50CPU(sparsity_by_layer=[0.8] * 54, seed=3, num_classes=10, dtype=torch.float64)
+  with torch.no_grad():
+    for a, b in zip(m32.w, m64.w):
+      b.copy_(a.double())
+  for m in (m32, m64):
+    assert all(t.dtype == m.dtype for t in m.w + m.m + m.other_params())
+  for a, b in zip(m32.m, m64.m):
+    np.testing.assert_array_equal(a.numpy(), b.numpy())
+  x = torch.randn(2, 3, 64, 64)
+  y = torch.tensor([1, 7])
+  w0 = [w.detach().clone() for w in m32.w]
+  o0 = [p.detach().clone() for p in m32.other_params()]
+  l32 = m32.train_step(x, y, lr=0.1, mu=0.9, wd=1e-4, keep_dense=True)
+  l64 = m64.train_step(x.double(), y, lr=0.1, mu=0.9, wd=1e-4, keep_dense=True)
+  assert abs(l32 - l64) <= 1e-5 * abs(l64)
+  # the update, restated: accum starts at zero, so accum' = g and W' = W - lr * g - lr * mu * g
+  for i in (0, 5, 53):
+    g = m32.m[i].numpy() * m32.dense_grads[i] + np.float32(1e-4) * w0[i].numpy()
+    w_ref, a_ref = O.momentum_apply(w0[i].numpy(), np.zeros_like(g), g, 0.1, 0.9)
+    np.testing.assert_allclose(m32.w[i].detach().numpy(), w_ref, rtol=0, atol=2e-7 * np.abs(w_ref).max())
+    np.testing.assert_allclose(m32.mom[i].numpy(), a_ref, rtol=0, atol=1e-6 * np.abs(a_ref).max())
+  moved = [float((p.detach() - q).abs().max()) for p, q in zip(m32.other_params(), o0)]
+  # the fc bias and the stem's batch norm are trained (inside the residual branches the zero-initialised last gamma
+  # of every block leaves the branch's own parameters without a gradient at step 0)
+  assert moved[-1] > 0 and moved[0] > 0 and moved[1] > 0
+  assert float(m32.mom_other[-1].abs().max()) > 0
