@@ -291,6 +291,35 @@ int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x,
                            rigl_bf16* dx /* nullable */, void* workspace,
                            size_t workspace_bytes, rigl_stream_t stream);
 
+/* rigl_masked_conv2d_bwd whose addend is the gradient of a SUBSAMPLED view of
+ * the conv's input: addend = bf16 [n][ceil(h / sub_h)][ceil(w / sub_w)][cin],
+ * added to dX at the pixels with h % sub_h == 0 and w % sub_w == 0 (elsewhere
+ * dX = dgrad).  The first block of a ResNet group reads its input twice -- conv1
+ * and the strided 1x1 projection shortcut (resnet_model.py:456-501,
+ * conv2d_fixed_padding with kernel 1: no padding, pixels (2i, 2j)) -- and the
+ * projection's input gradient is zero off that grid; it is computed as the dgrad
+ * of a stride-1 1x1 conv over the [n, ho, wo] grid (rigl_masked_conv2d_dgrad with
+ * such a descriptor) and handed over compact: a quarter of the bytes written and
+ * read, and none of the strided dgrad's zero rows.  dX is bit-identical to
+ * rigl_masked_conv2d_bwd fed the same gradient scattered into a zero tensor.
+ * Runs on the implicit-GEMM body whatever the layer (the only epilogue with this
+ * addressing); sub_h = sub_w = 1 is rigl_masked_conv2d_bwd.                    */
+/* The other half of that hand-over: the backward of a STRIDED 1x1 conv without
+ * padding (ho = ceil(h / stride_h), wo likewise) with dX on the conv's own grid:
+ * dx_grid = bf16 [n][ho][wo][cin], the gradient at the pixels the conv read (it is
+ * zero at every other pixel, which is not written anywhere) = the dgrad of the
+ * stride-1 1x1 conv over that grid; dW (dense, overwritten) from x as it lies.
+ * One shared launch like rigl_masked_conv2d_bwd; workspace as for it.           */
+int rigl_masked_conv2d_bwd_grid(const RiglConvDesc* d, const rigl_bf16* x,
+                                const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                                float* dw, rigl_bf16* dx_grid, void* workspace,
+                                size_t workspace_bytes, rigl_stream_t stream);
+int rigl_masked_conv2d_bwd_sub(const RiglConvDesc* d, const rigl_bf16* x,
+                               const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                               const rigl_bf16* addend, int32_t sub_h, int32_t sub_w,
+                               float* dw, rigl_bf16* dx, void* workspace,
+                               size_t workspace_bytes, rigl_stream_t stream);
+
 /* rigl_masked_conv2d_bwd with the BATCH-NORM BACKWARD REDUCTIONS of the
  * tensor dX is the gradient of riding in the dgrad epilogue.  In the reference every
  * conv input is y = relu?(batch_norm(x_bn) [+ shortcut]) (resnet_model.py:41-82,

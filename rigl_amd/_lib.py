@@ -112,6 +112,8 @@ SIGNATURES = {
     'rigl_masked_conv2d_bwd_bn': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ,
                                             C.POINTER(BnReduceFuse), _P]),
     'rigl_masked_conv2d_bwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    'rigl_masked_conv2d_bwd_grid': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    'rigl_masked_conv2d_bwd_sub': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _SZ, _P]),
     'rigl_masked_conv2d_wgrad': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P,
                                            _SZ, _P]),
     'rigl_conv2d_fwd_ref': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),

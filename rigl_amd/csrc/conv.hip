@@ -134,6 +134,10 @@ struct IgemmArgs {
   const uint16_t* B;   // packed weights
   void* C;             // output rows
   const uint16_t* ADD; // optional bf16 tensor added to the bf16 output rows (same layout as C), or NULL
+  // ADD of a SUBSAMPLED view (add_sh > 0): the addend has one row per output pixel (hi, wi) with hi % add_sh == 0 and
+  // wi % add_sw == 0, laid out [image][add_ho][add_wo][N]; every other pixel adds nothing.  (The gradient of a strided
+  // 1x1 conv that read the same tensor: rigl_masked_conv2d_bwd_sub.)
+  int add_sh, add_sw, add_ho, add_wo;
   float* STATS;        // optional per-row-tile column statistics [tiles_m][2][N]: sum y, sum y^2 of the bf16 outputs (fwd);
                        // with BNX (dgrad): sum dz, sum dz * xhat -- the batch-norm backward reductions of the produced tensor
   const uint16_t* BNX; // dgrad only, optional: input x of the batch norm whose OUTPUT gradient this kernel produces ([M][N] like C)
@@ -162,6 +166,16 @@ struct IgemmArgs {
   float* KS_SLAB; uint32_t* KS_CNT; int ksplit;
   FastDiv fd_rw, fd_rh, fd_cwc[4], fd_chc[4];
 };
+
+// Row of the subsampled addend that output row m (a pixel of the RH x RW row space) takes, or false: none.
+__device__ __forceinline__ bool addend_sub_row(const IgemmArgs& P, int m, int64_t& am) {
+  const int t = fdiv(m, P.fd_rw);
+  const int wi = m - t * P.RW, img = fdiv(t, P.fd_rh), hi = t - img * P.RH;
+  const int qh = hi / P.add_sh, qw = wi / P.add_sw;
+  if (qh * P.add_sh != hi || qw * P.add_sw != wi) return false;
+  am = ((int64_t)img * P.add_ho + qh) * P.add_wo + qw;
+  return true;
+}
 
 // STAGES: 2 = register-staged double buffer; 3 = LDS-DMA ring of that depth (a 4-deep ring and a 2-deep one under a
 // 128-VGPR cap were measured in rounds 1-2: 4-7 % slower over the layer set / neutral, and are gone).
@@ -611,8 +625,10 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P, unsigned char* sm
         for (int it = 0; it < ITERS; ++it) {
           const int idx = it * THREADS + tid, row = idx / CH, ch = idx % CH;
           const int m = CLS ? rowpix[row] : m0 + row, n = n0 + ch * 8;
-          addv[it] = (m >= 0 && m < P.M && n < P.N) ? *reinterpret_cast<const uint4*>(P.ADD + (int64_t)m * P.ldc + n)
-                                                    : make_uint4(0u, 0u, 0u, 0u);
+          bool aok = m >= 0 && m < P.M && n < P.N;
+          int64_t am = m;
+          if (P.add_sh && aok) aok = addend_sub_row(P, m, am);
+          addv[it] = aok ? *reinterpret_cast<const uint4*>(P.ADD + am * P.ldc + n) : make_uint4(0u, 0u, 0u, 0u);
         }
       }
 #pragma unroll
@@ -1550,8 +1566,17 @@ static int attach_bn(rigl::k1::IgemmArgs& a, const RiglConvDesc* d, const RiglBn
   return RIGL_OK;
 }
 
+// The addend of a dgrad may be the gradient of a SUBSAMPLED view of the tensor (sh, sw > 1: one row per pixel with
+// h % sh == 0 and w % sw == 0); only the igemm body's epilogue takes that form, so such a call stays on it.
+struct AddendSub { int sh, sw; };
+static inline bool addend_is_sub(const rigl_bf16* addend, AddendSub s) { return addend && (s.sh > 1 || s.sw > 1); }
+static void set_addend_sub(rigl::k1::IgemmArgs& a, const RiglConvDesc* d, AddendSub s) {
+  a.add_sh = s.sh; a.add_sw = s.sw;
+  a.add_ho = (d->h + s.sh - 1) / s.sh; a.add_wo = (d->w + s.sw - 1) / s.sw;
+}
+
 static int dgrad_impl(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf16* w_hwio, const rigl_bf16* addend,
-                      rigl_bf16* dx, const RiglBnReduceFuse* bn, rigl_stream_t stream);
+                      rigl_bf16* dx, const RiglBnReduceFuse* bn, rigl_stream_t stream, AddendSub sub = {1, 1});
 
 int rigl_masked_conv2d_dgrad_acc(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf16* w_hwio,
                                  const rigl_bf16* addend, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
@@ -1561,7 +1586,7 @@ int rigl_masked_conv2d_dgrad_acc(const RiglConvDesc* d, const rigl_bf16* dy, con
 }
 
 static int dgrad_impl(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf16* w_hwio, const rigl_bf16* addend,
-                      rigl_bf16* dx, const RiglBnReduceFuse* bn, rigl_stream_t stream) {
+                      rigl_bf16* dx, const RiglBnReduceFuse* bn, rigl_stream_t stream, AddendSub sub) {
   using namespace rigl;
   using namespace rigl::k1;
   int rc = check_desc(d, "rigl_masked_conv2d_dgrad");
@@ -1571,6 +1596,14 @@ static int dgrad_impl(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf1
   hipStream_t st = as_stream(stream);
   prof_set_tag(d);
   ProfFamily prof(PROF_CONV_DGRAD);
+  if (addend_is_sub(addend, sub)) {
+    if (bn) return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_dgrad: a subsampled addend and the batch-norm reductions do not combine");
+    IgemmArgs a = dgrad_args(d, dy, w_hwio, addend, dx);
+    set_addend_sub(a, d, sub);
+    launch_igemm<1, false>(a, st);
+    RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
+    return RIGL_OK;
+  }
   if (!bn && bwd1x1_kind(d)) {
     // the big-M 1x1 layers: dX from the single-pass backward kernel (without its weight-gradient half), so that it has
     // the bits rigl_masked_conv2d_bwd gives it
@@ -1712,7 +1745,8 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
 
 static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
                     const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
-                    const RiglBnReduceFuse* bn, rigl_stream_t stream);
+                    const RiglBnReduceFuse* bn, rigl_stream_t stream, AddendSub sub = {1, 1},
+                    const RiglConvDesc* dg = nullptr);
 
 // rigl_masked_conv2d_bwd with the batch-norm backward reductions of the tensor dX is the gradient of riding in the dgrad
 // epilogue.
@@ -1725,21 +1759,29 @@ int rigl_masked_conv2d_bwd_bn(const RiglConvDesc* d, const rigl_bf16* x, const r
 
 static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
                     const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
-                    const RiglBnReduceFuse* bn, rigl_stream_t stream) {
+                    const RiglBnReduceFuse* bn, rigl_stream_t stream, AddendSub sub, const RiglConvDesc* dg) {
+  // dg (rigl_masked_conv2d_bwd_grid): the dgrad half runs on THIS descriptor -- the stride-1 twin of a strided 1x1 conv
+  // on its own output grid -- while the weight gradient reads x through d; the two halves of the shared launch take
+  // their geometry from separate argument blocks anyway.
   using namespace rigl;
   using namespace rigl::k1;
   static const bool fuse = [] { const char* e = getenv("RIGL_BWD_FUSED"); return e ? atoi(e) != 0 : true; }();
+  const RiglConvDesc* dd = dg ? dg : d;
   int rc = check_desc(d, "rigl_masked_conv2d_bwd");
   if (rc) return rc;
   hipStream_t st = as_stream(stream);
   prof_set_tag(d);
-  const bool whole = dx && x && dy && w_hwio && dw;        // both gradients asked for, every operand there
+  const bool subadd = addend_is_sub(addend, sub);          // (only the igemm body's epilogue: the special paths step aside)
+  if (subadd && bn) return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_bwd: a subsampled addend and the batch-norm reductions do not combine");
+  if (subadd && !dx) return fail(RIGL_EINVAL, "rigl_masked_conv2d_bwd: an addend without dX");
+  const bool both = dx && x && dy && w_hwio && dw;          // both gradients asked for, every operand there
+  const bool whole = both && !subadd && !dg;                // ... and nothing that keeps the layer off its special kernels
   const size_t need = rigl_conv2d_workspace_bytes(d, 2);
   // A layer's dX must come from the same kernel whichever entry point computes it (rigl_masked_conv2d_dgrad or this
   // one): the ping-pong body accumulates in another order than the igemm body of the shared launch, so layers whose
   // dgrad has a ping-pong plan run wgrad and dgrad as two launches.
   bool dgrad_pp = false;
-  if (dx && (d->cin % 8) == 0 && (d->cout % 8) == 0 && !bn) {
+  if (dx && (d->cin % 8) == 0 && (d->cout % 8) == 0 && !bn && !subadd && !dg) {
     const IgemmArgs ap = dgrad_args(d, dy, w_hwio, addend, dx);
     dgrad_pp = plan_pp<1>(ap).variant != 0;
   }
@@ -1782,8 +1824,8 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
   }
   // The shared launch on the 8-wave ping-pong bodies ("pp_bwd"): layers whose weight gradient has 256-channel tiles and
   // whose dgrad is a long reduction.
-  if (RIGL_TUNE("pp_bwd", -1) != 0 && whole && !bn && !tiny_cin(d) && !small_cin(d) && pp_wgrad_legal(d)) {
-    IgemmArgs ad = dgrad_args(d, dy, w_hwio, addend, dx);
+  if (RIGL_TUNE("pp_bwd", -1) != 0 && both && !subadd && !bn && !tiny_cin(d) && !small_cin(d) && pp_wgrad_legal(d)) {
+    IgemmArgs ad = dgrad_args(dd, dy, w_hwio, addend, dx);
     const int dvar = RIGL_TUNE("pp_dgrad", -1) >= 0 ? PP_NONE : pp_bwd_dgrad_variant(ad);   // (a forced stand-alone dgrad tile wins)
     if (dvar != PP_NONE && pp_legal<1>(ad, dvar)) {
       int bm, bn2;
@@ -1792,7 +1834,7 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
       const int tiles_m = strided ? pp_fill_classes(ad, bm) : (ad.M + bm - 1) / bm;
       const unsigned nd = (unsigned)(tiles_m * (ad.N / bn2));
       // dgrad workgroup length in 256x256-tile K-tile units (a parity class visits about taps / (sh * sw) of the taps)
-      const int kt_d = (int)((int64_t)d->kh * d->kw * (d->cout / 64) * bm * bn2 / (256 * 256) / (d->stride_h * d->stride_w));
+      const int kt_d = (int)((int64_t)dd->kh * dd->kw * (dd->cout / 64) * bm * bn2 / (256 * 256) / (dd->stride_h * dd->stride_w));
       const PPBwdPlan pw = plan_wgrad_pp(d, nd, kt_d);
       if (need && (!workspace || workspace_bytes < need))
         return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
@@ -1810,8 +1852,9 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
       }
     }
   }
-  if (fuse && !dgrad_pp && whole && !tiny_cin(d) && !small_cin(d) && (d->cin % 8) == 0 && (d->cout % 8) == 0) {
-    IgemmArgs ad = dgrad_args(d, dy, w_hwio, addend, dx);
+  if (fuse && !dgrad_pp && both && !tiny_cin(d) && !small_cin(d) && (d->cin % 8) == 0 && (d->cout % 8) == 0) {
+    IgemmArgs ad = dgrad_args(dd, dy, w_hwio, addend, dx);
+    if (subadd) set_addend_sub(ad, dd, sub);
     rc = attach_bn(ad, d, bn);
     if (rc) return rc;
     const IgemmPlan pd = plan_igemm<1>(ad);
@@ -1855,7 +1898,7 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
   }
   rc = rigl_masked_conv2d_wgrad(d, x, dy, dw, workspace, workspace_bytes, stream);
   if (rc || !dx) return rc;
-  return dgrad_impl(d, dy, w_hwio, addend, dx, bn, stream);
+  return dgrad_impl(dd, dy, w_hwio, addend, dx, bn, stream, sub);
 }
 
 // Whole backward of one masked conv in one call: dW (dense) and, when dx is given, dX (+ addend).
@@ -1866,6 +1909,36 @@ int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl
                            const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
                            rigl_stream_t stream) {
   return bwd_impl(d, x, dy, w_hwio, addend, dw, dx, workspace, workspace_bytes, nullptr, stream);
+}
+
+// rigl_masked_conv2d_bwd whose addend is the gradient of a SUBSAMPLED view of the conv's input: [n][ceil(h / sub_h)][ceil(w /
+// sub_w)][cin], added at the pixels with h % sub_h == 0 and w % sub_w == 0 (the first block of a ResNet group: the block
+// input feeds conv1 and a strided 1x1 projection, whose input gradient exists only at every sub-th pixel and is handed over
+// compact instead of as a full-size tensor that is three quarters zeros).
+// Backward of a STRIDED 1x1 conv without padding whose dX is wanted on the conv's own grid only (the pixels it read):
+// dx_grid[n][ho][wo][cin] = the dgrad of the stride-1 1x1 conv over that grid (its consumer: rigl_masked_conv2d_bwd_sub of
+// the other reader of the tensor), dW from x as it lies -- one shared launch, the dgrad half on the compact descriptor.
+int rigl_masked_conv2d_bwd_grid(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                                float* dw, rigl_bf16* dx_grid, void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+  using namespace rigl;
+  using namespace rigl::k1;
+  int rc = check_desc(d, "rigl_masked_conv2d_bwd_grid");
+  if (rc) return rc;
+  if (d->kh != 1 || d->kw != 1 || d->pad_top || d->pad_left || d->ho != (d->h + d->stride_h - 1) / d->stride_h ||
+      d->wo != (d->w + d->stride_w - 1) / d->stride_w)
+    return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_bwd_grid: a 1x1 conv without padding whose output grid is every stride-th pixel");
+  if (!x || !dy || !w_hwio || !dw || !dx_grid) return fail(RIGL_EINVAL, "rigl_masked_conv2d_bwd_grid: NULL tensor");
+  if ((d->cin % 8) || (d->cout % 8)) return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_bwd_grid: cin/cout %% 8 != 0");
+  RiglConvDesc g = *d;
+  g.h = d->ho; g.w = d->wo; g.stride_h = g.stride_w = 1;
+  return bwd_impl(d, x, dy, w_hwio, nullptr, dw, dx_grid, workspace, workspace_bytes, nullptr, stream, AddendSub{1, 1}, &g);
+}
+
+int rigl_masked_conv2d_bwd_sub(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                               const rigl_bf16* addend, int32_t sub_h, int32_t sub_w, float* dw, rigl_bf16* dx,
+                               void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+  if (sub_h < 1 || sub_w < 1) return rigl::fail(RIGL_EINVAL, "rigl_masked_conv2d_bwd_sub: subsampling factors must be >= 1");
+  return bwd_impl(d, x, dy, w_hwio, addend, dw, dx, workspace, workspace_bytes, nullptr, stream, AddendSub{sub_h, sub_w});
 }
 
 

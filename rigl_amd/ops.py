@@ -402,14 +402,23 @@ def dgrad_stats_parts(d):
   return v
 
 
-def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None, bn_fuse=None):
+def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None, bn_fuse=None, addend_sub=None):
   """dW (into ``dw``, dense fp32) and -- when ``need_dx`` -- dX (+ ``addend``) of one conv with a single host
   transition and, for ordinary layers, a single launch (rigl_masked_conv2d_bwd) followed by the split-K reduce that
   completes dW.  ``on_dw_ready`` is called once dW's last kernel has been enqueued (the data-parallel exchange launches
   its buckets from there).  Returns dX or None.
   ``bn_fuse`` = dict(x=, saved=, relu=, relu_bits=) of the batch norm whose output this conv read: its backward
   reductions are computed in the dgrad epilogue (rigl_masked_conv2d_bwd_bn) and returned as
-  ``bn_fuse['partials']`` (fp32 [parts, 2, Cin]) for bn_bwd; left unset where the layer's kernels cannot."""
+  ``bn_fuse['partials']`` (fp32 [parts, 2, Cin]) for bn_bwd; left unset where the layer's kernels cannot.
+  ``addend_sub`` = (sh, sw): ``addend`` is the gradient of the subsampled view x[:, ::sh, ::sw, :] -- bf16
+  [n, ceil(h / sh), ceil(w / sw), cin] -- added at those pixels only (rigl_masked_conv2d_bwd_sub)."""
+  if addend_sub is not None and tuple(addend_sub) == (1, 1):
+    addend_sub = None
+  if addend_sub is not None:
+    if addend is None or not need_dx or bn_fuse is not None:
+      raise ValueError('addend_sub needs an addend and dX, and does not combine with bn_fuse')
+    if not (mfma_supported(d) and mfma_dgrad_supported(d)):
+      raise ValueError('addend_sub needs cin % 8 == cout % 8 == 0')
   if bn_fuse is not None:
     bn_fuse.pop('partials', None)
     if not (need_dx and mfma_supported(d) and mfma_dgrad_supported(d) and dgrad_stats_parts(d) > 0):
@@ -435,8 +444,18 @@ def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None, 
   if need_dx:
     _req(w_hwio, torch.bfloat16, 'w_hwio')
     dx = torch.empty((d.n, d.h, d.w, d.cin), dtype=torch.bfloat16, device=dy.device)
-    if addend is not None and addend.numel() != dx.numel():
+    if addend is not None and addend_sub is None and addend.numel() != dx.numel():
       raise ValueError('addend must have the shape of dx')
+  if addend_sub is not None:
+    sh, sw = addend_sub
+    if addend.numel() != d.n * (-(-d.h // sh)) * (-(-d.w // sw)) * d.cin:
+      raise ValueError('addend must be [n, ceil(h / sh), ceil(w / sw), cin]')
+    check(lib.rigl_masked_conv2d_bwd_sub(
+        C.byref(d), _ptr(x), _ptr(dy), _ptr(w_hwio), _ptr(addend), int(sh), int(sw), _ptr(dw), _ptr(dx), _ptr(ws),
+        ws.numel() if ws is not None else 0, _stream()))
+    if on_dw_ready is not None:
+      on_dw_ready()
+    return dx
   bn = None
   if bn_fuse is not None:
     bx, saved = bn_fuse['x'], bn_fuse['saved']
@@ -453,6 +472,30 @@ def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None, 
   check(lib.rigl_masked_conv2d_bwd_bn(
       C.byref(d), _ptr(x), _ptr(dy), _ptr(w_hwio), _ptr(addend), _ptr(dw), _ptr(dx), _ptr(ws),
       ws.numel() if ws is not None else 0, C.byref(bn) if bn is not None else None, _stream()))
+  if on_dw_ready is not None:
+    on_dw_ready()
+  return dx
+
+
+def conv_bwd_grid(d, x, dy, w_hwio, dw, on_dw_ready=None):
+  """Backward of a strided 1x1 conv without padding with dX on the conv's own grid: returns bf16 [n, ho, wo, cin] -- the
+  gradient at the pixels the conv read (zero elsewhere, never materialised) -- and writes the dense dW
+  (rigl_masked_conv2d_bwd_grid).  The consumer is conv_bwd(..., addend=that, addend_sub=strides) of the tensor's other
+  reader."""
+  _req(x, torch.bfloat16, 'x')
+  _req(dy, torch.bfloat16, 'dy')
+  _req(w_hwio, torch.bfloat16, 'w_hwio')
+  _req(dw, torch.float32, 'dw')
+  lib = _lib.load()
+  _count_macs('wgrad_macs', d)
+  _count_macs('dgrad_macs', ConvDesc(d.n, d.ho, d.wo, d.cin, d.ho, d.wo, d.cout, 1, 1, 1, 1, 0, 0))
+  need = getattr(d, '_ws_wgrad', None)
+  if need is None:
+    need = d._ws_wgrad = lib.rigl_conv2d_workspace_bytes(C.byref(d), 2)
+  ws = workspace(need, x.device, 'wg') if need else None
+  dx = torch.empty((d.n, d.ho, d.wo, d.cin), dtype=torch.bfloat16, device=dy.device)
+  check(lib.rigl_masked_conv2d_bwd_grid(C.byref(d), _ptr(x), _ptr(dy), _ptr(w_hwio), _ptr(dw), _ptr(dx), _ptr(ws),
+                                        ws.numel() if ws is not None else 0, _stream()))
   if on_dw_ready is not None:
     on_dw_ready()
   return dx

@@ -169,6 +169,75 @@ class _MaskedConvForkFn(torch.autograd.Function):
     return dx, None, None, None, None
 
 
+class _MaskedConvPairFn(torch.autograd.Function):
+  """(y_s, y_m) = (conv_s(x), conv_m(x)): the two readers of a tensor where conv_s is a STRIDED 1x1 conv without padding
+  -- the projection shortcut of a ResNet group's first block next to its conv1 (resnet_model.py:456-501).  conv_s only
+  reads the pixels (i * sh, j * sw), so dL/dx through it is zero everywhere else.  As two autograd nodes that gradient is
+  a full-size tensor (three quarters zeros at stride 2) written by a strided dgrad and read back by the other conv's
+  accumulating epilogue; as ONE node it is computed on the [n, ho, wo] grid as the dgrad of a stride-1 1x1 conv and
+  handed to conv_m's dgrad epilogue compact (rigl_masked_conv2d_bwd_sub): dx = dgrad_m(dy_m) + scatter(dgrad_s(dy_s)).
+  Both dense dW go straight into their gradient-arena slices, as in _MaskedConvFn."""
+
+  @staticmethod
+  def forward(ctx, x, lv_s, d_s, lv_m, d_m, want_stats):
+    ctx.lv_s, ctx.d_s, ctx.lv_m, ctx.d_m = lv_s, d_s, lv_m, d_m
+    ctx.save_for_backward(x)
+    if not want_stats:
+      return ops.conv_fwd(d_s, x, lv_s.ohwi), ops.conv_fwd(d_m, x, lv_m.ohwi)
+    ys, ps = ops.conv_fwd(d_s, x, lv_s.ohwi, stats=True)
+    ym, pm = ops.conv_fwd(d_m, x, lv_m.ohwi, stats=True)
+    ps = ps if ps is not None else torch.empty(0, device=x.device)
+    pm = pm if pm is not None else torch.empty(0, device=x.device)
+    ctx.mark_non_differentiable(ps, pm)
+    ctx.set_materialize_grads(False)
+    return ys, ym, ps, pm
+
+  @staticmethod
+  def backward(ctx, dys, dym, _dps=None, _dpm=None):
+    (x,) = ctx.saved_tensors
+    lv_s, d_s, lv_m, d_m = ctx.lv_s, ctx.d_s, ctx.lv_m, ctx.d_m
+    if dys is None:
+      dys = torch.zeros((d_s.n, d_s.ho, d_s.wo, d_s.cout), dtype=torch.bfloat16, device=x.device)
+    if dym is None:
+      dym = torch.zeros((d_m.n, d_m.ho, d_m.wo, d_m.cout), dtype=torch.bfloat16, device=x.device)
+    dys, dym = dys.contiguous(), dym.contiguous()
+    sync = getattr(lv_s.weights.graph, 'grad_sync', None)
+    ready = (lambda lv: (lambda: sync.notify_layer_grad_ready(lv.weights))) if sync is not None else (lambda lv: None)
+    # the strided conv: dW from x as it lies; dX on its own grid only (= the dgrad of a stride-1 1x1 conv over that grid)
+    dxs = ops.conv_bwd_grid(d_s, x, dys, lv_s.hwio, lv_s.weights.grad.view(-1), on_dw_ready=ready(lv_s))
+    dx = ops.conv_bwd(d_m, x, dym, lv_m.hwio, lv_m.weights.grad.view(-1), need_dx=True, addend=dxs,
+                      addend_sub=(d_s.stride_h, d_s.stride_w), on_dw_ready=ready(lv_m))
+    return dx, None, None, None, None, None
+
+
+def conv_pair(conv_sub, conv_main, x, bn_stats=False):
+  """(conv_sub(x), conv_main(x)) for a tensor read by exactly these two convs, conv_sub a strided 1x1 conv (see
+  _MaskedConvPairFn); any other pair of layers -- and fp32 activations -- take conv_sub.fork(x) + conv_main(alias)."""
+  n, h, w, c = x.shape
+  ok = (x.dtype == torch.bfloat16 and x.requires_grad and conv_sub.need_input_grad and conv_main.need_input_grad
+        and conv_sub.kh == conv_sub.kw == 1 and max(conv_sub.strides) > 1
+        and conv_sub.cin % 8 == 0 and conv_sub.units % 8 == 0 and conv_main.units % 8 == 0
+        and os.environ.get('RIGL_CONV_PAIR', '1') != '0')
+  d_s = conv_sub.desc_for(n, h, w) if ok else None
+  if ok and (d_s.pad_top or d_s.pad_left or d_s.ho != -(-h // d_s.stride_h) or d_s.wo != -(-w // d_s.stride_w)):
+    ok = False
+  if not ok:
+    ys, alias = conv_sub.fork(x, bn_stats)
+    return ys, conv_main(alias, bn_stats)
+  if c != conv_sub.cin or c != conv_main.cin:
+    raise ValueError('expected [N,H,W,%d], got %s' % (conv_sub.cin, tuple(x.shape)))
+  conv_sub.graph.refresh_shadows()
+  d_m = conv_main.desc_for(n, h, w)
+  if not bn_stats:
+    return _MaskedConvPairFn.apply(x.contiguous(), conv_sub.vars, d_s, conv_main.vars, d_m, False)
+  ys, ym, ps, pm = _MaskedConvPairFn.apply(x.contiguous(), conv_sub.vars, d_s, conv_main.vars, d_m, True)
+  if ps.numel():
+    ys.bn_partials = ps
+  if pm.numel():
+    ym.bn_partials = pm
+  return ys, ym
+
+
 class _Layer:
   """Common part of MaskedConv2d / MaskedDense."""
 

@@ -73,8 +73,8 @@ class _Bottleneck:
     # The block input feeds two consumers; the first one hands back an alias whose
     # gradient it accumulates in its own dgrad epilogue (no separate AddN pass).
     if self.proj is not None:
-      p, x = self.proj.fork(x)
-      y = self.c1(x)
+      # (a strided projection and conv1 as one autograd node: the projection's input gradient stays on its own grid)
+      p, y = PL.conv_pair(self.proj.conv, self.c1.conv, x, bn_stats=True)
     else:
       y, shortcut = self.c1.fork(x)
     y = self.bn1(y, is_training, relu=True)

@@ -236,6 +236,30 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
     dw2 = torch.empty_like(dw1)
     ops.conv_bwd(d, x, dy, hwio, dw2, need_dx=has_dx, addend=add if has_dx else None)
     assert torch.equal(dw1.view(torch.int32), dw2.view(torch.int32)), 'bwd.dw not deterministic'
+    if has_dx:
+      # the addend as the gradient of a SUBSAMPLED view (rigl_masked_conv2d_bwd_sub): added at the pixels (2i, 2j) only.
+      # That call runs on the implicit-GEMM body whatever the layer's default kernel, so its dgrad is taken from the same
+      # call with a zero addend (and checked against the reference), and the addition must then be exact.
+      addc = add[:, ::2, ::2, :].contiguous()
+      full = torch.zeros_like(add)
+      full[:, ::2, ::2, :] = addc
+      dw3 = torch.empty_like(dw1)
+      dx0 = ops.conv_bwd(d, x, dy, hwio, dw3, need_dx=True, addend=torch.zeros_like(addc), addend_sub=(2, 2))
+      worst = max(worst, convref.check_close('bwd_sub.dgrad', dx0, ref['dx'], ab['dx'], 1e-5, 2.0 ** -8))
+      worst = max(worst, convref.check_close('bwd_sub.dw', dw3.reshape(k, k, Cin, Cout), ref['dw'], ab['dw'], 1e-5))
+      dx3 = ops.conv_bwd(d, x, dy, hwio, dw3, need_dx=True, addend=addc, addend_sub=(2, 2))
+      assert torch.equal(dx3.view(torch.int16), (dx0 + full).view(torch.int16)), 'bwd_sub.dx != dgrad + scattered addend'
+      del dx0, dx3, full, addc
+    if has_dx and k == 1 and stride > 1 and pt == 0 and pl == 0 and Ho == -(-H // stride) and Wo == -(-W // stride):
+      # a strided 1x1 conv: dX on its own grid only (rigl_masked_conv2d_bwd_grid) = the reference's dX at those pixels
+      dw4 = torch.empty_like(dw1)
+      dxg = ops.conv_bwd_grid(d, x, dy, hwio, dw4)
+      worst = max(worst, convref.check_close('bwd_grid.dx', dxg, ref['dx'][:, ::stride, ::stride, :], ab['dx'][:, ::stride, ::stride, :],
+                                             1e-5, 2.0 ** -8))
+      worst = max(worst, convref.check_close('bwd_grid.dw', dw4.reshape(k, k, Cin, Cout), ref['dw'], ab['dw'], 1e-5))
+      off = torch.ones(H, W, dtype=torch.bool, device=DEV)
+      off[::stride, ::stride] = False
+      assert float(ref['dx'][:, off].abs().max()) == 0.0        # (what is not materialised is exactly zero)
   torch.cuda.synchronize()
   return worst
 
