@@ -666,11 +666,19 @@ class SparseDNWOptimizer(PruningGetterMixin, train.Optimizer):
         masks, self._mask_init_method, self._default_sparsity,
         self._custom_sparsity_map)
     items = []
-    for l in self.graph.masked_layers():
+    g = self.graph
+    # |W| of the whole masked segment in one pass over the arena (one launch, not one per layer); a layer's scores are a
+    # view of it.  Graphs that were not finalised (no arena) take the per-layer form.
+    seg = g.seg.get(V.KIND_MASKED) if getattr(g, 'finalized', False) else None
+    score = g.W[seg[0]:seg[1]].abs() if seg and seg[1] > seg[0] else None
+    for l in g.masked_layers():
       n = l.weights.numel
       n_keep = n - sparse_utils.get_n_zeros(n, sparsities[l.mask.name])
-      items.append((l.weights.data.abs().contiguous().view(-1), n_keep,
-                    l.mask.bits))
+      if score is not None and seg[0] <= l.weights.offset and l.weights.offset + n <= seg[1]:
+        sc = score[l.weights.offset - seg[0]:l.weights.offset - seg[0] + n]
+      else:
+        sc = l.weights.data.abs().contiguous().view(-1)
+      items.append((sc, n_keep, l.mask.bits))
     ops.topk_mask_batched(items)
     self.graph.shadows_dirty = True
     return None
