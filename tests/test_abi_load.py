@@ -48,6 +48,20 @@ def test_argument_errors_are_reported_not_thrown():
   assert lib.rigl_masked_conv2d_fwd(ctypes.byref(d), None, None, None, None, 0, None) == _lib.RIGL_EINVAL
   d.cout = 10
   assert lib.rigl_masked_conv2d_fwd(ctypes.byref(d), 1, 1, 1, None, 0, None) == _lib.RIGL_EUNSUPPORTED
+  # the round-4 entry points: fp32 twin, subsampled addend, grid backward
+  d.cout = 8
+  assert lib.rigl_masked_conv2d_fwd_f32(ctypes.byref(d), None, None, None, None, None) == _lib.RIGL_EINVAL
+  assert b'rigl_masked_conv2d_fwd_f32' in lib.rigl_last_error()
+  assert lib.rigl_masked_conv2d_dgrad_f32(ctypes.byref(d), None, None, None, None, None, None) == _lib.RIGL_EINVAL
+  assert lib.rigl_masked_conv2d_wgrad_f32(ctypes.byref(d), None, None, None, None, 0, None) == _lib.RIGL_EINVAL
+  assert lib.rigl_conv2d_wgrad_f32_workspace_bytes(None) == 0
+  assert lib.rigl_masked_conv2d_bwd_sub(ctypes.byref(d), 1, 1, 1, 1, 0, 2, 1, 1, None, 0, None) == _lib.RIGL_EINVAL
+  assert b'subsampling' in lib.rigl_last_error()
+  # ... the grid backward is for strided 1x1 convs without padding only
+  assert lib.rigl_masked_conv2d_bwd_grid(ctypes.byref(d), 1, 1, 1, 1, 1, None, 0, None) == _lib.RIGL_EUNSUPPORTED
+  g = _lib.ConvDesc(1, 8, 8, 8, 4, 4, 8, 1, 1, 2, 2, 0, 0)
+  assert lib.rigl_masked_conv2d_bwd_grid(ctypes.byref(g), None, None, None, None, None, None, 0, None) == _lib.RIGL_EINVAL
+  assert lib.rigl_tune_unset(None) == _lib.RIGL_EINVAL
 
 
 def test_ops_refuse_cpu_tensors():

@@ -217,3 +217,13 @@ def test_glue_compositions_fall_back_to_the_plain_ops_off_the_gpu():
     got = gnn.bn_relu_max_pool_3x3_s2_same(bn, x, training)
     want = gnn.max_pool_3x3_s2_same(bn(x, training, relu=True))
     assert got.shape == (2, 3, 3, 16) and torch.equal(got, want)
+
+
+def test_precision_flag_maps_to_the_activation_dtype():
+  """--precision of the reference (imagenet_train_eval.py:56-59): bfloat16 | float32, anything else is an error."""
+  import torch
+  from rigl_amd.workloads import nn as gnn
+  assert gnn.activation_dtype('bfloat16') == torch.bfloat16
+  assert gnn.activation_dtype('float32') == torch.float32
+  with pytest.raises(ValueError):
+    gnn.activation_dtype('float16')
