@@ -15,7 +15,7 @@ applied to the fp32 master weights on the fly), and
     three steps.  Measured: loss 3e-8 .. 8e-8; dW worst layer 1.1e-6 (WRN-22), 2.5e-5 .. 3.8e-5 (ResNet-50).
 
 Two facts about what a whole-network gradient comparison in fp32 can show, both measured with NO kernel of this repo
-involved (tools/fp32_noise_floor.py: stock torch-CPU float32 against float64 on oracle/resnet_cpu.py, batch 8):
+involved (tests/fp32_noise_floor.py: stock torch-CPU float32 against float64 on oracle/resnet_cpu.py, batch 8):
 
   1. A ReLU network's gradient is discontinuous where a pre-activation crosses zero.  Activations agree to 1e-5
      between float32 and float64, so among the 10^7 ReLU inputs of ResNet-50 a handful land on the other side of zero;
