@@ -40,7 +40,7 @@ for (H, Ci, Co) in ((56, 64, 256), (28, 128, 512), (14, 256, 1024), (56, 256, 64
   def nxt():
     turn[0] = (turn[0] + 1) % copies
     return turn[0]
-  for v in (0, 1):
+  for v in (0, int(os.environ.get('X1_ON', '1'))):
     ops.tune_set('x1x1', v)
     d = ops.conv_desc(N, H, H, Ci, Co, 1, 1, 1, 0, 0, H, H)
     it = max(10, copies)
