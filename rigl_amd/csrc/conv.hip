@@ -1315,6 +1315,7 @@ static inline int kpad(const RiglConvDesc* d) { return (d->kh * d->kw * d->cin +
 #include "stem.hpp"
 #include "c3x3.hpp"
 #include "x1x1.hpp"
+#include "rowstream.hpp"
 
 // Scratch of the K-split ping-pong forward (convpp.hpp: pp_ksplit_ok): two fp32 partial tiles + a counter per tile.
 static size_t pp_ksplit_workspace(const RiglConvDesc* d) {
@@ -1431,6 +1432,7 @@ int32_t rigl_conv2d_stats_parts(const RiglConvDesc* d) {
   const int64_t M = (int64_t)d->n * d->ho * d->wo;
   using namespace rigl::k1;
   if (c3x3_use(d)) return c3x3_stats_parts(d);     // c3x3.hpp: one partial per (persistent) workgroup
+  { RsPlan rp; if (rs_use<0>(d, &rp)) return rp.gprime; }   // rowstream.hpp: one partial per workgroup of a column slice
   if (x1x1_use<0>(d)) return x1x1_grid(d);         // x1x1.hpp: likewise
   return (int32_t)((M + 127) / 128);     // one partial per 128-row output tile
 }
@@ -1493,6 +1495,14 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, cons
     a.b_row_stride = d->kh * d->kw * d->cin; a.b_tap_stride = d->cin;
     a.a_bytes = (uint32_t)((size_t)d->n * d->h * d->w * d->cin * 2);
     a.b_bytes = (uint32_t)((size_t)d->kh * d->kw * d->cin * d->cout * 2);
+    {
+      RsPlan rp;
+      if (rs_use<0>(d, &rp)) {                 // 1x1 / stride 1: rows streamed through registers against an LDS-stationary filter slice
+        launch_rs<0>(d, rp, x, w_ohwi, nullptr, y, stats, st);
+        RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
+        return RIGL_OK;
+      }
+    }
     if (x1x1_use<0>(d)) {                      // 1x1 "expand" (64 -> 256, 128 -> 512, 256 -> 1024): rows in registers, filter chunks through LDS
       launch_x1x1<0>(d, x, w_ohwi, nullptr, y, stats, st);
       RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
@@ -1547,6 +1557,7 @@ int32_t rigl_conv2d_dgrad_stats_parts(const RiglConvDesc* d) {
   if ((d->cin % 8) || (d->cout % 8)) return 0;
   if (bwd1x1_kind(d)) return 0;               // the single-pass 1x1 backward has no reduction epilogue
   if (c3x3_use(d)) return 0;                  // nor has the slab-resident 3x3 dgrad
+  if (rs_use<1>(d)) return 0;                 // nor the row-streaming dgrad
   if (x1x1_use<1>(d)) return 0;               // nor the expand-GEMM dgrad of the 4f -> f convs
   IgemmArgs a = dgrad_args(d, nullptr, nullptr, nullptr, nullptr);
   if (plan_pp<1>(a).variant) return 0;        // the ping-pong dgrad has no reduction epilogue
@@ -1603,6 +1614,14 @@ static int dgrad_impl(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf1
     launch_igemm<1, false>(a, st);
     RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
     return RIGL_OK;
+  }
+  {
+    RsPlan rp;
+    if (!bn && rs_use<1>(d, &rp)) {             // dX[M][cin] = dY[M][cout] x W[cin][cout]^T, rows streamed (rowstream.hpp)
+      launch_rs<1>(d, rp, dy, w_hwio, addend, dx, nullptr, st);
+      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
+      return RIGL_OK;
+    }
   }
   if (!bn && bwd1x1_kind(d)) {
     // the big-M 1x1 layers: dX from the single-pass backward kernel (without its weight-gradient half), so that it has
@@ -1784,6 +1803,20 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
   if (dx && (d->cin % 8) == 0 && (d->cout % 8) == 0 && !bn && !subadd && !dg) {
     const IgemmArgs ap = dgrad_args(d, dy, w_hwio, addend, dx);
     dgrad_pp = plan_pp<1>(ap).variant != 0;
+  }
+  // Layers whose dgrad streams rows (rowstream.hpp): the weight gradient with its stand-alone plan, then the dgrad -- two
+  // launches (+ reduce) instead of the shared one
+  {
+    RsPlan rp;
+    if (whole && !bn && rs_use<1>(d, &rp)) {
+      ProfFamily prof(PROF_CONV_BWD);
+      rc = rigl_masked_conv2d_wgrad(d, x, dy, dw, workspace, workspace_bytes, stream);
+      if (rc) return rc;
+      prof_current_kind() = PROF_CONV_BWD;
+      launch_rs<1>(d, rp, dy, w_hwio, addend, dx, nullptr, st);
+      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");
+      return RIGL_OK;
+    }
   }
   // The big-M 1x1 layers: dX and dW in ONE pass over dY (bwd1x1.hpp), one slab per workgroup, then the reduce
   if (whole && !bn && bwd1x1_kind(d) && bwd1x1_ready(d)) {

@@ -296,6 +296,23 @@ def _count_depthwise(d):
     WORK['depthwise_bytes'] += 2 * d.n * (d.h * d.w + d.ho * d.wo) * d.cin
 
 
+# Plan-dependent sizes (workspace bytes, statistics parts) are asked of the library once per descriptor AND per knob
+# generation: the C-side answers follow the run-time knobs (a kernel switched on after a layer's first call changes how
+# many partial rows its forward writes; a stale, larger count would leave batch norm summing uninitialised rows).
+_TUNE_GEN = 0
+
+
+def _plan_cached(d, name, fn):
+  c = getattr(d, '_plan', None)
+  if c is None or c[0] != _TUNE_GEN:
+    c = (_TUNE_GEN, {})
+    d._plan = c
+  v = c[1].get(name)
+  if v is None:
+    v = c[1][name] = fn()
+  return v
+
+
 def conv_desc(n, h, w, cin, cout, kh, kw, stride, pad_top, pad_left, ho, wo):
   sh, sw = (stride, stride) if isinstance(stride, int) else stride
   return ConvDesc(n, h, w, cin, ho, wo, cout, kh, kw, sh, sw, pad_top,
@@ -327,10 +344,8 @@ def conv_fwd(d, x, w_ohwi, y=None, force_ref=False, stats=False):
     check(lib.rigl_conv2d_fwd_ref(C.byref(d), _ptr(x), _ptr(w_ohwi), _ptr(y),
                                   _stream()))
     return (y, None) if stats else y
-  need = getattr(d, '_ws_fwd', None)
-  if need is None:
-    need = d._ws_fwd = lib.rigl_conv2d_workspace_bytes(C.byref(d), 0)
-    d._stats_parts = lib.rigl_conv2d_stats_parts(C.byref(d))
+  need = _plan_cached(d, 'ws_fwd', lambda: lib.rigl_conv2d_workspace_bytes(C.byref(d), 0))
+  d._stats_parts = _plan_cached(d, 'stats_parts', lambda: lib.rigl_conv2d_stats_parts(C.byref(d)))
   ws = workspace(need, x.device) if need else None
   part = None
   if stats:
@@ -396,9 +411,7 @@ def conv_wgrad(d, x, dy, dw=None, force_ref=False):
 def dgrad_stats_parts(d):
   """Row tiles of this layer's dgrad kernel = rows of the batch-norm partials its epilogue can leave
   (0: the layer's dgrad has no such epilogue)."""
-  v = getattr(d, '_dgrad_parts', None)
-  if v is None:
-    v = d._dgrad_parts = int(_lib.load().rigl_conv2d_dgrad_stats_parts(C.byref(d)))
+  v = _plan_cached(d, 'dgrad_parts', lambda: int(_lib.load().rigl_conv2d_dgrad_stats_parts(C.byref(d))))
   return v
 
 
@@ -436,9 +449,7 @@ def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None, 
   _count_macs('wgrad_macs', d)
   if need_dx:
     _count_macs('dgrad_macs', d)
-  need = getattr(d, '_ws_wgrad', None)
-  if need is None:
-    need = d._ws_wgrad = lib.rigl_conv2d_workspace_bytes(C.byref(d), 2)
+  need = _plan_cached(d, 'ws_wgrad', lambda: lib.rigl_conv2d_workspace_bytes(C.byref(d), 2))
   ws = workspace(need, x.device, 'wg') if need else None
   dx = None
   if need_dx:
@@ -489,9 +500,7 @@ def conv_bwd_grid(d, x, dy, w_hwio, dw, on_dw_ready=None):
   lib = _lib.load()
   _count_macs('wgrad_macs', d)
   _count_macs('dgrad_macs', ConvDesc(d.n, d.ho, d.wo, d.cin, d.ho, d.wo, d.cout, 1, 1, 1, 1, 0, 0))
-  need = getattr(d, '_ws_wgrad', None)
-  if need is None:
-    need = d._ws_wgrad = lib.rigl_conv2d_workspace_bytes(C.byref(d), 2)
+  need = _plan_cached(d, 'ws_wgrad', lambda: lib.rigl_conv2d_workspace_bytes(C.byref(d), 2))
   ws = workspace(need, x.device, 'wg') if need else None
   dx = torch.empty((d.n, d.ho, d.wo, d.cin), dtype=torch.bfloat16, device=dy.device)
   check(lib.rigl_masked_conv2d_bwd_grid(C.byref(d), _ptr(x), _ptr(dy), _ptr(w_hwio), _ptr(dw), _ptr(dx), _ptr(ws),
@@ -527,9 +536,7 @@ def conv_bwd_f32(d, x, dy, w_hwio, mask_bits, dw, need_dx=True, addend=None, on_
   _req(mask_bits, torch.int32, 'mask_bits', allow_none=True)
   lib = _lib.load()
   _count_macs('wgrad_macs', d)
-  need = getattr(d, '_ws_wgrad_f32', None)
-  if need is None:
-    need = d._ws_wgrad_f32 = lib.rigl_conv2d_wgrad_f32_workspace_bytes(C.byref(d))
+  need = _plan_cached(d, 'ws_wgrad_f32', lambda: lib.rigl_conv2d_wgrad_f32_workspace_bytes(C.byref(d)))
   ws = workspace(need, x.device, 'wg32') if need else None
   check(lib.rigl_masked_conv2d_wgrad_f32(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws),
                                          ws.numel() if ws is not None else 0, _stream()))
@@ -559,9 +566,7 @@ def depthwise_fwd(d, x, w, stats=False):
   y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16, device=x.device)
   lib = _lib.load()
   if stats:
-    parts = getattr(d, '_dw_parts', None)
-    if parts is None:
-      parts = d._dw_parts = int(lib.rigl_depthwise_conv2d_stats_parts(C.byref(d)))
+    parts = _plan_cached(d, 'dw_parts', lambda: int(lib.rigl_depthwise_conv2d_stats_parts(C.byref(d))))
     if parts > 0:
       part = torch.empty((parts, 2, d.cout), dtype=torch.float32, device=x.device)
       check(lib.rigl_depthwise_conv2d_fwd_stats(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(part), part.numel(), _stream()))
@@ -856,13 +861,18 @@ def softmax_xent(logits, labels, label_smoothing=0.0, grad_scale=None, want_grad
 # profiling
 # ----------------------------------------------------------------------------
 def tune_set(key, value):
-  """Process-wide kernel-selection knob (rigl_tune_set); descriptors cache plan-dependent sizes, so make new ones."""
+  """Process-wide kernel-selection knob (rigl_tune_set).  The plan-dependent sizes cached on descriptors (_plan_cached)
+  are keyed on the knob generation, so a descriptor made before the call asks the library again."""
+  global _TUNE_GEN
   check(_lib.load().rigl_tune_set(key.encode(), int(value)))
+  _TUNE_GEN += 1
 
 
 def tune_unset(key):
   """Back to the knob's RIGL_<KEY> environment variable / built-in default (rigl_tune_unset)."""
+  global _TUNE_GEN
   check(_lib.load().rigl_tune_unset(key.encode()))
+  _TUNE_GEN += 1
 
 
 def tune_get(key, default=-1):

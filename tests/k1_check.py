@@ -99,6 +99,26 @@ X1_CASES = [
 ]
 
 
+# The row-streaming 1x1 body (rowstream.hpp): every (reduction, slice width) instantiation in both directions -- run with
+# RIGL_ROWSTREAM=2 so that the "reduce" shapes take it too -- fragments of fewer than 32 rows, ragged last fragments,
+# waves without a fragment, 1 .. 32 column slices
+RS_CASES = [
+    (16, 56, 56, 64, 256, 1, 1, 0, 0, 56, 56),     # fwd K = 64 / 128 columns (2 slices); dgrad K = 256 / 64 columns (1 slice)
+    (130, 23, 19, 64, 256, 1, 1, 0, 0, 23, 19),    # ... 56 810 rows: ragged
+    (16, 56, 56, 64, 64, 1, 1, 0, 0, 56, 56),      # K = 64 / 64 columns both ways
+    (8, 28, 28, 128, 64, 1, 1, 0, 0, 28, 28),      # fwd K = 128 / 64 columns; dgrad K = 64 / 128 columns; 6 272 rows on 2 048 waves
+    (64, 28, 28, 128, 512, 1, 1, 0, 0, 28, 28),    # fwd K = 128 / 128 columns (4 slices); dgrad K = 512 / 64 columns (2 slices)
+    (50, 13, 17, 128, 512, 1, 1, 0, 0, 13, 17),    # ... 11 050 rows
+    (200, 14, 14, 256, 1024, 1, 1, 0, 0, 14, 14),  # fwd K = 256 (8 slices); dgrad (K = 1024) on the other bodies
+    (128, 14, 14, 1024, 256, 1, 1, 0, 0, 14, 14),  # dgrad K = 256 / 1024 columns, the benchmarked shape (25 rows per fragment)
+    (16, 56, 56, 256, 64, 1, 1, 0, 0, 56, 56),     # fwd K = 256 / 64 columns; dgrad K = 64 / 256 columns
+    (64, 28, 28, 512, 128, 1, 1, 0, 0, 28, 28),    # fwd K = 512 / 64 columns; dgrad K = 128 / 512 columns
+    (128, 7, 7, 512, 2048, 1, 1, 0, 0, 7, 7),      # fwd K = 512, 32 slices of 64 columns, 8 workgroups per slice
+    (128, 7, 7, 2048, 512, 1, 1, 0, 0, 7, 7),      # dgrad K = 512 / 2048 columns
+    (90, 7, 7, 256, 1024, 1, 1, 0, 0, 7, 7),       # 4 410 rows: 18 rows per fragment, one pass
+]
+
+
 def _c3_tile_rows(H, W):
   """Tile height of the c3x3.hpp forward (c3x3_geom restated): the most rows whose patch + zero tail fit the 544-pixel
   LDS budget of one of the two patch buffers, one fewer where that divides H."""
@@ -184,15 +204,15 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
       rows = 128                                     # one partial per 128 output rows, whatever the tile
       c3 = (k == 3 and stride == 1 and Cin == 64 and Cout == 64 and pt == 1 and pl == 1 and
             part.shape[0] != (yf.shape[0] + rows - 1) // rows)
-      x1 = (k == 1 and stride == 1 and Cin in (64, 128, 256) and Cout >= 4 * Cin and
+      x1 = (k == 1 and stride == 1 and Cin in (64, 128, 256, 512) and
             part.shape[0] != (yf.shape[0] + rows - 1) // rows)
       stem_direct = (k == 7 and stride == 2 and Cin == 3 and Cout == 64 and pl == 3 and Ho % 16 == 0 and Wo % 16 == 0 and
                      W % 4 == 0 and ops.tune_get('stem_direct', 1) != 0)
       blk = None
       if x1:
-        # x1x1.hpp: one partial per persistent workgroup (two column halves per 128-row tile) -- the totals above are the
-        # whole check
-        assert part.shape[0] <= 2 * ((yf.shape[0] + rows - 1) // rows), 'x1x1: more statistics parts than work units'
+        # rowstream.hpp: one partial per persistent workgroup of a column slice (rigl_conv2d_stats_parts says how many) -- the
+        # totals above are the whole check
+        assert part.shape[0] <= 256, 'rowstream: more statistics parts than workgroups per slice'
       elif c3:
         # c3x3.hpp: one partial per persistent workgroup (rigl_conv2d_stats_parts says how many), each the sum over the
         # tiles that workgroup walked -- the totals above are the whole check
@@ -266,11 +286,11 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
 
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument('--set', default='small', choices=['small', 'pp', 'stem', 'c3', 'x1', 'resnet50'])
+  ap.add_argument('--set', default='small', choices=['small', 'pp', 'stem', 'c3', 'x1', 'rs', 'resnet50'])
   ap.add_argument('--batch', type=int, default=128)
   ap.add_argument('--only', type=int, default=-1)
   a = ap.parse_args()
-  cases = {'small': SMALL_CASES, 'pp': PP_CASES, 'stem': STEM_CASES, 'c3': C3_CASES, 'x1': X1_CASES}.get(a.set) or resnet50_shapes(a.batch)
+  cases = {'small': SMALL_CASES, 'pp': PP_CASES, 'stem': STEM_CASES, 'c3': C3_CASES, 'x1': X1_CASES, 'rs': RS_CASES}.get(a.set) or resnet50_shapes(a.batch)
   worst, n = 0.0, 0
   for i, c in enumerate(cases):
     if a.only >= 0 and i != a.only:

@@ -10,7 +10,7 @@ make -C "$ROOT/rigl_amd/csrc" >/dev/null
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-function "$@" \
   -c "$ROOT/rigl_amd/csrc/$src.hip" -o "$ROOT/build/alt/${src}_$name.o"
 objs=""
-for o in runtime prune_regrow optimizer conv conv_ref bn depthwise pool random head; do
+for o in runtime prune_regrow optimizer conv conv_ref conv_f32 bn depthwise pool random head; do
   [ "$o" = "$src" ] || objs="$objs $ROOT/build/$o.o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/build/alt/librigl_$name.so" "$ROOT/build/alt/${src}_$name.o" $objs
