@@ -657,20 +657,23 @@ int rigl_probe_mfma_bf16(int32_t blocks, int32_t iters, float* sink, rigl_stream
  *   "c3x3"                  0: the 3x3 / 64 -> 64 / stride-1 layers (24 <= w <=
  *                           62) through the generic bodies instead of the
  *                           LDS-resident-patch kernels of c3x3.hpp (1);
- *   "x1x1"                  the "expand" 1x1 forward GEMMs (cout >= 4 cin) on
- *                           x1x1.hpp: 0 never, 1 reductions of 64 / 128
- *                           channels (default), 2 also 256 (measured level);
- *                           "x1x1_dgrad" 1: also the dgrads of the 4f -> f convs
- *                           (measured 3-8 % slower: 0);
+ *   "rowstream"             the row-streaming body of the 1x1 / stride-1 GEMMs
+ *                           (rowstream.hpp: rows global -> registers, the
+ *                           filter slice stationary in LDS): 0 never, 1 the
+ *                           layers it measured faster on in the step (default:
+ *                           forwards with reductions <= 256 channels, the
+ *                           256 <- 64 dgrad), 2 every legal layer (reductions
+ *                           of 64 .. 512 channels, both directions);
  *   "k1_fp32"               1: rigl_amd.workloads hands the models fp32
  *                           activations (the fp32 validation kernels of K1;
  *                           read by the host mirror, not by the library) (0).
- * rigl_conv2d_stats_parts(d) follows these selections: the c3x3 / x1x1 kernels
- * leave ONE statistics part per persistent workgroup, not one per 128 rows.
+ * rigl_conv2d_stats_parts(d) follows these selections: the c3x3 / rowstream kernels
+ * leave ONE statistics part per persistent workgroup (of a column slice), not one per 128 rows.
  * Knobs whose A/B measurements said "no" in rounds 2-4 are gone with their
  * kernels (k1_nt_mb, pp_ph, bwd1x1_wgs, bwd1x1_256x64, stem_nt, RIGL_WGRAD_DEFER,
  * RIGL_WGRAD_STREAM, RIGL_CONV_STAGES, RIGL_CONV_W4_KT, RIGL_WGRAD_TR; round 4
- * also measured and did not keep bn_parts / bn_rpl and a side-stream reduce).
+ * also measured and did not keep bn_parts / bn_rpl and a side-stream reduce;
+ * round 5 replaced x1x1.hpp and its knobs by rowstream.hpp).
  * No reference counterpart (the reference selects cuDNN/TPU algorithms inside
  * TensorFlow: rigl/imagenet_resnet/pruning_layers.py:139-157).              */
 int rigl_tune_set(const char* key, int32_t value);

@@ -1314,7 +1314,6 @@ static inline int kpad(const RiglConvDesc* d) { return (d->kh * d->kw * d->cin +
 #include "bwd1x1.hpp"
 #include "stem.hpp"
 #include "c3x3.hpp"
-#include "x1x1.hpp"
 #include "rowstream.hpp"
 
 // Scratch of the K-split ping-pong forward (convpp.hpp: pp_ksplit_ok): two fp32 partial tiles + a counter per tile.
@@ -1433,7 +1432,6 @@ int32_t rigl_conv2d_stats_parts(const RiglConvDesc* d) {
   using namespace rigl::k1;
   if (c3x3_use(d)) return c3x3_stats_parts(d);     // c3x3.hpp: one partial per (persistent) workgroup
   { RsPlan rp; if (rs_use<0>(d, &rp)) return rp.gprime; }   // rowstream.hpp: one partial per workgroup of a column slice
-  if (x1x1_use<0>(d)) return x1x1_grid(d);         // x1x1.hpp: likewise
   return (int32_t)((M + 127) / 128);     // one partial per 128-row output tile
 }
 
@@ -1503,11 +1501,6 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, cons
         return RIGL_OK;
       }
     }
-    if (x1x1_use<0>(d)) {                      // 1x1 "expand" (64 -> 256, 128 -> 512, 256 -> 1024): rows in registers, filter chunks through LDS
-      launch_x1x1<0>(d, x, w_ohwi, nullptr, y, stats, st);
-      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
-      return RIGL_OK;
-    }
     if (c3x3_use(d)) {                         // 3x3, 64 -> 64: input patch resident in LDS, filter in registers (c3x3.hpp)
       launch_c3x3<false>(d, x, w_ohwi, nullptr, y, stats, st);
       RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd");
@@ -1558,7 +1551,6 @@ int32_t rigl_conv2d_dgrad_stats_parts(const RiglConvDesc* d) {
   if (bwd1x1_kind(d)) return 0;               // the single-pass 1x1 backward has no reduction epilogue
   if (c3x3_use(d)) return 0;                  // nor has the slab-resident 3x3 dgrad
   if (rs_use<1>(d)) return 0;                 // nor the row-streaming dgrad
-  if (x1x1_use<1>(d)) return 0;               // nor the expand-GEMM dgrad of the 4f -> f convs
   IgemmArgs a = dgrad_args(d, nullptr, nullptr, nullptr, nullptr);
   if (plan_pp<1>(a).variant) return 0;        // the ping-pong dgrad has no reduction epilogue
   const IgemmPlan pl = plan_igemm<1>(a);
@@ -1633,11 +1625,6 @@ static int dgrad_impl(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf1
   }
   if (!bn && c3x3_use(d)) {
     launch_c3x3<true>(d, dy, w_hwio, addend, dx, nullptr, st);
-    RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
-    return RIGL_OK;
-  }
-  if (!bn && x1x1_use<1>(d)) {                  // dX[M][cin] = dY[M][cout] x W[cin][cout]^T with cin >= 4 cout (x1x1.hpp)
-    launch_x1x1<1>(d, dy, w_hwio, addend, dx, nullptr, st);
     RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
     return RIGL_OK;
   }
@@ -1841,17 +1828,6 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
     ReduceArgs ra = {slabs, dw, (int64_t)9 * 64 * 64, (int64_t)9 * 64 * 64, c3x3_wgrad_geom(d).grid};
     launch_wgrad_reduce(ra, st);
     launch_c3x3<true>(d, dy, w_hwio, addend, dx, nullptr, st);
-    RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");
-    return RIGL_OK;
-  }
-  // 1x1 convs whose dgrad is an "expand" GEMM (256 <- 64, 512 <- 128, 1024 <- 256: x1x1.hpp): the weight gradient on the tr body
-  // with its stand-alone plan, then the dgrad -- two launches (+ reduce) instead of the shared one
-  if (whole && !bn && x1x1_use<1>(d)) {
-    ProfFamily prof(PROF_CONV_BWD);
-    rc = rigl_masked_conv2d_wgrad(d, x, dy, dw, workspace, workspace_bytes, stream);
-    if (rc) return rc;
-    prof_current_kind() = PROF_CONV_BWD;
-    launch_x1x1<1>(d, dy, w_hwio, addend, dx, nullptr, st);
     RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");
     return RIGL_OK;
   }

@@ -315,10 +315,22 @@ static bool rs_ready_i() {
     default: break;                                                                                      \
   }
 // "rowstream": 0 = off, 1 = on for the layers of rs_default (measured faster than the bodies they replace), 2 = every legal layer
+// The layers the body takes by default: where the ResNet-50 step at batch 128 got faster (tools/instep_table.py, gpurun r5c; us
+// per layer in the step, the body it replaces -> this one; alone from HBM in brackets, tools/rs_bench.py, gpurun r5a):
+//   forward + statistics, reductions of up to 256 channels:
+//     28x28 128->512 37.5 -> 31.3 (40.6 -> 37.4)   14x14 256->1024 30.1 -> 25.1 (33.7 -> 27.8)   56x56 256->64 53.8 -> 47.3
+//     56x56 256->128 78.8 -> 71.0   56x56 64->64 23.8 -> 19.1   56x56 64->256 54.4 -> 53.0 (the layers of the former x1x1.hpp)
+//     512-channel reductions stay on the ping-pong body (28x28 512->128 29.4 -> 32.6, 512->256 45.2 -> 55.1, 7x7 512->2048
+//     21.7 -> 33.9: 32 column slices re-read the rows 32 times)
+//   dgrad + addend: faster ALONE on every expand shape (14x14 1024<-256 42.7 -> 33.1, 28x28 512<-128 60.3 -> 44.5, 56x56
+//     256<-128 120 -> 103) but the one-call backward then loses the overlap of the shared launch with the weight gradient
+//     (in the step 14x14 1024->256 70.3 -> 72.8, 28x28 128->512 61.0 -> 72.0, 7x7 2048->512 63.8 -> 72.6); only the
+//     256 <- 64 dgrad of the 56x56 layers keeps it (backward 139.8 -> 133.0)
 template <int MODE>
 static bool rs_default(const RiglConvDesc* d, const RsPlan& p) {
   const int k = MODE == 0 ? d->cin : d->cout, n = MODE == 0 ? d->cout : d->cin;
-  return n >= 4 * k;                                   // the "expand" GEMMs
+  if (MODE == 0) return k <= 256;
+  return k == 64 && n == 256;
 }
 template <int MODE>
 static bool rs_use(const RiglConvDesc* d, RsPlan* out = nullptr) {

@@ -169,3 +169,68 @@ def get_mask_init_fn(all_masks, method, default_sparsity, custom_sparsity_map,
 
   init_fn.sparsities = sparsities
   return init_fn
+
+
+class StatLayer:
+  """What `get_stats` needs of a layer -- the fields it reads off a tf.keras layer (sparse_utils.py:367-447): the
+  kernel's name and shape, the layer type, the input's spatial size and the strides."""
+
+  class _Kernel:
+
+    def __init__(self, name, shape):
+      self.name = name
+      self.shape = tuple(int(s) for s in shape)
+
+  def __init__(self, kind, name, kernel_shape, input_size=None, strides=(1, 1)):
+    if kind not in ('conv2d', 'depthwise', 'dense'):
+      raise ValueError('kind must be conv2d, depthwise or dense')
+    self.kind = kind
+    self.kernel = StatLayer._Kernel(name, kernel_shape)
+    self.input_shape = (None, input_size, input_size, None)
+    self.strides = tuple(strides)
+
+
+def get_stats(masked_layers, default_sparsity=0.8, method='erdos_renyi', custom_sparsities=None, is_debug=False,
+              width=1., first_layer_name='conv1', last_layer_name='conv_preds', param_size=32,
+              erk_power_scale=DEFAULT_ERK_SCALE):
+  """Size and effective FLOPs of a sparse model (sparse_utils.py:376-454): the per-layer sparsities of `method` at
+  `default_sparsity`, then for every layer the MicroNet-challenge count of a sparse dot product (rigl_amd/counting.py).
+
+  ``masked_layers``: `StatLayer`s (or anything with .kernel.name / .kernel.shape / .kind / .input_shape / .strides).
+  Returns (total_flops = multiplications + additions of one inference, total_param_bits, real_sparsity) like the reference.
+  These are EFFECTIVE flops (zeros skipped) -- the reference's 0.42x at ERK 0.8; the MFMA kernels of this package execute
+  the dense-equivalent count, and bench.py reports the two side by side, never mixed."""
+  from rigl_amd import counting  # pylint: disable=import-outside-toplevel
+  if custom_sparsities is None:
+    custom_sparsities = {}
+  sparsities = get_sparsities([l.kernel for l in masked_layers], method, default_sparsity, custom_sparsities,
+                              lambda a: a, erk_power_scale=erk_power_scale)
+  total_flops = 0
+  total_param_bits = 0
+  total_params = 0.
+  n_zeros = 0.
+  for layer in masked_layers:
+    kernel = layer.kernel
+    k_shape = list(kernel.shape)
+    d_in, d_out = (0, 1) if len(k_shape) == 2 else (2, 3)
+    if not kernel.name.startswith(first_layer_name) and k_shape[d_in] != 1:
+      k_shape[d_in] = int(k_shape[d_in] * width)
+    if not kernel.name.startswith(last_layer_name) and k_shape[d_out] != 1:
+      k_shape[d_out] = int(k_shape[d_out] * width)
+    if is_debug:
+      print(kernel.name, layer.input_shape, k_shape, sparsities[kernel.name])
+    if layer.kind == 'conv2d':
+      layer_op = counting.Conv2D(layer.input_shape[1], k_shape, layer.strides, 'same', True, 'relu')
+    elif layer.kind == 'depthwise':
+      layer_op = counting.DepthWiseConv2D(layer.input_shape[1], k_shape, layer.strides, 'same', True, 'relu')
+    elif layer.kind == 'dense':
+      layer_op = counting.FullyConnected(k_shape, True, 'relu')
+    else:
+      raise ValueError('Should not happen.')
+    param_count, n_mults, n_adds = counting.count_ops(layer_op, sparsities[kernel.name], param_size)
+    total_param_bits += param_count
+    total_flops += n_mults + n_adds
+    n_param = np.prod(k_shape)
+    total_params += n_param
+    n_zeros += int(n_param * sparsities[kernel.name])
+  return total_flops, total_param_bits, n_zeros / total_params

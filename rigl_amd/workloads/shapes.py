@@ -158,3 +158,33 @@ def resnet50_layerwise_bound(batch, mfma_flops=2.5e15, hbm_bytes=8.0e12, num_cla
       t_mfma += tc
       t_hbm += tm
   return bound, t_mfma, t_hbm
+
+
+def resnet50_stat_layers(num_classes=1000, width=1.0):
+  """`sparse_utils.StatLayer`s of ResNet-50 in creation order (every conv + the classifier), for `sparse_utils.get_stats`."""
+  from rigl_amd.sparse_utils import StatLayer  # pylint: disable=import-outside-toplevel
+  out = [StatLayer('conv2d', 'initial_conv', (7, 7, 3, int(64 * width)), 224, (2, 2))]
+  hw = 56
+  for _, _, convs in resnet50_blocks(width):
+    stride = [c.stride for c in convs if c.role == 'c2'][0]
+    o = hw // stride
+    for c in convs:
+      res = o if c.role == 'c3' else hw
+      out.append(StatLayer('conv2d', c.end_point, (c.k, c.k, c.cin, c.cout), res, (c.stride, c.stride)))
+    hw = o
+  out.append(StatLayer('dense', 'final_dense', (int(2048 * width), num_classes)))
+  return out
+
+
+def mobilenet_v1_stat_layers(num_classes=1000):
+  """StatLayers of MobileNet-v1: stem, 13 x (depthwise 3x3, pointwise 1x1), classifier."""
+  from rigl_amd.sparse_utils import StatLayer  # pylint: disable=import-outside-toplevel
+  out = [StatLayer('conv2d', 'initial_conv', (3, 3, 3, 32), 224, (2, 2))]
+  hw, in_ch = 112, 32
+  for i, (f, s) in enumerate(MOBILENET_V1_BLOCKS):
+    out.append(StatLayer('depthwise', 'depthwise_nxn_%d' % i, (3, 3, in_ch, 1), hw, (s, s)))
+    hw //= s
+    out.append(StatLayer('conv2d', 'contraction_1x1_%d' % i, (1, 1, in_ch, f), hw, (1, 1)))
+    in_ch = f
+  out.append(StatLayer('dense', 'final_dense', (1024, num_classes)))
+  return out

@@ -7,6 +7,7 @@ which the library reads once per process, can be chosen per invocation:
 
   python tests/k1_check.py --set small         # small 1x1 / 3x3 shapes (both column widths, ragged N, halo rows)
   python tests/k1_check.py --set pp            # edge cases of the 8-wave ping-pong body (1..9 K-tiles, row tails, stride 2)
+  python tests/k1_check.py --set rs            # the row-streaming 1x1 body (run with RIGL_ROWSTREAM=2: every legal shape takes it)
   python tests/k1_check.py --set c3            # the slab-resident 3x3 kernels (64 -> 64 channels): tile heights, widths, partial tiles
   python tests/k1_check.py --set resnet50 --batch 128     # the 23 distinct ResNet-50 layer shapes at the benchmarked batch
 
@@ -81,21 +82,6 @@ C3_CASES = [
     (5, 30, 28, 64, 64, 3, 1, 1, 1, 30, 28),      # two tiles of 15 rows
     (1, 64, 62, 64, 64, 3, 1, 1, 1, 64, 62),      # the widest legal plane (64-pixel patch rows), one image
     (9, 24, 24, 64, 64, 3, 1, 1, 1, 24, 24),      # the narrowest, odd batch
-]
-
-
-# The "expand" 1x1 GEMM kernel (x1x1.hpp): reductions of 64 / 128 / 256 channels, forward (cout >= 4 cin) and dgrad
-# (cin >= 4 cout); one and several 128-row tiles per persistent workgroup, ragged last tiles
-X1_CASES = [
-    (16, 56, 56, 64, 256, 1, 1, 0, 0, 56, 56),     # K = 64: the whole filter resident, 392 tiles on 256 workgroups
-    (130, 23, 19, 64, 256, 1, 1, 0, 0, 23, 19),    # ... 56 810 rows: ragged last tile, two tiles on most workgroups
-    (64, 28, 28, 128, 512, 1, 1, 0, 0, 28, 28),    # K = 128: four chunks of 128 columns per tile
-    (50, 13, 17, 128, 512, 1, 1, 0, 0, 13, 17),    # ... 11 050 rows: fewer tiles than CUs, ragged
-    (200, 14, 14, 256, 1024, 1, 1, 0, 0, 14, 14),  # K = 256: sixteen chunks of 64 columns, 307 tiles
-    (16, 56, 56, 256, 64, 1, 1, 0, 0, 56, 56),     # dgrad is the expand GEMM (256 <- 64)
-    (64, 28, 28, 512, 128, 1, 1, 0, 0, 28, 28),    # ... 512 <- 128
-    (200, 14, 14, 1024, 256, 1, 1, 0, 0, 14, 14),  # ... 1024 <- 256
-    (60, 14, 14, 256, 2048, 1, 1, 0, 0, 14, 14),   # wider than the kernel's LDS statistics array allows: the generic body
 ]
 
 
@@ -286,11 +272,11 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
 
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument('--set', default='small', choices=['small', 'pp', 'stem', 'c3', 'x1', 'rs', 'resnet50'])
+  ap.add_argument('--set', default='small', choices=['small', 'pp', 'stem', 'c3', 'rs', 'resnet50'])
   ap.add_argument('--batch', type=int, default=128)
   ap.add_argument('--only', type=int, default=-1)
   a = ap.parse_args()
-  cases = {'small': SMALL_CASES, 'pp': PP_CASES, 'stem': STEM_CASES, 'c3': C3_CASES, 'x1': X1_CASES, 'rs': RS_CASES}.get(a.set) or resnet50_shapes(a.batch)
+  cases = {'small': SMALL_CASES, 'pp': PP_CASES, 'stem': STEM_CASES, 'c3': C3_CASES, 'rs': RS_CASES}.get(a.set) or resnet50_shapes(a.batch)
   worst, n = 0.0, 0
   for i, c in enumerate(cases):
     if a.only >= 0 and i != a.only:

@@ -55,7 +55,7 @@ def test_pingpong_edge_shapes(env):
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
 @pytest.mark.parametrize('env', PP_SETTINGS[:3] + PP_SETTINGS[4:5] + [
-    {'RIGL_BWD1X1': '0', 'RIGL_STEM_DIRECT': '0', 'RIGL_WGRAD_IL': '0', 'RIGL_C3X3': '0', 'RIGL_X1X1': '0'},   # the generic bodies on the layers with kernels of their own
+    {'RIGL_BWD1X1': '0', 'RIGL_STEM_DIRECT': '0', 'RIGL_WGRAD_IL': '0', 'RIGL_C3X3': '0', 'RIGL_ROWSTREAM': '0'},   # the generic bodies on the layers with kernels of their own
 ])
 def test_resnet50_layer_shapes_at_batch_128(env):
   """All distinct ResNet-50 conv shapes at the benchmarked per-GPU batch: fwd, fwd + statistics,
@@ -86,11 +86,11 @@ def test_slab_resident_3x3_shapes(env):
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
-@pytest.mark.parametrize('env', [{'RIGL_X1X1': '2', 'RIGL_X1X1_DGRAD': '1'}, {}])
-def test_expand_1x1_shapes(env):
-  """The "expand" 1x1 GEMM kernel (x1x1.hpp: activation rows in registers, filter chunks through LDS, persistent
-  workgroups; forward with statistics, dgrad with addend) for reductions of 64 / 128 / 256 channels, one and several
-  tiles per workgroup, ragged last tiles -- every variant forced on (the default takes the forwards with reductions of 64
-  and 128 channels); then the default selection on the same shapes."""
-  out = _run(['--set', 'x1'], env)
-  assert out['cases'] == 9
+@pytest.mark.parametrize('env', [{'RIGL_ROWSTREAM': '2'}, {}, {'RIGL_ROWSTREAM': '0'}])
+def test_row_streaming_1x1_shapes(env):
+  """The row-streaming 1x1 body (rowstream.hpp: activation / gradient rows global -> registers, the filter slice stationary
+  in LDS, barrier-free waves; forward with statistics, dgrad with and without addend) in every (reduction, slice width)
+  instantiation, 1 .. 32 column slices, fragments of fewer than 32 rows, ragged last fragments -- forced onto every legal
+  shape, then under the default selection, then with the body off (pins the cases themselves)."""
+  out = _run(['--set', 'rs'], env)
+  assert out['cases'] == 13
