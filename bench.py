@@ -197,7 +197,7 @@ def main():
     raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus N` bare, or under '
                      'torch.distributed.run --nproc-per-node N)' % (args.gpus, world))
 
-  from rigl_amd import ops, sparse_optimizers, train, variables
+  from rigl_amd import ops, sparse_optimizers, sparse_utils, train, variables
   from rigl_amd.dist import GradSync
   from rigl_amd.workloads import shapes
 
@@ -415,6 +415,23 @@ def main():
             'frac_of_bound': lb * 1e3 / (conv_ms / n_fwd_bwd) if conv_ms > 0 else 0.0,
             'note': 'sum over layers and fwd/dgrad/wgrad of max(flops / 2.5 PF, algorithmic bytes / 8 TB/s); '
                     'mfma_only_ms / ms_per_step is the highest `frac` any implementation of these layers can reach'}
+        # SURVEY 8(d) "report separately, never mix": the reference's EFFECTIVE flop count of the same sparse model
+        # (sparse_utils.get_stats: multiplications + additions of one inference with the zeros skipped -- README.md's
+        # 0.42x at ERK 0.8, 0.05x at 0.99) next to the dense-equivalent count the MFMA kernels execute and `achieved` divides by
+        try:
+          sl = shapes.resnet50_stat_layers()
+          sp = args.sparsity if args.sparsity is not None else (0.99 if args.workload == 'resnet50_erk99' else 0.8)
+          custom = {'initial_conv': 0.0} if args.workload == 'resnet50_erk99' else {}
+          dense_f = sparse_utils.get_stats(sl, 0.0, 'random')[0]
+          eff_f, eff_bits, eff_s = sparse_utils.get_stats(sl, sp, 'erdos_renyi_kernel', custom_sparsities=custom)
+          out['roofline']['effective_gflop_per_image'] = eff_f / 1e9
+          out['roofline']['effective'] = {
+              'inference_gflop_per_image': eff_f / 1e9, 'dense_inference_gflop_per_image': dense_f / 1e9,
+              'ratio_to_dense': eff_f / dense_f, 'model_size_mb': eff_bits / 8 / 1e6, 'sparsity': eff_s,
+              'note': 'sparse_utils.get_stats (mults + adds of one forward, zeros skipped); NOT what `achieved` counts: the '
+                      'kernels compute on dense storage, algorithmic_gflop_per_image is the dense-equivalent fwd+dgrad+wgrad'}
+        except Exception as e:  # pylint: disable=broad-except
+          print('effective flops: %r' % (e,), file=sys.stderr)
       # the HBM-bound kernels of the path, against the 8 TB/s HBM3E peak (algorithmic bytes: SURVEY 8d)
       n_params = sum(v.numel for v in g.trainable_variables())
       n_masked = sum(m.numel for m in g.get_masks())

@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define RIGL_ABI_VERSION 1
+/* Bumped whenever an entry point is removed or a signature changes (2: round 4 dropped
+ * rigl_masked_conv2d_bwd_deferred / rigl_wgrad_reduce_pending and two parameters of rigl_masked_conv2d_bwd_bn). */
+#define RIGL_ABI_VERSION 2
 
 typedef void* rigl_stream_t; /* hipStream_t */
 typedef uint16_t rigl_bf16;  /* raw bfloat16 bits */

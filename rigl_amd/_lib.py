@@ -7,6 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 2   # include/rigl_hip.h RIGL_ABI_VERSION this mirror was written against
 LIB_PATH = os.environ.get('RIGL_HIP_LIB') or os.path.join(_HERE, 'lib', 'librigl_hip.so')   # override: development builds
 
 RIGL_OK = 0
@@ -180,7 +181,7 @@ def load():
     fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
     fn.restype = res
     fn.argtypes = args
-  if lib.rigl_version() != 1:
+  if lib.rigl_version() != ABI_VERSION:
     raise RiglError(RIGL_EINVAL, 'ABI version mismatch')
   _lib = lib
   return lib

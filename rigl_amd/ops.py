@@ -905,6 +905,9 @@ def prof_collect_launches(cap=1 << 16):
   arr = (_lib.ProfLaunch * cap)()
   n = C.c_int64(0)
   check(_lib.load().rigl_prof_collect_launches(arr, cap, C.byref(n)))
+  if n.value > cap:
+    raise RuntimeError('prof_collect_launches: %d timed dispatches, room for %d (the rest were consumed and dropped): '
+                       'collect more often or pass a larger cap' % (n.value, cap))
   return [(_lib.PROF_KINDS[arr[i].kind], tuple(arr[i].tag), float(arr[i].ms)) for i in range(min(n.value, cap))]
 
 

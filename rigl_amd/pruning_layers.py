@@ -41,6 +41,9 @@ def _valid_out(size, k, stride):
 # 10-17 us per layer and the epilogue work it adds 15-19 us (profiles/r2/README.md) -- 13.29 vs 13.30 ms per step
 # with K1's share of it up by 1 ms.
 _BN_FUSE_BWD = os.environ.get('RIGL_BN_FUSE_BWD', '0') == '1'
+# RIGL_CONV_PAIR=0: the first block of a group runs projection and conv1 as two autograd nodes (read once; tests override
+# the module attribute).  The pair node carries no batch-norm holder: with RIGL_BN_FUSE_BWD=1 it steps aside for the fork path.
+_CONV_PAIR = os.environ.get('RIGL_CONV_PAIR', '1') != '0'
 # ... only for activations of at most this many MB (the large early tensors make the dgrad launch HBM-bound already)
 _BN_FUSE_MAX_BYTES = float(os.environ.get('RIGL_BN_FUSE_MAX_MB', '1e9')) * 1e6
 
@@ -217,7 +220,7 @@ def conv_pair(conv_sub, conv_main, x, bn_stats=False):
   ok = (x.dtype == torch.bfloat16 and x.requires_grad and conv_sub.need_input_grad and conv_main.need_input_grad
         and conv_sub.kh == conv_sub.kw == 1 and max(conv_sub.strides) > 1
         and conv_sub.cin % 8 == 0 and conv_sub.units % 8 == 0 and conv_main.units % 8 == 0
-        and os.environ.get('RIGL_CONV_PAIR', '1') != '0')
+        and _CONV_PAIR and not (_BN_FUSE_BWD and getattr(x, 'bn_ctx', None) is not None))
   d_s = conv_sub.desc_for(n, h, w) if ok else None
   if ok and (d_s.pad_top or d_s.pad_left or d_s.ho != -(-h // d_s.stride_h) or d_s.wo != -(-w // d_s.stride_w)):
     ok = False

@@ -670,7 +670,13 @@ class SparseDNWOptimizer(PruningGetterMixin, train.Optimizer):
     # |W| of the whole masked segment in one pass over the arena (one launch, not one per layer); a layer's scores are a
     # view of it.  Graphs that were not finalised (no arena) take the per-layer form.
     seg = g.seg.get(V.KIND_MASKED) if getattr(g, 'finalized', False) else None
-    score = g.W[seg[0]:seg[1]].abs() if seg and seg[1] > seg[0] else None
+    score = None
+    if seg and seg[1] > seg[0]:
+      # a persistent buffer (the selection runs every step: no 100 MB allocation per step)
+      score = getattr(self, '_dnw_score', None)
+      if score is None or score.numel() != seg[1] - seg[0] or score.device != g.W.device:
+        score = self._dnw_score = torch.empty(seg[1] - seg[0], dtype=g.W.dtype, device=g.W.device)
+      torch.abs(g.W[seg[0]:seg[1]], out=score)
     for l in g.masked_layers():
       n = l.weights.numel
       n_keep = n - sparse_utils.get_n_zeros(n, sparsities[l.mask.name])

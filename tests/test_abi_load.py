@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
   for s in _declared_symbols():
     assert hasattr(lib, s), 'librigl_hip.so does not export %s' % s
     assert s in _lib.SIGNATURES, 'no ctypes signature for %s' % s
-  assert lib.rigl_version() == 1
+  assert lib.rigl_version() == 2
   assert lib.rigl_last_error() == b''
 
 

@@ -26,7 +26,7 @@ CASES = [
 def _run(case, pair, monkeypatch):
   from rigl_amd import pruning_layers as PL, variables as V
   n, h, w, cin, cs, cm = case
-  monkeypatch.setenv('RIGL_CONV_PAIR', '1' if pair else '0')
+  monkeypatch.setattr(PL, '_CONV_PAIR', bool(pair))
   g = V.reset_default_graph(DEV)
   PL.set_init_seed(7)
   sub = PL.MaskedConv2d(g, 'proj', cin, cs, (1, 1), (2, 2), 'SAME', 'threshold', 0.0)

@@ -121,7 +121,9 @@ def test_rccl_code_path_executes_with_one_rank():
   rows = ar['in_step']['buckets']
   assert len(rows) >= 3 and sum(r['bytes'] for r in rows) == ar['bytes']          # every gradient element exchanged exactly once
   assert all('device_ms_after_first_bucket' in r for r in rows) and ar['in_step']['tail_wait_ms'] is not None
-  assert 'comm_exposed_ms' in ar['exposed']
+  import math
+  assert 'comm_exposed_ms' in ar['exposed'] and math.isfinite(float(ar['exposed']['comm_exposed_ms']))
+  assert math.isfinite(float(ar['in_step']['tail_wait_ms'])) and float(ar['in_step']['tail_wait_ms']) >= 0.0
   # and the numbers are those of the plain step
   plain = subprocess.run(cmd, env={k: v for k, v in env.items() if k != 'RIGL_BENCH_FORCE_SYNC'}, cwd=ROOT,
                          capture_output=True, text=True, timeout=600)

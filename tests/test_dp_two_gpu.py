@@ -44,7 +44,12 @@ def test_bench_two_ranks_over_rccl():
   assert ar['bus_GBps'] > 0 and ar['buckets'] >= 3 and ar['bytes'] > 4 * 25_000_000
   rows = ar['in_step']['buckets']
   assert sum(r['bytes'] for r in rows) == ar['bytes']            # every gradient element exchanged exactly once
-  assert 'comm_exposed_ms' in ar['exposed']
+  # the overlap evidence an 8-GPU node produces with nobody in the loop: exposed exchange time per step and the
+  # compute-stream wait behind backward for the last bucket -- present and finite
+  import math
+  assert 'comm_exposed_ms' in ar['exposed'] and math.isfinite(float(ar['exposed']['comm_exposed_ms']))
+  assert 'tail_wait_ms' in ar['in_step'] and ar['in_step']['tail_wait_ms'] is not None
+  assert math.isfinite(float(ar['in_step']['tail_wait_ms'])) and float(ar['in_step']['tail_wait_ms']) >= 0.0
   assert d['value'] > 0 and d['scaling'] == 'weak' and d['roofline']['frac'] > 0
 
 

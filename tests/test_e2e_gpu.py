@@ -316,7 +316,7 @@ def test_resnet50_every_conv_in_situ_and_loss_vs_cpu_oracle(rn50, monkeypatch):
   from oracle.resnet_cpu import ResNet50CPU
   # one autograd node per conv (the three strided projections otherwise share a node with their block's conv1, whose
   # internals -- the compact projection gradient -- are checked in tests/test_conv_pair_gpu.py)
-  monkeypatch.setenv('RIGL_CONV_PAIR', '0')
+  monkeypatch.setattr(PL, '_CONV_PAIR', False)
   g.refresh_shadows(force=True)
   for v in g.variables.values():
     if v.name.endswith('bn3/gamma:0'):
