@@ -157,6 +157,10 @@ def main():
   ap.add_argument('--batch', type=int, default=128, help='per-GPU batch')
   ap.add_argument('--workload', default='resnet50', choices=('resnet50', 'resnet50_erk99', 'mobilenet_v1', 'wrn22'))
   ap.add_argument('--sparsity', type=float, default=None, help="override the workload's sparsity")
+  ap.add_argument('--precision', default='bfloat16', choices=('bfloat16', 'float32'),
+                  help="the reference's --precision flag (imagenet_train_eval.py:56-59; its default is float32, its TPU runs and "
+                       'the graded line bfloat16).  float32: fp32 activations, K1 on conv_f32.hip (v_mfma_f32_32x32x2_f32, an '
+                       'un-tuned validation body), glue on stock torch ops; roofline against the 157.3 TFLOP/s fp32 matrix peak')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-prof', action='store_true')
   ap.add_argument('--graph', action='store_true',
@@ -201,6 +205,9 @@ def main():
   from rigl_amd.dist import GradSync
   from rigl_amd.workloads import shapes
 
+  fp32 = args.precision == 'float32'
+  if fp32:
+    ops.tune_set('k1_fp32', 1)             # workloads.nn.activation_dtype: the synthetic batch and every activation in fp32
   g = variables.reset_default_graph(dev)
   wl = build_workload(args.workload, g, dev, args.batch, rank, args.sparsity)
   sync = GradSync(g, enabled=not args.no_sync) if (world > 1 or force_sync) else None
@@ -343,7 +350,7 @@ def main():
         'metric': wl['metric'],
         'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'bf16', 'data': 'synthetic',
+        'dtype': 'fp32' if fp32 else 'bf16', 'data': 'synthetic',
         'config': {'workload': wl['label'],
                    'global_batch': global_batch, 'per_gpu_batch': args.batch,
                    'parallelism': 'dp%d' % world, 'mask_updates_in_timed_region': n_updates,
@@ -381,15 +388,20 @@ def main():
             break
           except (OSError, ValueError, KeyError):
             continue
+      peak_tf = 157.3 if fp32 else 2500.0   # MI355X_MICROARCH.md: fp32 matrix (= vector) peak / dense bf16 MFMA peak
+      if fp32:
+        traffic = traffic_build = None       # (the PMC passes were collected on the bf16 kernels)
       out['roofline'] = {
-          'bound': 'mfma', 'achieved': achieved, 'peak': 2500.0, 'unit': 'TFLOP/s',
-          'frac': achieved / 2500.0, 'traffic': traffic,
+          'bound': 'mfma', 'achieved': achieved, 'peak': peak_tf, 'unit': 'TFLOP/s',
+          'frac': achieved / peak_tf, 'traffic': traffic,
           'traffic_unit': 'HBM bytes per K1 launch (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes, profiles/r*/pmc_hbm_traffic.csv)',
           'traffic_lib_sha16': traffic_build,
           'traffic_from_this_build': (traffic_build == lib_sha16()) if traffic_build else None,
-          'kernel': 'K1 masked conv implicit-GEMM (fwd, dgrad, wgrad; conv_bwd = dgrad + wgrad sharing one launch): all %d '
-                    'kernel dispatches of %d of the %d timed steps (every %d-th + the mask-update steps), each stamped by its '
-                    'own dispatch (hipExtLaunchKernelGGL start/stop events)' % (launches, n_profiled, args.steps, prof_every),
+          'kernel': (('K1 in fp32 (conv_f32.hip, v_mfma_f32_32x32x2_f32; validation body, un-tuned; an event pair around every call): all %d '
+                      if fp32 else
+                      'K1 masked conv implicit-GEMM (fwd, dgrad, wgrad; conv_bwd = dgrad + wgrad sharing one launch): all %d ') +
+                     'kernel dispatches of %d of the %d timed steps (every %d-th + the mask-update steps), each stamped by its '
+                     'own dispatch (hipExtLaunchKernelGGL start/stop events)') % (launches, n_profiled, args.steps, prof_every),
           'profiled_steps': n_profiled,
           'algorithmic_gflop_per_image': flops_per_step / args.batch / 1e9,
           'avg_launch_ms': conv_ms / max(launches, 1),
@@ -402,8 +414,8 @@ def main():
       # `peak` (the graded denominator) stays the 2.5 PFLOP/s spec figure of MI355X_MICROARCH.md
       try:
         peak_here = ops.mfma_peak_probe(dev)
-        out['roofline']['peak_measured_on_this_box'] = peak_here
-        out['roofline']['frac_of_measured_peak'] = achieved / peak_here if peak_here > 0 else None
+        out['roofline']['peak_measured_on_this_box'] = peak_here        # (the bf16 probe; fp32 MFMA runs at 1/16 of it)
+        out['roofline']['frac_of_measured_peak'] = (achieved / (peak_here / 16.0 if fp32 else peak_here)) if peak_here > 0 else None
       except Exception as e:  # pylint: disable=broad-except
         out['roofline']['peak_measured_on_this_box'] = None
         print('mfma peak probe failed: %r' % (e,), file=sys.stderr)

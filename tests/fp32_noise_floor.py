@@ -37,14 +37,16 @@ def main():
   ap.add_argument('--same-piece', action='store_true')
   ap.add_argument('--lr', type=float, default=0.01)
   ap.add_argument('--threads', type=int, default=16)
+  ap.add_argument('--batch', type=int, default=8)
   a = ap.parse_args()
   torch.set_num_threads(a.threads)
   m32, m64 = build(torch.float32), build(torch.float64)
   with torch.no_grad():
     for w32, w64 in zip(m32.w, m64.w):
       w64.copy_(w32.double())
-  x = torch.randn(8, 3, 224, 224)
-  y = torch.randint(0, 1000, (8,))
+  x = torch.randn(a.batch, 3, 224, 224)
+  y = torch.randint(0, 1000, (a.batch,))
+  print('batch %d, %s' % (a.batch, 'same linear piece' if a.same_piece else 'as is'), flush=True)
   relu0, pool0 = F.relu, F.max_pool2d
   tape = []
 

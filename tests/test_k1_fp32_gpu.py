@@ -42,6 +42,18 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 TOL_LOSS = 1e-5
 TOL_DW_WRN22 = 1e-5      # measured 1.0e-6 .. 1.1e-6 (worst layer, three steps)
+# ResNet-50 at batch 32 / 64 (tools/fp32_batch_probe.py + tests/fp32_noise_floor.py --same-piece --batch B,
+# gpurun r5f, worst layer over the three steps):   this path vs float64      stock torch float32 vs float64
+#                                        batch  8    2.5e-5 .. 3.8e-5          2.5e-5 .. 4.9e-5
+#                                        batch 32    2.2e-5 .. 2.8e-5          2.4e-5 .. 2.7e-5
+#                                        batch 64    2.6e-5 .. 2.7e-5          2.4e-5 .. 2.6e-5
+# The worst layer (always bottleneck_3_block_group4_2_1, the last 512 -> 2048 conv on 7 x 7 maps) does NOT fall with the
+# batch: it is float32 accumulation itself (stock torch float32 sits on the same 2.5e-5), so there is no batch at which
+# every layer's dW is within 1e-5 of float64 in float32 arithmetic on this model.  What holds 1e-5: the loss (4e-8 ..
+# 9e-8) and the MEDIAN layer at steps 0 and 1 (4e-6 .. 7e-6; 1.0e-5 at step 2).  Asserted at batch 32: worst <= 4e-5,
+# median <= 1.5e-5.
+TOL_DW_RESNET50_B32 = 4e-5
+TOL_DW_MEDIAN_RESNET50_B32 = 1.5e-5
 TOL_DW_RESNET50 = 5e-5   # measured 2.5e-5 .. 3.8e-5; stock torch float32 on the same model: 2.6e-5 .. 4.3e-5 (docstring, 2.)
 
 
@@ -232,7 +244,7 @@ def _wrn_loss64(model, twin, x_nchw, labels):
   return F.cross_entropy(logits, labels)
 
 
-def _compare(step, loss, ref_loss, layers, ref_dense, report, tol_dw):
+def _compare(step, loss, ref_loss, layers, ref_dense, report, tol_dw, tol_median=None):
   rel = abs(loss - ref_loss) / abs(ref_loss)
   report.append('step %d  loss %.9f  float64 %.9f  rel %.2e' % (step, loss, ref_loss, rel))
   assert rel <= TOL_LOSS, report[-1]
@@ -246,6 +258,8 @@ def _compare(step, loss, ref_loss, layers, ref_dense, report, tol_dw):
                 % (max(errs) + (sorted(e for e, _ in errs)[len(errs) // 2],)))
   print(report[-2] + '\n' + report[-1], flush=True)
   assert max(errs)[0] <= tol_dw, (step, max(errs))
+  if tol_median is not None:
+    assert sorted(e for e, _ in errs)[len(errs) // 2] <= tol_median, (step, 'median')
 
 
 def test_wrn22_three_training_steps_in_fp32_vs_float64():
@@ -282,7 +296,7 @@ def test_wrn22_three_training_steps_in_fp32_vs_float64():
     opt.apply_gradients(gv, gs)
 
 
-def test_resnet50_three_training_steps_in_fp32_vs_float64_oracle():
+def _resnet50_three_steps(batch, tol_dw, tol_median=None):
   from oracle.resnet_cpu import ResNet50CPU
   from rigl_amd import sparse_utils, train, variables as V
   from rigl_amd.workloads import resnet50
@@ -307,7 +321,7 @@ def test_resnet50_three_training_steps_in_fp32_vs_float64_oracle():
     cpu.bn[b['c3'][1]][0].data.fill_(0.5)
   opt = train.MomentumOptimizer(lr, mu, use_nesterov=True, graph=g)
   gs = g.get_or_create_global_step()
-  x, y = resnet50.synthetic_batch(8, DEV, precision='float32')
+  x, y = resnet50.synthetic_batch(batch, DEV, precision='float32')
   x64, y64 = x.double().cpu().permute(0, 3, 1, 2).contiguous(), y.cpu()
   torch.set_num_threads(min(torch.get_num_threads(), 32))
   report = []
@@ -321,8 +335,20 @@ def test_resnet50_three_training_steps_in_fp32_vs_float64_oracle():
       ref_loss = cpu.train_step(x64, y64, lr=lr, mu=mu, wd=wd, keep_dense=True)
     assert not dec.tape
     ref_dense = {l.scope: torch.from_numpy(cpu.dense_grads[i]) for i, l in enumerate(g.layers)}
-    _compare(step, float(loss.detach()), ref_loss, g.layers, ref_dense, report, TOL_DW_RESNET50)
+    _compare(step, float(loss.detach()), ref_loss, g.layers, ref_dense, report, tol_dw, tol_median)
     opt.apply_gradients(gv, gs)
+  return report
+
+
+def test_resnet50_three_training_steps_in_fp32_vs_float64_oracle():
+  _resnet50_three_steps(8, TOL_DW_RESNET50)
+
+
+def test_resnet50_three_training_steps_in_fp32_vs_float64_oracle_batch_32():
+  """The same comparison at batch 32: four times the values per channel in every batch-norm
+  backward reduction.  The worst layer does not move (float32 accumulation, same as stock torch): the measured table
+  is in the comment above TOL_DW_RESNET50_B32."""
+  _resnet50_three_steps(32, TOL_DW_RESNET50_B32, TOL_DW_MEDIAN_RESNET50_B32)
 
 
 def test_bf16_path_is_untouched_by_the_precision_switch():
