@@ -284,7 +284,7 @@ def test_conv_fwd_256x128_tile_is_bit_identical(case):
              N, H, W, Cin, Cout, k, k, stride, pt, pl, Ho, Wo))
   outs = {}
   for big in ('0', '1', '2'):                    # never / the default rule / wherever legal
-    env = dict(os.environ, RIGL_CONV_BIG=big)
+    env = dict(os.environ, RIGL_CONV_BIG=big, RIGL_ROWSTREAM='0')   # (the 1x1 case is a rowstream.hpp shape by default: this test pins the igemm tiles)
     r = subprocess.run([sys.executable, '-c', prog], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     outs[big] = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
