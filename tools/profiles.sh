@@ -38,6 +38,14 @@ python $R/tools/k2_profile.py --summarise $(find $O/k2prof -name "*kernel_stats.
 rm -rf $O/k2prof
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mbprof -o mb -- python $R/bench.py --workload mobilenet_v1 --steps 20 --warmup 5 --no-cpu-baseline --no-prof > $O/mb_run.txt 2>&1
 cp $(find $O/mbprof -name "*kernel_stats.csv" | head -1) $O/mobilenet_kernel_stats.csv; rm -rf $O/mbprof
-cd $R; timeout 900 python -m pytest tests -q -m gpu > $O/gpu_tests_final.txt 2>&1; echo "pytest gpu rc=$?" | tee -a $O/log.txt; tail -3 $O/gpu_tests_final.txt | tee -a $O/log.txt
+# round 5: the row-streaming body alone (A/B against the bodies it replaces), the per-layer in-step table and the fp32 line
+cd $R
+timeout 400 python tools/rs_bench.py > $O/rs_bench.txt 2>&1; echo "rs_bench rc=$?" | tee -a $O/log.txt
+timeout 300 python tools/bench_kernels.py --out $O/bk_warm.json > /dev/null 2>&1
+timeout 300 python tools/bench_kernels.py --cold --out $O/bk_cold.json > /dev/null 2>&1
+timeout 300 python tools/instep_table.py --alone $O/bk_warm.json --cold $O/bk_cold.json --out $O/instep_table.json > $O/instep_table.txt 2>&1; echo "instep rc=$?" | tee -a $O/log.txt
+python tools/layer_excess.py $O/instep_table.json > $O/layer_excess.txt 2>&1
+timeout 600 python bench.py --precision float32 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_fp32.json 2>>$O/bench_err.txt; echo "fp32 rc=$?" | tee -a $O/log.txt
+cd $R; timeout 1500 python -m pytest tests -q -m gpu > $O/gpu_tests_final.txt 2>&1; echo "pytest gpu rc=$?" | tee -a $O/log.txt; tail -3 $O/gpu_tests_final.txt | tee -a $O/log.txt
 tail -3 $O/pmc_sq_k1.txt | tee -a $O/log.txt; tail -3 $O/k2_kernels.txt | tee -a $O/log.txt; tail -4 $O/bench_kernels_per_layer.txt | tee -a $O/log.txt
 ls -la $O | tee -a $O/log.txt
