@@ -23,6 +23,14 @@
 //     partial row per workgroup at the end (fixed order: deterministic).
 //   * Workgroup b -> XCD b % 8; the `slices` workgroups that stream the same rows against different filter slices sit on
 //     the same XCD, so a row fragment comes from HBM once and from that XCD's L2 for the other slices.
+// Where the time goes on a small layer (14x14 256 -> 1024 forward, 27.4 us per call; -DRIGL_RS_ABLATE builds, gpurun r5h-r5j):
+// without the output stores 22.6 us, without the ring refills 25.7, without statistics 27.9, without MFMAs 27.7, without
+// any of loads / stores / statistics 20.4, additionally without MFMAs 17.2, without the filter reads 18.8, with everything
+// off 10.1 (launch, filter load, barrier, statistics hand-off).  No single pipe paces it: ~10 us are fixed per launch, ~7 the
+// memory operations, ~3 the MFMAs.  Tried on top and measured level (removed): starting the second wave of every SIMD one
+// MFMA phase late (the waves are not in lockstep: no effect), every workgroup starting its filter load at another piece
+// (the load is latency, not L2 queueing), conflict-free staging rows and filter reads pipelined across chunk
+// boundaries (both kept: LDS conflicts 25-39 % -> see profiles/r5/pmc_sq_k1.txt, time unchanged).
 // Reference: layers.masked_conv2d with a 1x1 kernel (pruning_layers.py:139-157), the bottleneck's first / third conv and
 // the projection shortcut (resnet_model.py:396-501), and their autodiff.
 #pragma once
@@ -58,7 +66,7 @@ template <int KC, int TN>
 struct RsGeom {
   static constexpr int K = 64 * KC, NS = 32 * TN, RB = K * 2, CPR = K / 8;
   static constexpr int WBYTES = NS * RB;                         // the filter slice
-  static constexpr int SROW = NS * 2 + 16, STG_WAVE = 32 * SROW; // a wave's staging tile: 32 rows, 16 bytes of padding
+  static constexpr int SROW = NS * 2 + 8, STG_WAVE = 32 * SROW;  // a wave's staging tile: 32 rows, 8 bytes of padding (below)
   static constexpr int SMEM = WBYTES + 8 * STG_WAVE;
   static_assert(8 * STG_WAVE >= 8 * 64 * 16 * 4, "the statistics hand-off re-uses the staging tiles");
 };
@@ -158,38 +166,42 @@ __global__ __launch_bounds__(RS_THREADS) void k_rowstream(RsArgs P) {
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-#pragma unroll
-      for (int c = 0; c < KC; ++c) {
-        const int t = u * KC + c;                        // chunk of the unrolled body: its ring slot is static
-        const int slot = t & 3;
-        // 4 k-steps x TN MFMAs; the filter fragments of k-step g + 1 are requested above the MFMAs of k-step g
+      // K / 16 k-steps of TN MFMAs each.  The filter fragments of k-step s + 2 are requested right behind the MFMAs of
+      // k-step s (two register sets, also across the chunk boundaries: no exposed LDS latency inside a fragment); the ring
+      // slot of a chunk is re-loaded with chunk s + 4 of the wave's sequence behind the chunk's last MFMAs.
+      {
+        constexpr int S = KC * 4;
         bf16x8 bq[2][TN];
-#define RS_READ(g_, buf_)                                                                                \
+#define RS_READ(s_, buf_)                                                                                \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
-          bq[buf_][j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * RB + ((((c * 8 + 2 * (g_) + hi)) ^ swz) << 4));
-#define RS_MFMA(g_, buf_)                                                                                \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[buf_][j], a[slot][g_], acc[j], 0, 0, 0);
+          bq[buf_][j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * RB + ((((2 * (s_) + hi)) ^ swz) << 4));
         RS_READ(0, 0);
         RS_READ(1, 1);
         __builtin_amdgcn_sched_barrier(0);
-        RS_MFMA(0, 0);
-        RS_READ(2, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        RS_MFMA(1, 1);
-        RS_READ(3, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        RS_MFMA(2, 0);
-        RS_MFMA(3, 1);
-        __builtin_amdgcn_sched_barrier(0);
-#undef RS_READ
-#undef RS_MFMA
-        // refill the slot with chunk s + 4 of the wave's sequence
-        {
-          const int t4 = t + 4;
-          RS_LOAD_CHUNK(slot, i0 + t4 / KC, t4 % KC);
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+          const int c = st / 4, g4 = st % 4;
+          const int t = u * KC + c;                      // chunk of the unrolled body: its ring slot is static
+          const int slot = t & 3;
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#if defined(RIGL_RS_ABLATE) && (RIGL_RS_ABLATE & 8)        // timing experiment 8: no MFMAs (operands stay live through one add)
+            acc[j][0] += (float)bq[st & 1][j][0] + (float)a[slot][g4][0];
+#else
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[st & 1][j], a[slot][g4], acc[j], 0, 0, 0);
+#endif
+#if !(defined(RIGL_RS_ABLATE) && (RIGL_RS_ABLATE & 64))      // timing experiment 64: the filter fragments are read once per fragment
+          if (st + 2 < S) RS_READ(st + 2, st & 1);
+#endif
+          if (g4 == 3) {
+            const int t4 = t + 4;
+#if !(defined(RIGL_RS_ABLATE) && (RIGL_RS_ABLATE & 1))      // timing experiment 1: the ring is never refilled (wrong results)
+            RS_LOAD_CHUNK(slot, i0 + t4 / KC, t4 % KC);
+#endif
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+#undef RS_READ
       }
       RS_STAMP(3 + 3 * ii);
       // ---- epilogue: D row = (e & 3) + 8 * (e >> 2) + 4 * hi -> channel of n-tile j, column = lane & 31 -> row of the fragment
@@ -201,6 +213,12 @@ __global__ __launch_bounds__(RS_THREADS) void k_rowstream(RsArgs P) {
           uint2 pk;
           pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));
           pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi2, bf16x2));
+          // rows are 8 bytes longer than the tile: row r starts 2 r banks further, so the 16 lanes of a ds_write_b64 group (16
+          // rows, one column) cover all 32 banks of their window (16 bytes of padding left rows r and r + 8 on the same banks:
+          // 2-way conflicts on every staging write, 25-39 % of the kernel's LDS cycles in profiles/r5/pmc_sq_k1.txt)
+#if defined(RIGL_RS_ABLATE) && (RIGL_RS_ABLATE & 32)       // timing experiment 32: no staging writes
+          if (pk.x == 0x12345678u)
+#endif
           *reinterpret_cast<uint2*>(stg + r31 * SROW + (j * 32 + 8 * q + 4 * hi) * 2) = pk;
         }
       // read back / add / store / sum in groups of four iterations (16 registers of read-back data live at a time)
@@ -208,7 +226,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rowstream(RsArgs P) {
       for (int g0 = 0; g0 < ITERS; g0 += 4) {
         uint4 v[4];
 #pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) v[i4] = *reinterpret_cast<const uint4*>(stg + ((g0 + i4) * RPI + srow) * SROW + sch * 16);
+        for (int i4 = 0; i4 < 4; ++i4) {
+          // this lane's 16 bytes as two ds_read_b64 (rows are only 8-byte aligned): the 16 lanes of row R and the 16 of
+          // row R + 1 interleave on the banks
+          const unsigned char* const p = stg + ((g0 + i4) * RPI + srow) * SROW + sch * 16;
+          const uint2 lo8 = *reinterpret_cast<const uint2*>(p), hi8 = *reinterpret_cast<const uint2*>(p + 8);
+          v[i4] = make_uint4(lo8.x, lo8.y, hi8.x, hi8.y);
+        }
         if (ADDEND) {
 #pragma unroll
           for (int i4 = 0; i4 < 4; ++i4) {
@@ -220,9 +244,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_rowstream(RsArgs P) {
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
           const u32x4 o = {v[i4].x, v[i4].y, v[i4].z, v[i4].w};
+#if defined(RIGL_RS_ABLATE) && (RIGL_RS_ABLATE & 2)        // timing experiment 2: no output stores
+          if (o.x == 0x12345678u)
+#endif
           __builtin_amdgcn_raw_buffer_store_b128(o, rsrcC, (int)coff[g0 + i4], 0, 0);
         }
+#if defined(RIGL_RS_ABLATE) && (RIGL_RS_ABLATE & 4)        // timing experiment 4: no statistics
+        if (false) {
+#else
         if (!DGRAD) {
+#endif
           // rows beyond the fragment were multiplied as zeros: they add nothing
 #pragma unroll
           for (int i4 = 0; i4 < 4; ++i4)
