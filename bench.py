@@ -379,7 +379,7 @@ def main():
       # stamped with the library build it was collected on.
       traffic = traffic_build = None
       if args.workload == 'resnet50':
-        for rnd in ('r4', 'r3', 'r2', 'r1'):
+        for rnd in ('r5', 'r4', 'r3', 'r2', 'r1'):
           try:
             with open(os.path.join(ROOT, 'profiles', rnd, 'k1_traffic.json')) as fh:
               tj = json.load(fh)
