@@ -16,7 +16,8 @@
 //     waves are 3.06 fragments of 32 rows (one wave in sixteen runs a fourth pass: 77 %) but 3.92 of 25.  Fragment fr
 //     belongs to slot fr % slots: at any moment the grid streams ONE window of the tensors.
 //   * Epilogue per fragment (operands swapped: a lane holds 4 consecutive output channels of one row): bf16, staged in a
-//     wave-private LDS tile, read back 16 bytes per lane = whole 64 * TN-byte row segments, dgrad adds the shortcut
+//     wave-private LDS tile (rows padded by 8 bytes: conflict-free ds_write_b64), read back 16 bytes per lane (two
+//     ds_read_b64) = whole 64 * TN-byte row segments, dgrad adds the shortcut
 //     gradient (bf16(bf16(acc) + addend), requested at the top of the fragment), stores.  Forward: the batch-norm
 //     statistics of the bf16 outputs are summed from the read-back chunks -- a lane sees the SAME eight channels in
 //     every iteration of every fragment, so sixteen fp32 registers per lane collect them for the whole kernel; one
