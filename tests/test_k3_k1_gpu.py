@@ -454,3 +454,30 @@ def test_depthwise_conv(case):
     assert torch.equal(part, part2)
   else:
     assert part is None
+
+
+def test_plan_caches_follow_the_knobs_on_a_live_descriptor():
+  """the statistics-part count cached on a descriptor follows a knob set AFTER the layer's first call --
+  a kernel switched on later writes fewer partial rows than the stale count, and batch norm would have summed
+  uninitialised rows.  Same descriptor, rowstream off -> on -> off: the partial tensor's shape follows and the sums hold."""
+  from rigl_amd import ops
+  g = torch.Generator().manual_seed(4)
+  N, H, Ci, Co = 8, 28, 128, 512
+  x = torch.randn(N, H, H, Ci, generator=g).to(torch.bfloat16).to(DEV)
+  w = (torch.randn(Ci * Co, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+  d = ops.conv_desc(N, H, H, Ci, Co, 1, 1, 1, 0, 0, H, H)
+  M = N * H * H
+  shapes = []
+  try:
+    for v in (0, 1, 0):
+      ops.tune_set('rowstream', v)
+      y, part = ops.conv_fwd(d, x, w, stats=True)
+      shapes.append(part.shape[0])
+      yf = y.double().reshape(M, Co)
+      s = part.double().sum(0)
+      assert float((s[0] - yf.sum(0)).abs().max()) <= 2e-6 * float(yf.abs().sum(0).max()) + 1e-6
+      q = (yf * yf).sum(0)
+      assert float(((s[1] - q).abs() / (q + 1e-6)).max()) <= 2e-6
+  finally:
+    ops.tune_unset('rowstream')
+  assert shapes[0] == shapes[2] == (M + 127) // 128 and shapes[1] != shapes[0] and shapes[1] % 8 == 0
