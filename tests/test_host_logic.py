@@ -174,6 +174,7 @@ def test_reference_alias_package():
   assert a.SparseRigLOptimizer is sparse_optimizers.SparseRigLOptimizer
   assert a.get_grow_grads is sparse_optimizers.get_grow_grads
   assert b.get_mask_random is sparse_utils.get_mask_random
+  assert b.get_stats is sparse_utils.get_stats
   assert c.sparse_conv2d is pruning_layers.sparse_conv2d
 
 
