@@ -293,6 +293,7 @@ __global__ __launch_bounds__(THREADS) void k_bwd1x1(Bwd1x1Args P) {
 // kernel off (a layer's dX then comes from the igemm body again, in both entry points).
 static inline int bwd1x1_kind(const RiglConvDesc* d) {
   if (d->kh != 1 || d->kw != 1 || d->stride_h != 1 || d->stride_w != 1 || d->pad_top || d->pad_left) return 0;
+  if (d->ho != d->h || d->wo != d->w) return 0;            // (a cropped output grid: the generic bodies walk ho x wo)
   if ((int64_t)d->n * d->h * d->w < 65536) return 0;
   if (RIGL_TUNE("bwd1x1", 1) == 0) return 0;
   if (d->cin == 64 && d->cout == 256) return 1;

@@ -1,0 +1,354 @@
+// K1, single-pass backward of the 1x1 / stride-1 "reduce" convs with MANY input channels (included inside namespace
+// rigl::k1 of conv.hip): cin a multiple of 128 (512, 1024, 256 ...), cout 128 or 256 -- the layers bwd1x1.hpp's
+// "W in registers, cin = 64" form cannot take and that ran as two GEMMs sharing one grid (k_bwd_fused: dY read twice, X
+// and dY staged by two different bodies, 2-3.5x over their bound).  Here the input-channel axis is cut into slices of
+// SC = 128 channels and a workgroup (8 waves, one per CU) owns ONE slice for ONE group of pixel rows:
+//   * its W slice [128][cout] never leaves the registers: wave (cf = wave & 3) holds the 32 x cout fragment of its 32 input
+//     channels as MFMA "A" operands (cout / 4 VGPRs);
+//   * it walks its 32-pixel K-tiles once (tile kt of row group g = tile g + kt * G of the tensor: at any moment the grid
+//     streams ONE window): dY rows [32][cout] and the X slice [32][128] come in by LDS-DMA through an NST-deep ring;
+//   * dX[32][slice] = dY x Wslice^T on v_mfma_f32_32x32x16_bf16 (operands swapped: a lane holds 4 consecutive input
+//     channels of one pixel) by the four waves of one half of the workgroup -- the halves alternate tile by tile, and waves
+//     w and w + 4 share a SIMD, so every SIMD issues the same MFMA count per tile; the tile leaves through an LDS
+//     staging tile as whole 16-byte row segments (+ the shortcut gradient: bf16(bf16(acc) + addend));
+//   * dW[slice][cout] += X^T dY on transposing LDS reads (ds_read_b64_tr_b16) of the SAME two tiles, 2 x 2 (cout = 256)
+//     or 1 x 2 (cout = 128) 32x32 fragments per wave, accumulated over ALL tiles of the workgroup; one partial per
+//     workgroup at the end into slab[g][slice rows][cout] (launch_wgrad_reduce sums the G slabs in a fixed order:
+//     deterministic dW).
+// dY is read from HBM once per XCD (the `slices` workgroups of a row group sit on one XCD and run in step), X, the addend
+// and dX once.  The dY tile serves a row-major ds_read_b128 (k = output channel) and the transposing read (k = pixel);
+// its 16-byte chunks are XORed with ((row & 3) << 2) | ((row >> 2) & 3) on the DMA's source side: the sixteen rows of a
+// ds_read_b128 lane group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}) then sit in sixteen different 16-byte bank
+// slots, and the four rows of a transposing 32-lane pass in four different 64-byte bank quarters (256- and 512-byte rows
+// alike: a row is a whole number of 256-byte bank windows).  tools/emu/bs_emu.py restates the index arithmetic per lane.
+// Loop as in bwd1x1.hpp: counted vmcnt on LOADS only, one raw barrier per K-tile, the stores of tile kt at the top of
+// iteration kt + 1, the program order of an iteration's vector-memory operations pinned.
+// Reference: the autodiff of layers.masked_conv2d for the bottleneck's first conv (pruning_layers.py:139-157,
+// resnet_model.py:456-470; sparse_optimizers_base.py:478-485 for the dense dW).
+#pragma once
+
+struct BsArgs {
+  const uint16_t* X;    // [M][CI] bf16
+  const uint16_t* DY;   // [M][CO] bf16
+  const uint16_t* W;    // [CI][CO] bf16 (the HWIO shadow of a 1x1 kernel)
+  const uint16_t* ADD;  // [M][CI] bf16 or NULL
+  uint16_t* DX;         // [M][CI] bf16
+  float* SLAB;          // [G][CI][CO] fp32 partial dW (unused with DO_W = false)
+  int M, CI, slices, G;
+  uint32_t x_bytes, dy_bytes;
+  unsigned long long* TRACE;   // development (-DRIGL_BS_TRACE): [grid][2 waves (0 and 4)][8] s_memtime ticks per phase
+};
+#ifdef RIGL_BS_TRACE
+#define BS_STAMP(i_) { if (P.TRACE) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tr_acc[i_] += n_ - tr_last; tr_last = n_; } }
+#else
+#define BS_STAMP(i_) { }
+#endif
+
+constexpr int BS_THREADS = 512;
+
+__device__ __forceinline__ int bs_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// bf16(a + b) per half on the hardware converter (round to nearest even)
+__device__ __forceinline__ uint32_t bs_add_bf16x2(uint32_t a, uint32_t b) {
+  const f32x2 s2 = {__uint_as_float(a << 16) + __uint_as_float(b << 16),
+                    __uint_as_float(a & 0xFFFF0000u) + __uint_as_float(b & 0xFFFF0000u)};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(s2, bf16x2));
+}
+
+template <int CO, bool DO_W>
+struct BsGeom {
+  static constexpr int SC = 128, PX = 32, NST = 4;             // (NST - 1 odd: the half that issues a tile is the half that multiplies it)
+  static constexpr int YROWB = CO * 2, XROWB = SC * 2;
+  static constexpr int Y_BYTES = PX * YROWB, X_BYTES = DO_W ? PX * XROWB : 0, A_BYTES = PX * XROWB;
+  static constexpr int STAGE = Y_BYTES + X_BYTES + A_BYTES;    // dY rows, the X slice, the slice of the shortcut gradient
+  static constexpr int DXROWB = XROWB + 8, DX_BYTES = PX * DXROWB;     // 8 bytes of padding: conflict-free ds_write_b64 (rowstream.hpp)
+  static constexpr int SMEM = NST * STAGE + 2 * DX_BYTES;
+};
+
+template <int CO, bool DO_W>
+__global__ __launch_bounds__(BS_THREADS) void k_bwdslice(BsArgs P) {
+  using G = BsGeom<CO, DO_W>;
+  constexpr int SC = G::SC, PX = G::PX, NST = G::NST, YROWB = G::YROWB, XROWB = G::XROWB;
+  constexpr int Y_BYTES = G::Y_BYTES, X_BYTES = G::X_BYTES, STAGE = G::STAGE, DXROWB = G::DXROWB, DX_BYTES = G::DX_BYTES;
+  // a tile's DMA pieces (1 KB wave-instructions) are issued by the FOUR waves of one half: per wave
+  constexpr int YPW = Y_BYTES / 1024 / 4, XPW = DO_W ? 2 : 0, APW = 2;
+  static_assert(Y_BYTES % 4096 == 0 && PX * XROWB == 8192, "whole rounds of four waves");
+  constexpr int PW_N = YPW + XPW, PW_A = PW_N + APW;           // DMA instructions per issuing thread per K-tile (without / with addend)
+  constexpr int KS = CO / 16;                                  // dgrad k-steps
+  constexpr int NFO = CO / 32;                                 // wgrad: 32x32 fragments of dW[128][CO] along cout (4 along cin)
+  constexpr int TI = NFO >= 8 ? 2 : 1, TO = 2;                 // fragments per wave: TI x TO
+  static_assert((4 / TI) * (NFO / TO) == 8, "eight waves cover the slice's dW");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_bs[];
+  unsigned char* const dxs = smem_bs + NST * STAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, r31 = lane & 31;
+  // workgroup -> (channel slice, row group): the slices of one row group share an XCD (block b runs on XCD b % 8)
+  const int xcd = (int)(blockIdx.x & 7u), idx = (int)(blockIdx.x >> 3);
+  const int slice = idx % P.slices, g = xcd + 8 * (idx / P.slices);
+  const int KT_all = (P.M + PX - 1) / PX;
+  const int KT = g < KT_all ? (KT_all - g + P.G - 1) / P.G : 0;
+  const __amdgpu_buffer_rsrc_t rsrcY = make_rsrc(P.DY, P.dy_bytes), rsrcX = make_rsrc(P.X, P.x_bytes);
+  const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.ADD ? P.ADD : P.DY, P.ADD ? P.x_bytes : 0u);
+  const bool has_add = P.ADD != nullptr;
+  // the two halves of the workgroup: cf = the wave's 32-channel fragment of the slice, par = the parity of the tiles whose dX it
+  // computes (and whose DMA it issued); waves w and w + 4 share a SIMD
+  const int cf = wave & 3, par = wave >> 2;
+
+  // ---- DMA lanes: wave-instruction i of a tile with ROWB-byte rows fills rows i * (1024 / ROWB) ..; lane l: row + l / (ROWB / 16),
+  // 16-byte slot l % (ROWB / 16), fetching the logical chunk slot ^ swizzle(row); piece i = q * 4 + cf of the issuing half
+  int y_row[YPW], y_col[YPW], x_row[2], x_col[2];
+#pragma unroll
+  for (int q = 0; q < YPW; ++q) {
+    const int i = q * 4 + cf, row = i * (1024 / YROWB) + lane / (YROWB / 16), slot = lane % (YROWB / 16);
+    y_row[q] = row; y_col[q] = (slot ^ bs_swz(row)) * 8;
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = q * 4 + cf, row = i * (1024 / XROWB) + lane / (XROWB / 16);
+    x_row[q] = row; x_col[q] = slice * SC + (((lane % (XROWB / 16)) ^ bs_swz(row)) * 8);
+  }
+#define BS_ISSUE(kt_, stage_)                                                                            \
+  {                                                                                                      \
+    const int p0_ = (g + (kt_) * P.G) * PX;                                                              \
+    unsigned char* const st_ = smem_bs + (stage_) * STAGE;                                               \
+    _Pragma("unroll") for (int q = 0; q < YPW; ++q) {                                                    \
+      const int p_ = p0_ + y_row[q];                                                                     \
+      const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * CO + y_col[q]) * 2u) : (int)OOB;                 \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                          \
+          rsrcY, (__attribute__((address_space(3))) void*)(st_ + (q * 4 + cf) * 1024), 16, off_, 0, 0, 0); \
+    }                                                                                                    \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
+      const int p_ = p0_ + x_row[q];                                                                     \
+      const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * P.CI + x_col[q]) * 2u) : (int)OOB;               \
+      if (DO_W)                                                                                          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
+            rsrcX, (__attribute__((address_space(3))) void*)(st_ + Y_BYTES + (q * 4 + cf) * 1024), 16, off_, 0, 0, 0); \
+      if (has_add)                                                                                       \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
+            rsrcA, (__attribute__((address_space(3))) void*)(st_ + Y_BYTES + X_BYTES + (q * 4 + cf) * 1024), 16, off_, 0, 0, 0); \
+    }                                                                                                    \
+  }
+
+  // ---- dgrad: the wave's W fragment (32 input channels x CO) in registers
+  bf16x8 wfr[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int ci = slice * SC + cf * 32 + r31, co = ks * 16 + hi * 8;
+    wfr[ks] = *reinterpret_cast<const bf16x8*>(P.W + (int64_t)ci * CO + co);
+  }
+  // dY fragment of k-step ks: lane l = row l & 31, logical chunk 2 * ks + (l >> 5)
+  const int d_base = r31 * YROWB, d_swz = bs_swz(r31);
+
+  // ---- wgrad: transposing fragment reads (lane geometry of bwd1x1.hpp / wgrad_tr_body)
+  const int gq = lane >> 4, j16 = lane & 15;
+  const int t_row = 8 * (gq >> 1) + (j16 >> 2);                     // + 16 * k2 (+ 4 for the second half of the 8 pixels)
+  const int t_low = 2 * (gq & 1) + ((j16 >> 1) & 1), t_half = (j16 & 1) * 8;
+  const int fi0 = TI == 2 ? (wave & 1) * 2 : (wave & 3);            // first cin fragment of the wave
+  const int fo0 = TI == 2 ? (wave >> 1) * 2 : (wave >> 2) * 2;      // first cout fragment
+  f32x16 acc2[DO_W ? TI : 1][TO];
+  if (DO_W) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TO; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
+  }
+#define BS_TR_OFF(ROWB_, chunk_, plus4_) \
+  ((t_row + (plus4_)) * (ROWB_) + ((((chunk_) + t_low) ^ bs_swz(t_row + (plus4_))) << 4) + t_half)
+
+  // a dX tile is 32 rows x 16 pieces of 16 bytes, stored by the four waves of one half: two pieces per thread
+  const int ft = cf * 64 + lane;
+  // stores the staged tile ktp (written by this half before the barrier this is called behind)
+#define BS_FLUSH(ktp_)                                                                                   \
+  {                                                                                                      \
+    uint4 v_[2];                                                                                         \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
+      const int pc_ = q * 256 + ft, row_ = pc_ >> 4, ch_ = pc_ & 15;                                     \
+      const unsigned char* src_ = dxs + ((ktp_) & 1) * DX_BYTES + row_ * DXROWB + ch_ * 16;              \
+      const uint2 lo8_ = *reinterpret_cast<const uint2*>(src_), hi8_ = *reinterpret_cast<const uint2*>(src_ + 8); \
+      v_[q] = make_uint4(lo8_.x, lo8_.y, hi8_.x, hi8_.y);                                                \
+    }                                                                                                    \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
+      const int pc_ = q * 256 + ft, row_ = pc_ >> 4, ch_ = pc_ & 15;                                     \
+      const int p_ = (g + (ktp_) * P.G) * PX + row_;                                                     \
+      if (p_ < P.M) *reinterpret_cast<uint4*>(P.DX + (int64_t)p_ * P.CI + slice * SC + ch_ * 8) = v_[q]; \
+    }                                                                                                    \
+  }
+#ifdef RIGL_BS_TRACE
+  unsigned long long tr_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+  unsigned long long tr_last = __builtin_amdgcn_s_memtime();
+#endif
+  // prologue: tile t comes from the half with par = t & 1
+  if (par == 0) { if (0 < KT) BS_ISSUE(0, 0); if (2 < KT) BS_ISSUE(2, 2); }
+  else { if (1 < KT) BS_ISSUE(1, 1); }
+  BS_STAMP(7);
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool mine = (kt & 1) == par;
+    if (mine) {
+      // this half issued tile kt three iterations ago; the only LOADS behind it are the pieces of tile kt + 2 (stores are not
+      // counted on: bwd1x1.hpp)
+      if (kt + 2 < KT) { if (has_add) wait_vmcnt<PW_A>(); else wait_vmcnt<PW_N>(); }
+      else wait_vmcnt<0>();
+    }
+    // (a raw s_barrier does not wait for this wave's ds_writes of the previous dX tile: bwd1x1.hpp)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    BS_STAMP(0);
+    const unsigned char* Ys = smem_bs + (kt % NST) * STAGE;
+    const unsigned char* Xs = Ys + Y_BYTES;
+    const unsigned char* As = Xs + X_BYTES;
+    f32x16 a0, a1;
+    uint2 av[4];
+    if (!mine) {
+      // the other half's tile: bring in tile kt + 3 (ours) and store our dX tile kt - 1 -- the vector-memory issue of the
+      // workgroup runs under the MFMAs of the half that shares our SIMDs
+      if (kt + NST - 1 < KT) BS_ISSUE(kt + NST - 1, (kt + NST - 1) % NST);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      BS_STAMP(1);
+      if (kt > 0) BS_FLUSH(kt - 1);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      BS_STAMP(2);
+    } else {
+      // ---- dX tile: D[ci][px] = W-fragment x dY-fragment, two accumulators (even / odd k-steps: no back-to-back dependent MFMAs)
+      if (has_add) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          av[q] = *reinterpret_cast<const uint2*>(As + r31 * XROWB + (((cf * 4 + q) ^ d_swz) << 4) + hi * 8);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a0[e] = a1[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ks += 2) {
+        const bf16x8 y0 = *reinterpret_cast<const bf16x8*>(Ys + d_base + (((2 * ks + hi) ^ d_swz) << 4));
+        const bf16x8 y1 = *reinterpret_cast<const bf16x8*>(Ys + d_base + (((2 * ks + 2 + hi) ^ d_swz) << 4));
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[ks], y0, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[ks + 1], y1, a1, 0, 0, 0);
+      }
+      BS_STAMP(4);
+    }
+    // ---- dW partial: D2[ci][co] += X^T-fragment x dY^T-fragment, two k-steps of 16 pixels
+    if (DO_W) {
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        bf16x8 fa[TI], fb[TO];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+          fa[i] = lds_read_tr_pair(Xs + k2 * 16 * XROWB + BS_TR_OFF(XROWB, (fi0 + i) * 4, 0), Xs + k2 * 16 * XROWB + BS_TR_OFF(XROWB, (fi0 + i) * 4, 4));
+#pragma unroll
+        for (int j = 0; j < TO; ++j)
+          fb[j] = lds_read_tr_pair(Ys + k2 * 16 * YROWB + BS_TR_OFF(YROWB, (fo0 + j) * 4, 0), Ys + k2 * 16 * YROWB + BS_TR_OFF(YROWB, (fo0 + j) * 4, 4));
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TO; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc2[i][j], 0, 0, 0);
+      }
+    }
+    BS_STAMP(5);
+    // ---- dX tile (+ the shortcut gradient: bf16(bf16(acc) + addend)) -> LDS: D row (e & 3) + 8 * (e >> 2) + 4 * hi = input
+    // channel of the fragment, column lane & 31 = pixel
+    if (mine) {
+      unsigned char* const dst = dxs + (kt & 1) * DX_BYTES + r31 * DXROWB;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x2 lo = {a0[4 * q] + a1[4 * q], a0[4 * q + 1] + a1[4 * q + 1]};
+        const f32x2 hi2 = {a0[4 * q + 2] + a1[4 * q + 2], a0[4 * q + 3] + a1[4 * q + 3]};
+        uint2 pk;
+        pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));
+        pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi2, bf16x2));
+        if (has_add) { pk.x = bs_add_bf16x2(pk.x, av[q].x); pk.y = bs_add_bf16x2(pk.y, av[q].y); }
+        *reinterpret_cast<uint2*>(dst + (cf * 32 + 8 * q + 4 * hi) * 2) = pk;
+      }
+    }
+    BS_STAMP(6);
+  }
+  if (KT > 0) {
+    __syncthreads();
+    if (((KT - 1) & 1) == par) BS_FLUSH(KT - 1);
+  }
+#undef BS_FLUSH
+#undef BS_ISSUE
+#undef BS_TR_OFF
+  // ---- the workgroup's dW partial -> slab g, rows of its slice
+  if (DO_W) {
+    float* const out = P.SLAB + ((int64_t)g * P.CI + slice * SC) * CO;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TO; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ci = (fi0 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi, co = (fo0 + j) * 32 + r31;
+          out[(int64_t)ci * CO + co] = acc2[i][j][e];
+        }
+  }
+#ifdef RIGL_BS_TRACE
+  if (P.TRACE && lane == 0 && (wave & 3) == 0) {
+    const unsigned long long n_ = __builtin_amdgcn_s_memtime();
+    tr_acc[7] += n_ - tr_last;
+    for (int i = 0; i < 8; ++i) P.TRACE[((int64_t)blockIdx.x * 2 + (wave >> 2)) * 8 + i] = tr_acc[i];
+  }
+#endif
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+// Legal: 1x1, stride 1, no padding, same output grid; cout 128 or 256; cin a multiple of 128 with cin / 128 a power of two
+// <= 32; enough 32-pixel tiles for every row group.  "bwdslice": 0 = off, 1 = the measured layers, 2 = every legal layer.
+struct BsPlan { int co, slices, G; };
+static bool bs_plan(const RiglConvDesc* d, BsPlan& p) {
+  if (d->kh != 1 || d->kw != 1 || d->stride_h != 1 || d->stride_w != 1 || d->pad_top || d->pad_left) return false;
+  if (d->ho != d->h || d->wo != d->w) return false;
+  if (d->cout != 128 && d->cout != 256) return false;
+  if (d->cin % 128) return false;
+  p.co = d->cout; p.slices = d->cin / 128;
+  if (p.slices > 32 || (p.slices & (p.slices - 1))) return false;
+  const int64_t M = (int64_t)d->n * d->h * d->w;
+  if (M * d->cin * 2 >= (1ll << 31)) return false;
+  int groups = num_cus() / (8 * p.slices);
+  if (groups < 1) groups = 1;
+  p.G = 8 * groups;
+  if ((M + 31) / 32 < 4ll * p.G) return false;       // at least four tiles per row group
+  return true;
+}
+template <int CO, bool DO_W>
+static bool bs_ready_i() {
+  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwdslice<CO, DO_W>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, BsGeom<CO, DO_W>::SMEM) == hipSuccess;
+  return ready;
+}
+static bool bs_use(const RiglConvDesc* d, BsPlan* out = nullptr) {
+  BsPlan p;
+  if (!bs_plan(d, p)) return false;
+  const int knob = RIGL_TUNE("bwdslice", 1);
+  if (knob == 0) return false;
+  const bool ready = p.co == 256 ? (bs_ready_i<256, true>() && bs_ready_i<256, false>())
+                                 : (bs_ready_i<128, true>() && bs_ready_i<128, false>());
+  if (ready && out) *out = p;
+  return ready;
+}
+static size_t bs_workspace(const RiglConvDesc* d) {
+  BsPlan p;
+  return bs_plan(d, p) ? (size_t)p.G * d->cin * d->cout * 4 : 0;
+}
+template <int CO, bool DO_W>
+static void launch_bs_i(const BsArgs& a, hipStream_t st) {
+  RIGL_K_LAUNCH((k_bwdslice<CO, DO_W>), dim3((unsigned)(a.slices * a.G)), dim3(BS_THREADS), (unsigned)(BsGeom<CO, DO_W>::SMEM), st, a);
+}
+// slab == NULL: dX only (the same bits as with the weight-gradient half)
+static void launch_bs(const RiglConvDesc* d, const BsPlan& p, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                      const rigl_bf16* addend, rigl_bf16* dx, float* slab, hipStream_t st) {
+  BsArgs a = {};
+#ifdef RIGL_BS_TRACE
+  { const char* e = getenv("RIGL_BS_TRACE_PTR"); a.TRACE = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr; }
+#endif
+  a.X = x; a.DY = dy; a.W = w_hwio; a.ADD = addend; a.DX = dx; a.SLAB = slab;
+  a.M = d->n * d->h * d->w; a.CI = d->cin; a.slices = p.slices; a.G = p.G;
+  a.x_bytes = (uint32_t)((size_t)a.M * d->cin * 2); a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
+  if (p.co == 256) { if (slab) launch_bs_i<256, true>(a, st); else launch_bs_i<256, false>(a, st); }
+  else { if (slab) launch_bs_i<128, true>(a, st); else launch_bs_i<128, false>(a, st); }
+}

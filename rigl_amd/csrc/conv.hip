@@ -1315,6 +1315,7 @@ static inline int kpad(const RiglConvDesc* d) { return (d->kh * d->kw * d->cin +
 #include "stem.hpp"
 #include "c3x3.hpp"
 #include "rowstream.hpp"
+#include "bwdslice.hpp"
 
 // Scratch of the K-split ping-pong forward (convpp.hpp: pp_ksplit_ok): two fp32 partial tiles + a counter per tile.
 static size_t pp_ksplit_workspace(const RiglConvDesc* d) {
@@ -1421,6 +1422,8 @@ size_t rigl_conv2d_workspace_bytes(const RiglConvDesc* d, int32_t which) {
     if (n11 > need) need = n11;
     const size_t n33 = align_up(c3x3_wgrad_workspace(d), 256);  // ... as do the slab-resident 3x3 kernels (c3x3.hpp)
     if (n33 > need) need = n33;
+    const size_t nbs = align_up(bs_workspace(d), 256);          // ... and the channel-sliced single-pass backward (bwdslice.hpp)
+    if (nbs > need) need = nbs;
     return need;
   }
   return 0;
@@ -1549,6 +1552,7 @@ int32_t rigl_conv2d_dgrad_stats_parts(const RiglConvDesc* d) {
   if (!d || check_desc(d, "rigl_conv2d_dgrad_stats_parts")) return 0;
   if ((d->cin % 8) || (d->cout % 8)) return 0;
   if (bwd1x1_kind(d)) return 0;               // the single-pass 1x1 backward has no reduction epilogue
+  if (bs_use(d)) return 0;                    // nor has its channel-sliced form
   if (c3x3_use(d)) return 0;                  // nor has the slab-resident 3x3 dgrad
   if (rs_use<1>(d)) return 0;                 // nor the row-streaming dgrad
   IgemmArgs a = dgrad_args(d, nullptr, nullptr, nullptr, nullptr);
@@ -1607,18 +1611,27 @@ static int dgrad_impl(const RiglConvDesc* d, const rigl_bf16* dy, const rigl_bf1
     RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
     return RIGL_OK;
   }
-  {
-    RsPlan rp;
-    if (!bn && rs_use<1>(d, &rp)) {             // dX[M][cin] = dY[M][cout] x W[cin][cout]^T, rows streamed (rowstream.hpp)
-      launch_rs<1>(d, rp, dy, w_hwio, addend, dx, nullptr, st);
-      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
-      return RIGL_OK;
-    }
-  }
+  // (the single-pass kernels first, in the order of bwd_impl: a layer's dX has the same bits from both entry points)
   if (!bn && bwd1x1_kind(d)) {
     // the big-M 1x1 layers: dX from the single-pass backward kernel (without its weight-gradient half), so that it has
     // the bits rigl_masked_conv2d_bwd gives it
     if (launch_bwd1x1(d, nullptr, dy, w_hwio, addend, dx, nullptr, st)) {
+      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
+      return RIGL_OK;
+    }
+  }
+  {
+    BsPlan bp;
+    if (!bn && bs_use(d, &bp)) {                // the many-input-channel 1x1 layers: the channel-sliced single-pass kernel, dX half only
+      launch_bs(d, bp, nullptr, dy, w_hwio, addend, dx, nullptr, st);
+      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
+      return RIGL_OK;
+    }
+  }
+  {
+    RsPlan rp;
+    if (!bn && rs_use<1>(d, &rp)) {             // dX[M][cin] = dY[M][cout] x W[cin][cout]^T, rows streamed (rowstream.hpp)
+      launch_rs<1>(d, rp, dy, w_hwio, addend, dx, nullptr, st);
       RIGL_CHECK_LAUNCH("rigl_masked_conv2d_dgrad");
       return RIGL_OK;
     }
@@ -1791,6 +1804,34 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
     const IgemmArgs ap = dgrad_args(d, dy, w_hwio, addend, dx);
     dgrad_pp = plan_pp<1>(ap).variant != 0;
   }
+  // The big-M 1x1 layers: dX and dW in ONE pass over dY (bwd1x1.hpp), one slab per workgroup, then the reduce
+  if (whole && !bn && bwd1x1_kind(d) && bwd1x1_ready(d)) {
+    if (need && (!workspace || workspace_bytes < need))
+      return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
+    ProfFamily prof(PROF_CONV_BWD);
+    if (launch_bwd1x1(d, x, dy, w_hwio, addend, dx, static_cast<float*>(workspace), st)) {
+      const int64_t n_out = (int64_t)d->cin * d->cout;
+      ReduceArgs ra = {static_cast<const float*>(workspace), dw, n_out, n_out, bwd1x1_splits()};
+      launch_wgrad_reduce(ra, st);
+      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");
+      return RIGL_OK;
+    }
+  }
+  // The many-input-channel 1x1 layers: the same single pass per 128-channel slice (bwdslice.hpp), one slab per row group
+  {
+    BsPlan bp;
+    if (whole && !bn && bs_use(d, &bp)) {
+      if (need && (!workspace || workspace_bytes < need))
+        return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
+      ProfFamily prof(PROF_CONV_BWD);
+      launch_bs(d, bp, x, dy, w_hwio, addend, dx, static_cast<float*>(workspace), st);
+      const int64_t n_out = (int64_t)d->cin * d->cout;
+      ReduceArgs ra = {static_cast<const float*>(workspace), dw, n_out, n_out, bp.G};
+      launch_wgrad_reduce(ra, st);
+      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");
+      return RIGL_OK;
+    }
+  }
   // Layers whose dgrad streams rows (rowstream.hpp): the weight gradient with its stand-alone plan, then the dgrad -- two
   // launches (+ reduce) instead of the shared one
   {
@@ -1801,19 +1842,6 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
       if (rc) return rc;
       prof_current_kind() = PROF_CONV_BWD;
       launch_rs<1>(d, rp, dy, w_hwio, addend, dx, nullptr, st);
-      RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");
-      return RIGL_OK;
-    }
-  }
-  // The big-M 1x1 layers: dX and dW in ONE pass over dY (bwd1x1.hpp), one slab per workgroup, then the reduce
-  if (whole && !bn && bwd1x1_kind(d) && bwd1x1_ready(d)) {
-    if (need && (!workspace || workspace_bytes < need))
-      return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
-    ProfFamily prof(PROF_CONV_BWD);
-    if (launch_bwd1x1(d, x, dy, w_hwio, addend, dx, static_cast<float*>(workspace), st)) {
-      const int64_t n_out = (int64_t)d->cin * d->cout;
-      ReduceArgs ra = {static_cast<const float*>(workspace), dw, n_out, n_out, bwd1x1_splits()};
-      launch_wgrad_reduce(ra, st);
       RIGL_CHECK_LAUNCH("rigl_masked_conv2d_bwd");
       return RIGL_OK;
     }

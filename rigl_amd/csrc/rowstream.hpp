@@ -308,6 +308,7 @@ struct RsPlan { int kc, tn, slices, gprime, F, nfrag; };
 template <int MODE>
 static bool rs_plan(const RiglConvDesc* d, RsPlan& p) {
   if (d->kh != 1 || d->kw != 1 || d->stride_h != 1 || d->stride_w != 1 || d->pad_top || d->pad_left) return false;
+  if (d->ho != d->h || d->wo != d->w) return false;        // (a cropped output grid: the generic bodies walk ho x wo)
   const int k = MODE == 0 ? d->cin : d->cout, n = MODE == 0 ? d->cout : d->cin;
   if (k != 64 && k != 128 && k != 256 && k != 512) return false;
   p.kc = k / 64;
@@ -361,7 +362,10 @@ static bool rs_ready_i() {
 template <int MODE>
 static bool rs_default(const RiglConvDesc* d, const RsPlan& p) {
   const int k = MODE == 0 ? d->cin : d->cout, n = MODE == 0 ? d->cout : d->cin;
-  if (MODE == 0) return k <= 256;
+  // (measured on the ResNet-50 shapes at batch 128 only: up to 8 column slices -- 32 slices re-read the rows 32 times, the
+  // 512 -> 2048 regression above -- and the row counts of that table; anything else keeps its former body unless knob = 2)
+  const int64_t M = (int64_t)d->n * d->h * d->w;
+  if (MODE == 0) return k <= 256 && p.slices <= 8 && M >= 25088;
   return k == 64 && n == 256;
 }
 template <int MODE>

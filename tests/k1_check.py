@@ -8,6 +8,7 @@ which the library reads once per process, can be chosen per invocation:
   python tests/k1_check.py --set small         # small 1x1 / 3x3 shapes (both column widths, ragged N, halo rows)
   python tests/k1_check.py --set pp            # edge cases of the 8-wave ping-pong body (1..9 K-tiles, row tails, stride 2)
   python tests/k1_check.py --set rs            # the row-streaming 1x1 body (run with RIGL_ROWSTREAM=2: every legal shape takes it)
+  python tests/k1_check.py --set bs            # the channel-sliced single-pass 1x1 backward (bwdslice.hpp): 1 .. 32 slices, ragged tiles
   python tests/k1_check.py --set c3            # the slab-resident 3x3 kernels (64 -> 64 channels): tile heights, widths, partial tiles
   python tests/k1_check.py --set resnet50 --batch 128     # the 23 distinct ResNet-50 layer shapes at the benchmarked batch
 
@@ -105,6 +106,20 @@ RS_CASES = [
 ]
 
 
+# The channel-sliced single-pass 1x1 backward (bwdslice.hpp): cout 128 / 256, 1 .. 32 slices of 128 input channels, row
+# groups with and without a ragged last tile, the benchmarked shapes
+BS_CASES = [
+    (128, 14, 14, 1024, 256, 1, 1, 0, 0, 14, 14),  # the benchmarked group-3 layer: 8 slices x 32 row groups
+    (128, 28, 28, 512, 128, 1, 1, 0, 0, 28, 28),   # the group-2 layer: 4 slices x 64 row groups, cout 128 (1 x 2 fragments per wave)
+    (32, 28, 28, 512, 256, 1, 1, 0, 0, 28, 28),    # 4 slices, cout 256
+    (16, 56, 56, 256, 128, 1, 1, 0, 0, 56, 56),    # 2 slices x 128 row groups
+    (130, 13, 15, 1024, 256, 1, 1, 0, 0, 13, 15),  # 25 350 rows: a six-row last tile
+    (130, 23, 19, 128, 128, 1, 1, 0, 0, 23, 19),   # one slice, 256 row groups, ragged
+    (67, 14, 14, 2048, 128, 1, 1, 0, 0, 14, 14),   # 16 slices x 16 row groups, ragged
+    (20, 14, 14, 4096, 128, 1, 1, 0, 0, 14, 14),   # 32 slices x 8 row groups
+]
+
+
 def _c3_tile_rows(H, W):
   """Tile height of the c3x3.hpp forward (c3x3_geom restated): the most rows whose patch + zero tail fit the 544-pixel
   LDS budget of one of the two patch buffers, one fewer where that divides H."""
@@ -198,7 +213,8 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
       if x1:
         # rowstream.hpp: one partial per persistent workgroup of a column slice (rigl_conv2d_stats_parts says how many) -- the
         # totals above are the whole check
-        assert part.shape[0] <= 256, 'rowstream: more statistics parts than workgroups per slice'
+        assert part.shape[0] <= torch.cuda.get_device_properties(0).multi_processor_count, \
+            'rowstream: more statistics parts than workgroups per slice'
       elif c3:
         # c3x3.hpp: one partial per persistent workgroup (rigl_conv2d_stats_parts says how many), each the sum over the
         # tiles that workgroup walked -- the totals above are the whole check
@@ -272,11 +288,11 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
 
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument('--set', default='small', choices=['small', 'pp', 'stem', 'c3', 'rs', 'resnet50'])
+  ap.add_argument('--set', default='small', choices=['small', 'pp', 'stem', 'c3', 'rs', 'bs', 'resnet50'])
   ap.add_argument('--batch', type=int, default=128)
   ap.add_argument('--only', type=int, default=-1)
   a = ap.parse_args()
-  cases = {'small': SMALL_CASES, 'pp': PP_CASES, 'stem': STEM_CASES, 'c3': C3_CASES, 'rs': RS_CASES}.get(a.set) or resnet50_shapes(a.batch)
+  cases = {'small': SMALL_CASES, 'pp': PP_CASES, 'stem': STEM_CASES, 'c3': C3_CASES, 'rs': RS_CASES, 'bs': BS_CASES}.get(a.set) or resnet50_shapes(a.batch)
   worst, n = 0.0, 0
   for i, c in enumerate(cases):
     if a.only >= 0 and i != a.only:

@@ -55,7 +55,7 @@ def test_pingpong_edge_shapes(env):
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
 @pytest.mark.parametrize('env', PP_SETTINGS[:3] + PP_SETTINGS[4:5] + [
-    {'RIGL_BWD1X1': '0', 'RIGL_STEM_DIRECT': '0', 'RIGL_WGRAD_IL': '0', 'RIGL_C3X3': '0', 'RIGL_ROWSTREAM': '0'},   # the generic bodies on the layers with kernels of their own
+    {'RIGL_BWD1X1': '0', 'RIGL_STEM_DIRECT': '0', 'RIGL_WGRAD_IL': '0', 'RIGL_C3X3': '0', 'RIGL_ROWSTREAM': '0', 'RIGL_BWDSLICE': '0'},   # the generic bodies on the layers with kernels of their own
 ])
 def test_resnet50_layer_shapes_at_batch_128(env):
   """All distinct ResNet-50 conv shapes at the benchmarked per-GPU batch: fwd, fwd + statistics,
@@ -94,3 +94,14 @@ def test_row_streaming_1x1_shapes(env):
   shape, then under the default selection, then with the body off (pins the cases themselves)."""
   out = _run(['--set', 'rs'], env)
   assert out['cases'] == 13
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
+@pytest.mark.parametrize('env', [{}, {'RIGL_BWDSLICE': '0'}])
+def test_channel_sliced_single_pass_backward_shapes(env):
+  """The channel-sliced single-pass backward of the many-input-channel 1x1 layers (bwdslice.hpp: W slice in registers, dY
+  and the X slice through one LDS-DMA ring, dX and the slice's dW from the same tiles) on 1 .. 32 slices, cout 128 / 256,
+  ragged last tiles: dgrad (+ addend), the one-call backward (dX bit-equal to dgrad + addend, dW deterministic) against
+  the fp64 reference; with the knob off the same shapes on the shared-launch bodies (pins the cases themselves)."""
+  out = _run(['--set', 'bs'], env)
+  assert out['cases'] == 8
