@@ -31,11 +31,14 @@ struct BsArgs {
   const uint16_t* X;    // [M][CI] bf16
   const uint16_t* DY;   // [M][CO] bf16
   const uint16_t* W;    // [CI][CO] bf16 (the HWIO shadow of a 1x1 kernel)
-  const uint16_t* ADD;  // [M][CI] bf16 or NULL
+  const uint16_t* ADD;  // [M][CI] bf16 or NULL; with add_sh > 0 the gradient of a SUBSAMPLED view: one row per pixel with
+                        // h % add_sh == 0 and w % add_sw == 0, laid out [image][add_ho][add_wo][CI] (rigl_masked_conv2d_bwd_sub)
   uint16_t* DX;         // [M][CI] bf16
   float* SLAB;          // [G][CI][CO] fp32 partial dW (unused with DO_W = false)
   int M, CI, slices, G;
-  uint32_t x_bytes, dy_bytes;
+  uint32_t x_bytes, dy_bytes, add_bytes;
+  int add_sh, add_sw, add_ho, add_wo, IH, IW;
+  FastDiv fd_w, fd_h;
   unsigned long long* TRACE;   // development (-DRIGL_BS_TRACE): [grid][2 waves (0 and 4)][8] s_memtime ticks per phase
 };
 #ifdef RIGL_BS_TRACE
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice(BsArgs P) {
   const int KT_all = (P.M + PX - 1) / PX;
   const int KT = g < KT_all ? (KT_all - g + P.G - 1) / P.G : 0;
   const __amdgpu_buffer_rsrc_t rsrcY = make_rsrc(P.DY, P.dy_bytes), rsrcX = make_rsrc(P.X, P.x_bytes);
-  const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.ADD ? P.ADD : P.DY, P.ADD ? P.x_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.ADD ? P.ADD : P.DY, P.ADD ? P.add_bytes : 0u);
   const bool has_add = P.ADD != nullptr;
   // the two halves of the workgroup: cf = the wave's 32-channel fragment of the slice, par = the parity of the tiles whose dX it
   // computes (and whose DMA it issued); waves w and w + 4 share a SIMD
@@ -125,9 +128,17 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice(BsArgs P) {
       if (DO_W)                                                                                          \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
             rsrcX, (__attribute__((address_space(3))) void*)(st_ + Y_BYTES + (q * 4 + cf) * 1024), 16, off_, 0, 0, 0); \
-      if (has_add)                                                                                       \
+      if (has_add) {                                                                                     \
+        int offa_ = off_;                                                                                \
+        if (P.add_sh) {      /* the addend row of pixel p_ (if it has one: else zeros) */                 \
+          const int t_ = fdiv(p_, P.fd_w), wi_ = p_ - t_ * P.IW, im_ = fdiv(t_, P.fd_h), hi_ = t_ - im_ * P.IH; \
+          const int qh_ = hi_ / P.add_sh, qw_ = wi_ / P.add_sw;                                          \
+          const bool on_ = p_ < P.M && qh_ * P.add_sh == hi_ && qw_ * P.add_sw == wi_;                   \
+          offa_ = on_ ? (int)((uint32_t)(((im_ * P.add_ho + qh_) * P.add_wo + qw_) * P.CI + x_col[q]) * 2u) : (int)OOB; \
+        }                                                                                                \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
-            rsrcA, (__attribute__((address_space(3))) void*)(st_ + Y_BYTES + X_BYTES + (q * 4 + cf) * 1024), 16, off_, 0, 0, 0); \
+            rsrcA, (__attribute__((address_space(3))) void*)(st_ + Y_BYTES + X_BYTES + (q * 4 + cf) * 1024), 16, offa_, 0, 0, 0); \
+      }                                                                                                  \
     }                                                                                                    \
   }
 
@@ -341,7 +352,7 @@ static void launch_bs_i(const BsArgs& a, hipStream_t st) {
 }
 // slab == NULL: dX only (the same bits as with the weight-gradient half)
 static void launch_bs(const RiglConvDesc* d, const BsPlan& p, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
-                      const rigl_bf16* addend, rigl_bf16* dx, float* slab, hipStream_t st) {
+                      const rigl_bf16* addend, rigl_bf16* dx, float* slab, hipStream_t st, int sub_h = 1, int sub_w = 1) {
   BsArgs a = {};
 #ifdef RIGL_BS_TRACE
   { const char* e = getenv("RIGL_BS_TRACE_PTR"); a.TRACE = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr; }
@@ -349,6 +360,12 @@ static void launch_bs(const RiglConvDesc* d, const BsPlan& p, const rigl_bf16* x
   a.X = x; a.DY = dy; a.W = w_hwio; a.ADD = addend; a.DX = dx; a.SLAB = slab;
   a.M = d->n * d->h * d->w; a.CI = d->cin; a.slices = p.slices; a.G = p.G;
   a.x_bytes = (uint32_t)((size_t)a.M * d->cin * 2); a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
+  a.add_bytes = a.x_bytes; a.IH = d->h; a.IW = d->w;
+  if (addend && (sub_h > 1 || sub_w > 1)) {
+    a.add_sh = sub_h; a.add_sw = sub_w; a.add_ho = (d->h + sub_h - 1) / sub_h; a.add_wo = (d->w + sub_w - 1) / sub_w;
+    a.add_bytes = (uint32_t)((size_t)d->n * a.add_ho * a.add_wo * d->cin * 2);
+    a.fd_w = make_fastdiv(d->w); a.fd_h = make_fastdiv(d->h);
+  }
   if (p.co == 256) { if (slab) launch_bs_i<256, true>(a, st); else launch_bs_i<256, false>(a, st); }
   else { if (slab) launch_bs_i<128, true>(a, st); else launch_bs_i<128, false>(a, st); }
 }

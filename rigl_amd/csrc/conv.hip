@@ -1820,11 +1820,12 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
   // The many-input-channel 1x1 layers: the same single pass per 128-channel slice (bwdslice.hpp), one slab per row group
   {
     BsPlan bp;
-    if (whole && !bn && bs_use(d, &bp)) {
+    // (a subsampled addend -- the first block of a group -- rides in the same DMA ring: rows without an addend row read zeros)
+    if (both && !dg && !bn && bs_use(d, &bp)) {
       if (need && (!workspace || workspace_bytes < need))
         return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
       ProfFamily prof(PROF_CONV_BWD);
-      launch_bs(d, bp, x, dy, w_hwio, addend, dx, static_cast<float*>(workspace), st);
+      launch_bs(d, bp, x, dy, w_hwio, addend, dx, static_cast<float*>(workspace), st, sub.sh, sub.sw);
       const int64_t n_out = (int64_t)d->cin * d->cout;
       ReduceArgs ra = {static_cast<const float*>(workspace), dw, n_out, n_out, bp.G};
       launch_wgrad_reduce(ra, st);
