@@ -167,6 +167,9 @@ def main():
                   help='replay ordinary steps from a captured HIP graph (rigl_amd.train.GraphedStep; N = 1 only): for '
                        'launch-bound models such as wrn22.  The K1 timings of `roofline` then come from a few eager '
                        'steps run AFTER the timed region')
+  ap.add_argument('--no-graph', action='store_true',
+                  help='wrn22 replays its ordinary steps from a captured HIP graph by default (launch-bound: 52.7 k -> 80.4 k '
+                       'images/s, profiles/r5); this flag runs it eagerly')
   ap.add_argument('--no-sync', action='store_true',
                   help='N > 1 only: run the step WITHOUT the gradient exchange (replicas diverge; gives the compute-only step '
                        'time that comm_exposed_ms is measured against -- never a headline number)')
@@ -230,6 +233,8 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
+  if args.workload == 'wrn22' and not args.no_graph and args.precision == 'bfloat16':
+    args.graph = True                       # (the measured default of the launch-bound workload)
   graphed = train.GraphedStep(loss_fn, opt, gs) if (args.graph and world == 1) else None
   run_step = graphed if graphed is not None else step
   for i in range(args.warmup):
@@ -379,7 +384,7 @@ def main():
       # stamped with the library build it was collected on.
       traffic = traffic_build = None
       if args.workload == 'resnet50':
-        for rnd in ('r5', 'r4', 'r3', 'r2', 'r1'):
+        for rnd in ('r6', 'r5', 'r4', 'r3', 'r2', 'r1'):
           try:
             with open(os.path.join(ROOT, 'profiles', rnd, 'k1_traffic.json')) as fh:
               tj = json.load(fh)

@@ -10,7 +10,8 @@ timeout 600 python bench.py > $O/bench_n1.json 2>$O/bench_err.txt; echo "bench r
 for w in resnet50_erk99 mobilenet_v1 wrn22; do
   timeout 300 python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2>>$O/bench_err.txt; echo "$w rc=$?" | tee -a $O/log.txt
 done
-timeout 300 python bench.py --workload wrn22 --graph --no-cpu-baseline > $O/bench_wrn22_graph.json 2>>$O/bench_err.txt; echo "wrn22 graph rc=$?" | tee -a $O/log.txt
+# (wrn22 replays a captured HIP graph by default since round 6; the eager line for comparison)
+timeout 300 python bench.py --workload wrn22 --no-graph --no-cpu-baseline > $O/bench_wrn22_eager.json 2>>$O/bench_err.txt; echo "wrn22 eager rc=$?" | tee -a $O/log.txt
 timeout 600 python tools/bench_kernels.py > $O/bench_kernels_per_layer.txt 2>&1; echo "bench_kernels rc=$?" | tee -a $O/log.txt
 if [ "${SKIP_SWEEP:-0}" != "1" ]; then
 timeout 600 python tools/pp_sweep.py --batch 128 --iters 20 --out $O/pp_sweep_b128.json > $O/pp_sweep_b128.txt 2>&1; echo "pp_sweep 128 rc=$?" | tee -a $O/log.txt
@@ -41,6 +42,9 @@ cp $(find $O/mbprof -name "*kernel_stats.csv" | head -1) $O/mobilenet_kernel_sta
 # round 5: the row-streaming body alone (A/B against the bodies it replaces), the per-layer in-step table and the fp32 line
 cd $R
 timeout 400 python tools/rs_bench.py > $O/rs_bench.txt 2>&1; echo "rs_bench rc=$?" | tee -a $O/log.txt
+# round 6: the channel-sliced single-pass backward alone (A/B), where an in-step kernel's time goes relative to alone
+timeout 400 python tools/bs_bench.py > $O/bs_bench.txt 2>&1; echo "bs_bench rc=$?" | tee -a $O/log.txt
+timeout 300 python tools/instep_probe.py > $O/instep_probe.txt 2>&1; echo "instep_probe rc=$?" | tee -a $O/log.txt
 timeout 300 python tools/bench_kernels.py --out $O/bk_warm.json > /dev/null 2>&1
 timeout 300 python tools/bench_kernels.py --cold --out $O/bk_cold.json > /dev/null 2>&1
 timeout 300 python tools/instep_table.py --alone $O/bk_warm.json --cold $O/bk_cold.json --out $O/instep_table.json > $O/instep_table.txt 2>&1; echo "instep rc=$?" | tee -a $O/log.txt
