@@ -676,6 +676,9 @@ int rigl_probe_mfma_bf16(int32_t blocks, int32_t iters, float* sink, rigl_stream
  * RIGL_WGRAD_STREAM, RIGL_CONV_STAGES, RIGL_CONV_W4_KT, RIGL_WGRAD_TR; round 4
  * also measured and did not keep bn_parts / bn_rpl and a side-stream reduce;
  * round 5 replaced x1x1.hpp and its knobs by rowstream.hpp).
+ * Round 6: "bwdslice" (0 = off, 1 = default: the channel-sliced single-pass
+ * backward of the 1x1 / stride-1 layers with cin % 128 == 0 and cout 128 / 256,
+ * bwdslice.hpp).
  * No reference counterpart (the reference selects cuDNN/TPU algorithms inside
  * TensorFlow: rigl/imagenet_resnet/pruning_layers.py:139-157).              */
 int rigl_tune_set(const char* key, int32_t value);
@@ -683,6 +686,11 @@ int32_t rigl_tune_get(const char* key, int32_t dflt);
 /* Back to "never set" (the RIGL_<KEY> environment variable, else the built-in
  * default); rigl_tune_set(key, INT32_MIN) is the same call.                  */
 int rigl_tune_unset(const char* key);
+/* Counts the rigl_tune_set / rigl_tune_unset calls of this process: whoever caches
+ * a plan-dependent answer of the library (rigl_conv2d_stats_parts,
+ * rigl_conv2d_workspace_bytes ...) keys the cache on it -- a knob flipped through
+ * ANY binding then invalidates it (the Python mirror does: ops._plan_cached). */
+uint64_t rigl_tune_generation(void);
 
 #ifdef __cplusplus
 }

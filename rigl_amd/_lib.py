@@ -156,6 +156,7 @@ SIGNATURES = {
     'rigl_probe_mfma_bf16': (C.c_int, [_I32, _I32, _P, _P]),
     'rigl_tune_set': (C.c_int, [C.c_char_p, _I32]),
     'rigl_tune_get': (_I32, [C.c_char_p, _I32]),
+    'rigl_tune_generation': (C.c_uint64, []),
     'rigl_tune_unset': (C.c_int, [C.c_char_p]),
 }
 

@@ -189,6 +189,8 @@ int rigl_tune_unset(const char* key) {
 
 int32_t rigl_tune_get(const char* key, int32_t dflt) { return key ? rigl::tune_get(key, dflt) : dflt; }
 
+uint64_t rigl_tune_generation(void) { return rigl::tune_generation(); }
+
 int rigl_prof_enable(int32_t on) {
   std::lock_guard<std::mutex> l(rigl::g_prof_mu);
   rigl::g_prof_on = on != 0;

@@ -299,13 +299,15 @@ def _count_depthwise(d):
 # Plan-dependent sizes (workspace bytes, statistics parts) are asked of the library once per descriptor AND per knob
 # generation: the C-side answers follow the run-time knobs (a kernel switched on after a layer's first call changes how
 # many partial rows its forward writes; a stale, larger count would leave batch norm summing uninitialised rows).
-_TUNE_GEN = 0
+# The generation is the LIBRARY's (rigl_tune_generation): a knob flipped through any other binding of the same process
+# invalidates the cache too.
 
 
 def _plan_cached(d, name, fn):
+  gen = int(_lib.load().rigl_tune_generation())
   c = getattr(d, '_plan', None)
-  if c is None or c[0] != _TUNE_GEN:
-    c = (_TUNE_GEN, {})
+  if c is None or c[0] != gen:
+    c = (gen, {})
     d._plan = c
   v = c[1].get(name)
   if v is None:
@@ -863,16 +865,12 @@ def softmax_xent(logits, labels, label_smoothing=0.0, grad_scale=None, want_grad
 def tune_set(key, value):
   """Process-wide kernel-selection knob (rigl_tune_set).  The plan-dependent sizes cached on descriptors (_plan_cached)
   are keyed on the knob generation, so a descriptor made before the call asks the library again."""
-  global _TUNE_GEN
   check(_lib.load().rigl_tune_set(key.encode(), int(value)))
-  _TUNE_GEN += 1
 
 
 def tune_unset(key):
   """Back to the knob's RIGL_<KEY> environment variable / built-in default (rigl_tune_unset)."""
-  global _TUNE_GEN
   check(_lib.load().rigl_tune_unset(key.encode()))
-  _TUNE_GEN += 1
 
 
 def tune_get(key, default=-1):
