@@ -21,8 +21,17 @@
 // ds_read_b128 lane group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}) then sit in sixteen different 16-byte bank
 // slots, and the four rows of a transposing 32-lane pass in four different 64-byte bank quarters (256- and 512-byte rows
 // alike: a row is a whole number of 256-byte bank windows).  tools/emu/bs_emu.py restates the index arithmetic per lane.
-// Loop as in bwd1x1.hpp: counted vmcnt on LOADS only, one raw barrier per K-tile, the stores of tile kt at the top of
-// iteration kt + 1, the program order of an iteration's vector-memory operations pinned.
+// Loop: one raw barrier per K-tile; the half that multiplies tile kt waits (counted vmcnt, LOADS only: bwd1x1.hpp) for the
+// pieces it issued three iterations earlier, the other half issues tile kt + 3 and stores dX tile kt - 1.
+// How it got here (gpurun r6a-r6d, 14x14 1024 -> 256 at batch 128, one-call backward alone from HBM, us; the shared-launch
+// bodies it replaces: 71.7): first version -- every wave issues its share of the DMA, stores its piece of the previous dX
+// tile and loads its piece of the addend into registers in every iteration -- 75.4 (phase stamps, -DRIGL_BS_TRACE + tools/
+// bs_trace.py: 30-36 % of a wave's time in the flush, 22-29 % waiting: loads return in order, so waiting for the addend
+// piece requested one iteration ago drains the three-tile DMA queue behind it, and every wave's MFMAs wait behind its own
+// vector-memory issue); addend through the DMA ring and added at staging time + the halves alternating duty: 60.3 (28x28
+// 512 -> 128: 95.0 -> 78.2, 512 -> 256: 126.1 -> 96.8, 56x56 256 -> 128: 170.5 -> 145.7).  The kernel then moves its 198 MB
+// (X, addend, dX, dY, 32 slabs) in ~41 us = 4.8 TB/s of mixed reads and writes: s_setprio for the multiplying half
+// measured level (removed).
 // Reference: the autodiff of layers.masked_conv2d for the bottleneck's first conv (pruning_layers.py:139-157,
 // resnet_model.py:456-470; sparse_optimizers_base.py:478-485 for the dense dW).
 #pragma once
