@@ -691,6 +691,11 @@ int rigl_tune_unset(const char* key);
  * rigl_conv2d_workspace_bytes ...) keys the cache on it -- a knob flipped through
  * ANY binding then invalidates it (the Python mirror does: ops._plan_cached). */
 uint64_t rigl_tune_generation(void);
+/* The address of that counter (valid for the life of the process; read it as a
+ * volatile uint64): a binding that checks it on every call -- launch-bound models
+ * make hundreds of cached-plan lookups per step -- reads memory instead of
+ * crossing the FFI.                                                           */
+const volatile uint64_t* rigl_tune_generation_addr(void);
 
 #ifdef __cplusplus
 }

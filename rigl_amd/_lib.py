@@ -157,6 +157,7 @@ SIGNATURES = {
     'rigl_tune_set': (C.c_int, [C.c_char_p, _I32]),
     'rigl_tune_get': (_I32, [C.c_char_p, _I32]),
     'rigl_tune_generation': (C.c_uint64, []),
+    'rigl_tune_generation_addr': (C.c_void_p, []),
     'rigl_tune_unset': (C.c_int, [C.c_char_p]),
 }
 

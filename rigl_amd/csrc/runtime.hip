@@ -190,6 +190,10 @@ int rigl_tune_unset(const char* key) {
 int32_t rigl_tune_get(const char* key, int32_t dflt) { return key ? rigl::tune_get(key, dflt) : dflt; }
 
 uint64_t rigl_tune_generation(void) { return rigl::tune_generation(); }
+const volatile uint64_t* rigl_tune_generation_addr(void) {
+  static_assert(sizeof(rigl::g_tune_gen) == sizeof(uint64_t), "the counter is a plain 64-bit word");
+  return reinterpret_cast<const volatile uint64_t*>(&rigl::g_tune_gen);
+}
 
 int rigl_prof_enable(int32_t on) {
   std::lock_guard<std::mutex> l(rigl::g_prof_mu);

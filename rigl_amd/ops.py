@@ -303,8 +303,14 @@ def _count_depthwise(d):
 # invalidates the cache too.
 
 
+_GEN_WORD = None      # the library's counter, read in place (a ctypes call per lookup cost the launch-bound wrn22 step 0.5 ms)
+
+
 def _plan_cached(d, name, fn):
-  gen = int(_lib.load().rigl_tune_generation())
+  global _GEN_WORD
+  if _GEN_WORD is None:
+    _GEN_WORD = C.c_uint64.from_address(_lib.load().rigl_tune_generation_addr())
+  gen = _GEN_WORD.value
   c = getattr(d, '_plan', None)
   if c is None or c[0] != gen:
     c = (gen, {})
