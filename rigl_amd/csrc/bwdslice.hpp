@@ -69,7 +69,11 @@ __device__ __forceinline__ uint32_t bs_add_bf16x2(uint32_t a, uint32_t b) {
 
 template <int CO, bool DO_W>
 struct BsGeom {
-  static constexpr int SC = 128, PX = 32, NST = 4;             // (NST - 1 odd: the half that issues a tile is the half that multiplies it)
+#ifndef RIGL_BS_NST128
+#define RIGL_BS_NST128 4   // (5 -- four 24 KB tiles in flight -- measured level in the step and 3 us slower alone: 77.5 -> 80.4 us)
+#endif
+  static constexpr int SC = 128, PX = 32;
+  static constexpr int NST = CO == 128 ? RIGL_BS_NST128 : 4;   // ring depth
   static constexpr int YROWB = CO * 2, XROWB = SC * 2;
   static constexpr int Y_BYTES = PX * YROWB, X_BYTES = DO_W ? PX * XROWB : 0, A_BYTES = PX * XROWB;
   static constexpr int STAGE = Y_BYTES + X_BYTES + A_BYTES;    // dY rows, the X slice, the slice of the shortcut gradient
@@ -201,15 +205,19 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice(BsArgs P) {
   unsigned long long tr_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
   unsigned long long tr_last = __builtin_amdgcn_s_memtime();
 #endif
-  // prologue: tile t comes from the half with par = t & 1
-  if (par == 0) { if (0 < KT) BS_ISSUE(0, 0); if (2 < KT) BS_ISSUE(2, 2); }
-  else { if (1 < KT) BS_ISSUE(1, 1); }
+  // Tile t is issued NST - 1 iterations before it is multiplied, by the half that is NOT multiplying then: half
+  // (t + NST) & 1.  Prologue: the first NST - 1 tiles, each by its half.
+  constexpr int ISS = NST & 1;              // par of the half that issues the even tiles
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t)
+    if (((t & 1) ^ ISS) == par && t < KT) BS_ISSUE(t, t);
   BS_STAMP(7);
   for (int kt = 0; kt < KT; ++kt) {
     const bool mine = (kt & 1) == par;
-    if (mine) {
-      // this half issued tile kt three iterations ago; the only LOADS behind it are the pieces of tile kt + 2 (stores are not
-      // counted on: bwd1x1.hpp)
+    if ((((kt & 1) ^ ISS) == par)) {
+      // this half issued tile kt; the only LOADS it has issued behind it are the pieces of tile kt + 2 (NST <= 5; stores are
+      // not counted on: bwd1x1.hpp)
+      static_assert(NST == 4 || NST == 5, "one younger tile of the same half in flight behind the awaited one");
       if (kt + 2 < KT) { if (has_add) wait_vmcnt<PW_A>(); else wait_vmcnt<PW_N>(); }
       else wait_vmcnt<0>();
     }

@@ -62,7 +62,7 @@ def run_workgroup(block, X, DY, W, ADD, DX, SLAB, M, CI, CO, slices, G, NST, do_
 
   def issue(kt, stage, par):
     """the four waves of half `par` bring in tile kt"""
-    assert (kt & 1) == par, "a tile is issued by the half that multiplies it"
+    assert ((kt & 1) ^ (NST & 1)) == par, "tile t is issued by half (t + NST) & 1: the half not multiplying NST - 1 iterations earlier"
     p0 = (g + kt * G) * PX
     for cf in range(4):
       for q in range(YPW):
@@ -115,12 +115,9 @@ def run_workgroup(block, X, DY, W, ADD, DX, SLAB, M, CI, CO, slices, G, NST, do_
           assert np.all(np.isnan(DX[p, slice_ * SC + ch * 8:slice_ * SC + ch * 8 + 8])), "written twice"
           DX[p, slice_ * SC + ch * 8:slice_ * SC + ch * 8 + 8] = v
 
-  if 0 < KT:
-    issue(0, 0, 0)
-  if 2 < KT:
-    issue(2, 2, 0)
-  if 1 < KT:
-    issue(1, 1, 1)
+  for t in range(NST - 1):
+    if t < KT:
+      issue(t, t, (t & 1) ^ (NST & 1))
   for kt in range(KT):
     Ys = (kt % NST) * STAGE
     Xs = Ys + Y_BYTES
@@ -221,5 +218,5 @@ if __name__ == "__main__":
   for co in (128, 256):
     bank_check(co)
   check(8 * 8 * 32 + 40, 256, 256, 8, 4)
-  check(8 * 5 * 32 - 7, 128, 128, 8, 4, add=False)
-  check(16 * 3 * 32, 256, 128, 16, 4)
+  check(8 * 5 * 32 - 7, 128, 128, 8, 5, add=False)
+  check(16 * 3 * 32, 256, 128, 16, 5)
