@@ -58,7 +58,15 @@ struct Geom {
   int tpr, rpb;       // threads per row (pow2 >= min(cg,256)), rows per pass
   int parts;          // row partitions (= gridDim.x of the reduction kernels)
   int64_t rows_per_part;
+  int fixed;          // apply passes: the grid stride is a multiple of the channel groups, so a thread sees ONE channel group in
+                      // every iteration and keeps its per-channel parameters in registers (no LDS copy of all C channels per
+                      // workgroup: at C = 2048 that copy was 56 KB -- two workgroups per CU -- and 3.5x the bytes the workgroup streams)
 };
+
+__device__ __forceinline__ void ld8f(const float* __restrict__ p, float (&o)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
 
 // Reduction over rows of up to two per-channel quantities.
 //   MODE 0 (fwd stats): q0 = sum x, q1 = sum x^2
@@ -225,20 +233,31 @@ template <bool RELU, bool HAS_RES>
 __global__ __launch_bounds__(THREADS) void k_fwd_apply(Geom G, const uint16_t* __restrict__ x, const uint16_t* __restrict__ res,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         uint16_t* __restrict__ y, uint8_t* __restrict__ mbits) {
-  extern __shared__ __attribute__((aligned(16))) float prm[];   // [2][C]
-  for (int i = threadIdx.x; i < G.C; i += THREADS) { prm[i] = scale[i]; prm[G.C + i] = shift[i]; }
-  __syncthreads();
+  extern __shared__ __attribute__((aligned(16))) float prm[];   // [2][C] (unused when G.fixed)
+  const bool fixed = G.fixed != 0;
+  float psc[8], psh[8];
+  if (fixed) {
+    const int c0 = (int)(((int64_t)blockIdx.x * THREADS + threadIdx.x) % G.cg) * 8;
+    ld8f(scale + c0, psc); ld8f(shift + c0, psh);
+  } else {
+    for (int i = threadIdx.x; i < G.C; i += THREADS) { prm[i] = scale[i]; prm[G.C + i] = shift[i]; }
+    __syncthreads();
+  }
   const int64_t total = G.M * G.cg;
   const int64_t stride = (int64_t)gridDim.x * THREADS;
   for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += stride) {
-    const int cgi = (int)(i % G.cg);
+    if (!fixed) {
+      const int cgi = (int)(i % G.cg);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { psc[j] = prm[cgi * 8 + j]; psh[j] = prm[G.C + cgi * 8 + j]; }
+    }
     float xv[8], rv[8];
     unpack8(ld16(x + i * 8, G.nt), xv);
     if (HAS_RES) unpack8(ld16(res + i * 8, G.nt), rv);
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float v = fmaf(xv[j], prm[cgi * 8 + j], prm[G.C + cgi * 8 + j]);
+      float v = fmaf(xv[j], psc[j], psh[j]);
       if (HAS_RES) v += rv[j];
       o[j] = RELU ? fmaxf(v, 0.f) : v;
     }
@@ -279,17 +298,34 @@ __global__ __launch_bounds__(THREADS) void k_bwd_apply(Geom G, const uint16_t* _
                                                         const float* __restrict__ invstd, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, const float* __restrict__ coef,
                                                         uint16_t* __restrict__ dx, uint16_t* __restrict__ dres) {
-  extern __shared__ __attribute__((aligned(16))) float prm[];   // [7][C]: mean, invstd, a, b, c, scale, shift
-  for (int i = threadIdx.x; i < G.C; i += THREADS) {
-    prm[i] = mean[i]; prm[G.C + i] = invstd[i];
-    prm[2 * G.C + i] = coef[i]; prm[3 * G.C + i] = coef[G.C + i]; prm[4 * G.C + i] = coef[2 * G.C + i];
-    if (RELU && MSK == 0) { prm[5 * G.C + i] = scale[i]; prm[6 * G.C + i] = shift[i]; }
+  extern __shared__ __attribute__((aligned(16))) float prm[];   // [7][C]: mean, invstd, a, b, c, scale, shift (unused when G.fixed)
+  const bool fixed = G.fixed != 0;
+  float pm[8], pis[8], pa[8], pb[8], pc[8], psc[8], psh[8];
+  if (fixed) {
+    const int c0 = (int)(((int64_t)blockIdx.x * THREADS + threadIdx.x) % G.cg) * 8;
+    ld8f(mean + c0, pm); ld8f(invstd + c0, pis);
+    ld8f(coef + c0, pa); ld8f(coef + G.C + c0, pb); ld8f(coef + 2 * G.C + c0, pc);
+    if (RELU && MSK == 0) { ld8f(scale + c0, psc); ld8f(shift + c0, psh); }
+  } else {
+    for (int i = threadIdx.x; i < G.C; i += THREADS) {
+      prm[i] = mean[i]; prm[G.C + i] = invstd[i];
+      prm[2 * G.C + i] = coef[i]; prm[3 * G.C + i] = coef[G.C + i]; prm[4 * G.C + i] = coef[2 * G.C + i];
+      if (RELU && MSK == 0) { prm[5 * G.C + i] = scale[i]; prm[6 * G.C + i] = shift[i]; }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int64_t total = G.M * G.cg;
   const int64_t stride = (int64_t)gridDim.x * THREADS;
   for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += stride) {
-    const int c0 = (int)(i % G.cg) * 8;
+    if (!fixed) {
+      const int c0 = (int)(i % G.cg) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pm[j] = prm[c0 + j]; pis[j] = prm[G.C + c0 + j]; pa[j] = prm[2 * G.C + c0 + j]; pb[j] = prm[3 * G.C + c0 + j];
+        pc[j] = prm[4 * G.C + c0 + j];
+        if (RELU && MSK == 0) { psc[j] = prm[5 * G.C + c0 + j]; psh[j] = prm[6 * G.C + c0 + j]; }
+      }
+    }
     float xv[8], dv[8], yv[8];
     unpack8(ld16(x + i * 8, G.nt), xv);
     unpack8(ld16(dy + i * 8, G.nt), dv);
@@ -300,11 +336,10 @@ __global__ __launch_bounds__(THREADS) void k_bwd_apply(Geom G, const uint16_t* _
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       bool on = true;
-      if (RELU) on = MSK == 1 ? (yv[j] > 0.f) : (MSK == 2 ? ((mb >> j) & 1u) != 0u
-                                                           : (fmaf(xv[j], prm[5 * G.C + c0 + j], prm[6 * G.C + c0 + j]) > 0.f));
+      if (RELU) on = MSK == 1 ? (yv[j] > 0.f) : (MSK == 2 ? ((mb >> j) & 1u) != 0u : (fmaf(xv[j], psc[j], psh[j]) > 0.f));
       const float dz = on ? dv[j] : 0.f;
-      const float xh = (xv[j] - prm[c0 + j]) * prm[G.C + c0 + j];
-      o[j] = prm[2 * G.C + c0 + j] * (dz - prm[3 * G.C + c0 + j] - xh * prm[4 * G.C + c0 + j]);
+      const float xh = (xv[j] - pm[j]) * pis[j];
+      o[j] = pa[j] * (dz - pb[j] - xh * pc[j]);
       z[j] = dz;
     }
     uint4 out;
@@ -331,15 +366,26 @@ __global__ __launch_bounds__(THREADS) void k_fwd_apply_pair(Geom G, const uint16
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ scale2, const float* __restrict__ shift2,
                                                              uint16_t* __restrict__ y, uint8_t* __restrict__ mbits) {
-  extern __shared__ __attribute__((aligned(16))) float prm[];   // [4][C]
-  for (int i = threadIdx.x; i < G.C; i += THREADS) {
-    prm[i] = scale[i]; prm[G.C + i] = shift[i]; prm[2 * G.C + i] = scale2[i]; prm[3 * G.C + i] = shift2[i];
+  extern __shared__ __attribute__((aligned(16))) float prm[];   // [4][C] (unused when G.fixed)
+  const bool fixed = G.fixed != 0;
+  float p0[8], p1[8], p2[8], p3[8];           // scale, shift, scale2, shift2 of this thread's eight channels
+  if (fixed) {
+    const int c0 = (int)(((int64_t)blockIdx.x * THREADS + threadIdx.x) % G.cg) * 8;
+    ld8f(scale + c0, p0); ld8f(shift + c0, p1); ld8f(scale2 + c0, p2); ld8f(shift2 + c0, p3);
+  } else {
+    for (int i = threadIdx.x; i < G.C; i += THREADS) {
+      prm[i] = scale[i]; prm[G.C + i] = shift[i]; prm[2 * G.C + i] = scale2[i]; prm[3 * G.C + i] = shift2[i];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int64_t total = G.M * G.cg;
   const int64_t stride = (int64_t)gridDim.x * THREADS;
   for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += stride) {
-    const int c0 = (int)(i % G.cg) * 8;
+    if (!fixed) {
+      const int c0 = (int)(i % G.cg) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { p0[j] = prm[c0 + j]; p1[j] = prm[G.C + c0 + j]; p2[j] = prm[2 * G.C + c0 + j]; p3[j] = prm[3 * G.C + c0 + j]; }
+    }
     float xv[8], rv[8];
     unpack8(ld16(x + i * 8, G.nt), xv);
     unpack8(ld16(x2 + i * 8, G.nt), rv);
@@ -347,10 +393,9 @@ __global__ __launch_bounds__(THREADS) void k_fwd_apply_pair(Geom G, const uint16
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
       // the shortcut as its own batch norm would have stored it
-      const uint32_t pk = pack2(fmaf(rv[j], prm[2 * G.C + c0 + j], prm[3 * G.C + c0 + j]),
-                                fmaf(rv[j + 1], prm[2 * G.C + c0 + j + 1], prm[3 * G.C + c0 + j + 1]));
-      float v0 = fmaf(xv[j], prm[c0 + j], prm[G.C + c0 + j]);
-      float v1 = fmaf(xv[j + 1], prm[c0 + j + 1], prm[G.C + c0 + j + 1]);
+      const uint32_t pk = pack2(fmaf(rv[j], p2[j], p3[j]), fmaf(rv[j + 1], p2[j + 1], p3[j + 1]));
+      float v0 = fmaf(xv[j], p0[j], p1[j]);
+      float v1 = fmaf(xv[j + 1], p0[j + 1], p1[j + 1]);
       v0 += bf_lo(pk); v1 += bf_hi(pk);
       o[j] = RELU ? fmaxf(v0, 0.f) : v0;
       o[j + 1] = RELU ? fmaxf(v1, 0.f) : v1;
@@ -451,18 +496,32 @@ __global__ __launch_bounds__(THREADS) void k_bwd_apply_pair(Geom G, const uint16
                                                              const float* __restrict__ mean2, const float* __restrict__ invstd2,
                                                              const float* __restrict__ coef, const float* __restrict__ coef2,
                                                              uint16_t* __restrict__ dx, uint16_t* __restrict__ dx2) {
-  extern __shared__ __attribute__((aligned(16))) float prm[];   // [10][C]: mean, invstd, a, b, c of either side
-  for (int i = threadIdx.x; i < G.C; i += THREADS) {
-    prm[i] = mean[i]; prm[G.C + i] = invstd[i];
-    prm[2 * G.C + i] = coef[i]; prm[3 * G.C + i] = coef[G.C + i]; prm[4 * G.C + i] = coef[2 * G.C + i];
-    prm[5 * G.C + i] = mean2[i]; prm[6 * G.C + i] = invstd2[i];
-    prm[7 * G.C + i] = coef2[i]; prm[8 * G.C + i] = coef2[G.C + i]; prm[9 * G.C + i] = coef2[2 * G.C + i];
+  extern __shared__ __attribute__((aligned(16))) float prm[];   // [10][C]: mean, invstd, a, b, c of either side (unused when G.fixed)
+  const bool fixed = G.fixed != 0;
+  float q[10][8];
+  if (fixed) {
+    const int c0 = (int)(((int64_t)blockIdx.x * THREADS + threadIdx.x) % G.cg) * 8;
+    ld8f(mean + c0, q[0]); ld8f(invstd + c0, q[1]); ld8f(coef + c0, q[2]); ld8f(coef + G.C + c0, q[3]); ld8f(coef + 2 * G.C + c0, q[4]);
+    ld8f(mean2 + c0, q[5]); ld8f(invstd2 + c0, q[6]); ld8f(coef2 + c0, q[7]); ld8f(coef2 + G.C + c0, q[8]); ld8f(coef2 + 2 * G.C + c0, q[9]);
+  } else {
+    for (int i = threadIdx.x; i < G.C; i += THREADS) {
+      prm[i] = mean[i]; prm[G.C + i] = invstd[i];
+      prm[2 * G.C + i] = coef[i]; prm[3 * G.C + i] = coef[G.C + i]; prm[4 * G.C + i] = coef[2 * G.C + i];
+      prm[5 * G.C + i] = mean2[i]; prm[6 * G.C + i] = invstd2[i];
+      prm[7 * G.C + i] = coef2[i]; prm[8 * G.C + i] = coef2[G.C + i]; prm[9 * G.C + i] = coef2[2 * G.C + i];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int64_t total = G.M * G.cg;
   const int64_t stride = (int64_t)gridDim.x * THREADS;
   for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += stride) {
-    const int c0 = (int)(i % G.cg) * 8;
+    if (!fixed) {
+      const int c0 = (int)(i % G.cg) * 8;
+#pragma unroll
+      for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[k][j] = prm[k * G.C + c0 + j];
+    }
     float xv[8], x2v[8], dv[8];
     unpack8(ld16(x + i * 8, G.nt), xv);
     unpack8(ld16(x2 + i * 8, G.nt), x2v);
@@ -472,10 +531,10 @@ __global__ __launch_bounds__(THREADS) void k_bwd_apply_pair(Geom G, const uint16
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float dz = ((mb >> j) & 1u) != 0u ? dv[j] : 0.f;
-      const float xh = (xv[j] - prm[c0 + j]) * prm[G.C + c0 + j];
-      o[j] = prm[2 * G.C + c0 + j] * (dz - prm[3 * G.C + c0 + j] - xh * prm[4 * G.C + c0 + j]);
-      const float xh2 = (x2v[j] - prm[5 * G.C + c0 + j]) * prm[6 * G.C + c0 + j];
-      o2[j] = prm[7 * G.C + c0 + j] * (dz - prm[8 * G.C + c0 + j] - xh2 * prm[9 * G.C + c0 + j]);
+      const float xh = (xv[j] - q[0][j]) * q[1][j];
+      o[j] = q[2][j] * (dz - q[3][j] - xh * q[4][j]);
+      const float xh2 = (x2v[j] - q[5][j]) * q[6][j];
+      o2[j] = q[7][j] * (dz - q[8][j] - xh2 * q[9][j]);
     }
     uint4 out;
     out.x = pack2(o[0], o[1]); out.y = pack2(o[2], o[3]); out.z = pack2(o[4], o[5]); out.w = pack2(o[6], o[7]);
@@ -490,6 +549,7 @@ static Geom make_geom(int64_t m, int c) {
   // measured in the ResNet-50 step (round 3): 0 -> 2 = -0.06 .. -0.10 ms, the convs gain too (less of their L2 evicted)
   g.nt = (int64_t)m * c * 2 >= (int64_t)RIGL_TUNE("bn_nt_mb", 0) * (1 << 20) ? RIGL_TUNE("bn_nt", 2) : 0;
   g.il = RIGL_TUNE("bn_il", 1);
+  g.fixed = 0;
   g.M = m; g.C = c; g.cg = c / 8;
   int tpr = 1;
   while (tpr < g.cg && tpr < THREADS) tpr <<= 1;
@@ -507,7 +567,8 @@ static Geom make_geom(int64_t m, int c) {
   return g;
 }
 
-static unsigned apply_grid(const Geom& g) {
+// (sets g.fixed: see Geom)
+static unsigned apply_grid(Geom& g) {
 // Grid of the element-wise apply passes: 2 x 16 B per thread, at most 16384 workgroups (4 per thread / 4096
 // measured 0.8 % slower in the ResNet-50 step: more, shorter workgroups drain the tail of these streams sooner).
 #ifndef RIGL_BN_APPLY_PER_THREAD
@@ -519,6 +580,7 @@ static unsigned apply_grid(const Geom& g) {
   int64_t b = (g.M * g.cg + THREADS * RIGL_BN_APPLY_PER_THREAD - 1) / (THREADS * RIGL_BN_APPLY_PER_THREAD);
   if (b > RIGL_BN_APPLY_CAP) b = RIGL_BN_APPLY_CAP;
   if (b < 1) b = 1;
+  g.fixed = (RIGL_TUNE("bn_regs", 1) != 0 && (b * THREADS) % g.cg == 0) ? 1 : 0;
   return (unsigned)b;
 }
 
@@ -596,8 +658,8 @@ int rigl_bn_fwd_stats(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16*
   int rc = fwd_statistics(g, c, x, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
                           save_scale, save_shift, stats, stats_parts, workspace, workspace_bytes, st);
   if (rc) return rc;
-  const size_t lds = (size_t)2 * c * 4;
   dim3 agrid(apply_grid(g));
+  const size_t lds = g.fixed ? 0 : (size_t)2 * c * 4;
   if (relu && residual) hipLaunchKernelGGL((k_fwd_apply<true, true>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y, relu_bits);
   else if (relu) hipLaunchKernelGGL((k_fwd_apply<true, false>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y, relu_bits);
   else if (residual) hipLaunchKernelGGL((k_fwd_apply<false, true>), agrid, dim3(THREADS), lds, st, g, x, residual, save_scale, save_shift, y, nullptr);
@@ -651,8 +713,8 @@ int rigl_bn_add_bn_fwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16
   int rc = fwd_statistics(g, c, x, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
                           save_scale, save_shift, stats, stats_parts, workspace, workspace_bytes, st);
   if (rc) return rc;
-  const size_t lds = (size_t)4 * c * 4;
   dim3 agrid(apply_grid(g));
+  const size_t lds = g.fixed ? 0 : (size_t)4 * c * 4;
   if (relu) hipLaunchKernelGGL(k_fwd_apply_pair<true>, agrid, dim3(THREADS), lds, st, g, x, x2, save_scale, save_shift, scale2, shift2, y, relu_bits);
   else hipLaunchKernelGGL(k_fwd_apply_pair<false>, agrid, dim3(THREADS), lds, st, g, x, x2, save_scale, save_shift, scale2, shift2, y, nullptr);
   RIGL_CHECK_LAUNCH("rigl_bn_add_bn_fwd");
@@ -694,7 +756,8 @@ int rigl_bn_add_bn_bwd(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16
   const FinSet f0 = {partial, gamma, save_invstd, dgamma, dbeta, coef};
   const FinSet f1 = {partial2, gamma2, save_invstd2, dgamma2, dbeta2, coef2};
   hipLaunchKernelGGL(k_bwd_finalize_pair<16>, dim3((unsigned)((c + 15) / 16), 2), dim3(THREADS), 0, st, g, f0, f1);
-  hipLaunchKernelGGL(k_bwd_apply_pair, dim3(apply_grid(g)), dim3(THREADS), lds, st, g, x, x2, relu_bits, dy, save_mean, save_invstd,
+  const dim3 pgrid(apply_grid(g));
+  hipLaunchKernelGGL(k_bwd_apply_pair, pgrid, dim3(THREADS), g.fixed ? 0 : lds, st, g, x, x2, relu_bits, dy, save_mean, save_invstd,
                      save_mean2, save_invstd2, coef, coef2, dx, dx2);
   RIGL_CHECK_LAUNCH("rigl_bn_add_bn_bwd");
   return RIGL_OK;
@@ -743,8 +806,8 @@ int rigl_bn_bwd_stats(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16*
   else
     hipLaunchKernelGGL(k_bwd_finalize<16>, dim3((unsigned)((c + 15) / 16)), dim3(THREADS), 0, st, g, red, gamma,
                        save_invstd, dgamma, dbeta, coef);
-  const size_t lds = (size_t)7 * c * 4;
   dim3 agrid(apply_grid(g));
+  const size_t lds = g.fixed ? 0 : (size_t)7 * c * 4;
 #define RIGL_BWD_APPLY(R, K, D) hipLaunchKernelGGL((k_bwd_apply<R, K, D>), agrid, dim3(THREADS), lds, st, g, x, y, relu_bits, dy, save_mean, save_invstd, save_scale, save_shift, coef, dx, dresidual)
   const bool dres = dresidual != nullptr;
   if (!relu) { if (dres) RIGL_BWD_APPLY(false, 0, true); else RIGL_BWD_APPLY(false, 0, false); }
