@@ -558,7 +558,8 @@ static Geom make_geom(int64_t m, int c) {
 #define RIGL_BN_ROWS_PER_LANE 8    // 16 left the 14x14 layers with 196 workgroups for 256 CUs (19.9 -> 18.1 us)
 #endif
   int64_t parts = (m + (int64_t)g.rpb * RIGL_BN_ROWS_PER_LANE - 1) / ((int64_t)g.rpb * RIGL_BN_ROWS_PER_LANE);   // rows per row-lane
-  if (parts > MAX_PARTS) parts = MAX_PARTS;
+  const int64_t cap = RIGL_TUNE("bn_max_parts", MAX_PARTS);
+  if (parts > cap) parts = cap;
   if (parts < 1) parts = 1;
   int64_t rpp = (m + parts - 1) / parts;
   rpp = (rpp + g.rpb - 1) / g.rpb * g.rpb;
@@ -800,7 +801,7 @@ int rigl_bn_bwd_stats(int64_t m, int32_t c, const rigl_bf16* x, const rigl_bf16*
     else RIGL_BWD_REDUCE(true, 0);
 #undef RIGL_BWD_REDUCE
   }
-  if (g.parts > MAX_PARTS)      // only a dgrad epilogue leaves more partial rows than k_reduce's cap (<16> is 0.7 us faster below it)
+  if (g.parts > MAX_PARTS)      // (more partial rows than 512: a dgrad epilogue's, or a raised "bn_max_parts"; <16> is 0.7 us faster below it)
     hipLaunchKernelGGL(k_bwd_finalize<4>, dim3((unsigned)((c + 3) / 4)), dim3(THREADS), 0, st, g, red, gamma,
                        save_invstd, dgamma, dbeta, coef);
   else

@@ -341,3 +341,39 @@ def test_bottleneck_with_projection_shortcut_fused_equals_unfused():
   assert torch.equal(y1.view(torch.int16), y0.view(torch.int16))
   assert torch.equal(dx1.view(torch.int16), dx0.view(torch.int16))
   assert torch.equal(G1, G0)
+
+
+@pytest.mark.parametrize('shape', [(4, 14, 14, 1024), (2, 7, 7, 2048), (8, 28, 28, 128), (33, 3, 3, 40)])
+def test_apply_passes_parameters_in_registers_equal_the_lds_copy(shape):
+  """Round 6: the apply passes keep a thread's per-channel parameters in registers where the grid stride is a multiple of
+  the channel groups ("bn_regs", default on) instead of staging all C channels' parameters in LDS per workgroup.  Same
+  arithmetic on the same values: every output of the forward (+ residual + ReLU + bits), the backward (dx, dres) and the
+  two-batch-norm pair must have the bits of the LDS path (resnet_model.py:41-82, 456-501 through autodiff)."""
+  from rigl_amd import ops
+  gen = torch.Generator(device=DEV).manual_seed(sum(shape))
+  c = shape[-1]
+  x = (torch.randn(shape, generator=gen, device=DEV) * 1.7 + 0.3).to(torch.bfloat16)
+  x2 = torch.randn(shape, generator=gen, device=DEV).to(torch.bfloat16)
+  dy = torch.randn(shape, generator=gen, device=DEV).to(torch.bfloat16)
+  gamma = torch.rand(c, generator=gen, device=DEV) + 0.5
+  beta = torch.randn(c, generator=gen, device=DEV) * 0.2
+  outs = []
+  try:
+    for regs in (1, 0):
+      ops.tune_set('bn_regs', regs)
+      rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+      y, saved, bits = ops.bn_fwd(x, gamma, beta, rm, rv, 0.1, 1e-5, True, x2, want_relu_bits=True)
+      dg, db = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+      dx, dres = ops.bn_bwd(x, None, dy, gamma, saved, True, dg, db, want_dres=True, relu_bits=bits)
+      y0, saved0 = ops.bn_fwd(x, gamma, beta, rm.clone(), rv.clone(), 0.1, 1e-5, True, None)
+      dx0, _ = ops.bn_bwd(x, None, dy, gamma, saved0, True, dg, db, want_dres=False)
+      rm2, rv2 = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+      saved2 = ops.bn_statistics(x2, gamma, beta, rm2, rv2, 0.1, 1e-5)
+      yp, savedp, bitsp = ops.bn_add_bn_fwd(x, x2, saved2, gamma, beta, rm.clone(), rv.clone(), 0.1, 1e-5, True)
+      dgp, dbp, dgp2, dbp2 = (torch.empty(c, device=DEV) for _ in range(4))
+      dxp, dxp2 = ops.bn_add_bn_bwd(x, x2, bitsp, dy, gamma, savedp, gamma, saved2, dgp, dbp, dgp2, dbp2)
+      outs.append([t.clone() for t in (y, bits, dx, dres, y0, dx0, yp, bitsp, dxp, dxp2)])
+  finally:
+    ops.tune_unset('bn_regs')
+  for a, b in zip(*outs):
+    assert torch.equal(a.view(torch.uint8) if a.dtype != torch.uint8 else a, b.view(torch.uint8) if b.dtype != torch.uint8 else b)
