@@ -720,13 +720,15 @@ static PPPlan plan_pp(const IgemmArgs& a) {
 // Forward layers whose tiles would occupy at most half of the CUs (the 7x7 layers at batch 128: 98 tiles) split the
 // reduction in two ("pp_ksplit" = 0: never).  Measured at batch 128 (forward alone, us): 7x7x512 3x3 52.4 -> 43.5 (565 -> 681
 // TFLOP/s), its stride-2 sibling 50.9 -> 42.9, 2048->512 1x1 (32 K-tiles) 26.9 -> 28.5 -- the 256 KB hand-off per tile
-// (write-through stores, drained before the ticket; the partner's read) costs ~8 us, so only reductions of >= 32 K-tiles
-// split ("pp_ksplit_min_kt"; round 6: 48 -> 32 brings the 7x7 2048 -> 512 forwards in, conv_fwd 1.955 -> 1.938 ms per step; 16: level).  Forward only: a layer's dX must have the same bits from the stand-alone dgrad and from the shared backward
+// (write-through stores, drained before the ticket; the partner's read) costs ~8 us, so only reductions of >= 48 K-tiles
+// split ("pp_ksplit_min_kt"; round 6 measured 32: the 7x7 2048 -> 512 forwards join, conv_fwd -0.015 ms per step -- but the
+// 14x14 3x3 layer at HALF the batch (98 tiles, 36 K-tiles) then splits while the full batch does not, and a layer's bits would
+// depend on the batch size: tests/test_fullsize_properties_gpu.py; 48 stays).  Forward only: a layer's dX must have the same bits from the stand-alone dgrad and from the shared backward
 // launch, which does not split (its weight-gradient workgroups already fill the chip).
 static inline bool pp_ksplit_ok(const IgemmArgs& a, const PPPlan& p) {
   if (!p.variant || RIGL_TUNE("pp_ksplit", 1) == 0) return false;
   const int kt = a.KH * a.KW * (a.Cred / 64);
-  return 2 * (int64_t)p.grid <= (int64_t)num_cus() && kt >= RIGL_TUNE("pp_ksplit_min_kt", 32);
+  return 2 * (int64_t)p.grid <= (int64_t)num_cus() && kt >= RIGL_TUNE("pp_ksplit_min_kt", 48);
 }
 
 template <int MODE>
