@@ -304,7 +304,8 @@ int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x,
  * such a descriptor) and handed over compact: a quarter of the bytes written and
  * read, and none of the strided dgrad's zero rows.  dX is bit-identical to
  * rigl_masked_conv2d_bwd fed the same gradient scattered into a zero tensor.
- * Runs on the implicit-GEMM body whatever the layer (the only epilogue with this
+ * Runs on the implicit-GEMM body (or, round 6, the channel-sliced single-pass
+ * backward where that is the layer's kernel: the only bodies with this
  * addressing); sub_h = sub_w = 1 is rigl_masked_conv2d_bwd.                    */
 /* The other half of that hand-over: the backward of a STRIDED 1x1 conv without
  * padding (ho = ceil(h / stride_h), wo likewise) with dX on the conv's own grid:
@@ -321,6 +322,21 @@ int rigl_masked_conv2d_bwd_sub(const RiglConvDesc* d, const rigl_bf16* x,
                                const rigl_bf16* addend, int32_t sub_h, int32_t sub_w,
                                float* dw, rigl_bf16* dx, void* workspace,
                                size_t workspace_bytes, rigl_stream_t stream);
+/* rigl_masked_conv2d_bwd whose addend arrives UNMASKED with a 1-bit-per-element
+ * mask (addend_bits: [n*h*w][cin / 8] bytes, bit j of a byte = channel 8 b + j;
+ * set = the addend counts there): dx = bf16(bf16(dgrad) + (bit ? addend : 0)).
+ * Replaces the tf.where / relu-gradient op that masks the shortcut's gradient of
+ * relu(bn3 + shortcut) (rigl/imagenet_resnet/resnet_model.py:497-501 through
+ * autodiff): the batch norm's backward hands its output gradient over as it is,
+ * with the ReLU bits its forward left, and never writes the masked copy.  Only for
+ * the layers rigl_conv2d_bwd_takes_masked_addend says 1 for (the channel-sliced
+ * single-pass backward, bwdslice.hpp); RIGL_EUNSUPPORTED otherwise.            */
+int32_t rigl_conv2d_bwd_takes_masked_addend(const RiglConvDesc* d);
+int rigl_masked_conv2d_bwd_masked(const RiglConvDesc* d, const rigl_bf16* x,
+                                  const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                                  const rigl_bf16* addend, const uint8_t* addend_bits,
+                                  float* dw, rigl_bf16* dx, void* workspace,
+                                  size_t workspace_bytes, rigl_stream_t stream);
 
 /* rigl_masked_conv2d_bwd with the BATCH-NORM BACKWARD REDUCTIONS of the
  * tensor dX is the gradient of riding in the dgrad epilogue.  In the reference every

@@ -113,6 +113,8 @@ SIGNATURES = {
     'rigl_masked_conv2d_bwd_bn': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ,
                                             C.POINTER(BnReduceFuse), _P]),
     'rigl_masked_conv2d_bwd': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    'rigl_masked_conv2d_bwd_masked': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    'rigl_conv2d_bwd_takes_masked_addend': (_I32, [C.POINTER(ConvDesc)]),
     'rigl_masked_conv2d_bwd_grid': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'rigl_masked_conv2d_bwd_sub': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _SZ, _P]),
     'rigl_masked_conv2d_wgrad': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P,

@@ -42,6 +42,9 @@ struct BsArgs {
   const uint16_t* W;    // [CI][CO] bf16 (the HWIO shadow of a 1x1 kernel)
   const uint16_t* ADD;  // [M][CI] bf16 or NULL; with add_sh > 0 the gradient of a SUBSAMPLED view: one row per pixel with
                         // h % add_sh == 0 and w % add_sw == 0, laid out [image][add_ho][add_wo][CI] (rigl_masked_conv2d_bwd_sub)
+  const uint8_t* ABITS; // or NULL: 1 bit per element of ADD ([M][CI / 8] bytes, bit j of a byte = channel 8 b + j): the addend
+                        // counts only where its bit is set -- the shortcut gradient handed over UNMASKED with the ReLU bits of
+                        // relu(bn3 + shortcut) (rigl_masked_conv2d_bwd_masked: the masked copy is never written)
   uint16_t* DX;         // [M][CI] bf16
   float* SLAB;          // [G][CI][CO] fp32 partial dW (unused with DO_W = false)
   int M, CI, slices, G;
@@ -76,7 +79,8 @@ struct BsGeom {
   static constexpr int NST = CO == 128 ? RIGL_BS_NST128 : 4;   // ring depth
   static constexpr int YROWB = CO * 2, XROWB = SC * 2;
   static constexpr int Y_BYTES = PX * YROWB, X_BYTES = DO_W ? PX * XROWB : 0, A_BYTES = PX * XROWB;
-  static constexpr int STAGE = Y_BYTES + X_BYTES + A_BYTES;    // dY rows, the X slice, the slice of the shortcut gradient
+  static constexpr int B_BYTES = PX * SC / 8;                  // the ReLU bits of the shortcut-gradient slice (16 bytes per row)
+  static constexpr int STAGE = Y_BYTES + X_BYTES + A_BYTES + B_BYTES;   // dY rows, the X slice, the slice of the shortcut gradient (+ bits)
   static constexpr int DXROWB = XROWB + 8, DX_BYTES = PX * DXROWB;     // 8 bytes of padding: conflict-free ds_write_b64 (rowstream.hpp)
   static constexpr int SMEM = NST * STAGE + 2 * DX_BYTES;
 };
@@ -107,7 +111,9 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice(BsArgs P) {
   const int KT = g < KT_all ? (KT_all - g + P.G - 1) / P.G : 0;
   const __amdgpu_buffer_rsrc_t rsrcY = make_rsrc(P.DY, P.dy_bytes), rsrcX = make_rsrc(P.X, P.x_bytes);
   const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.ADD ? P.ADD : P.DY, P.ADD ? P.add_bytes : 0u);
-  const bool has_add = P.ADD != nullptr;
+  const bool has_add = P.ADD != nullptr, has_bits = P.ABITS != nullptr;
+  const __amdgpu_buffer_rsrc_t rsrcB = make_rsrc(has_bits ? (const void*)P.ABITS : (const void*)P.DY, has_bits ? P.add_bytes / 16u : 0u);
+  constexpr int A_BYTES = G::A_BYTES;
   // the two halves of the workgroup: cf = the wave's 32-channel fragment of the slice, par = the parity of the tiles whose dX it
   // computes (and whose DMA it issued); waves w and w + 4 share a SIMD
   const int cf = wave & 3, par = wave >> 2;
@@ -152,6 +158,12 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice(BsArgs P) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
             rsrcA, (__attribute__((address_space(3))) void*)(st_ + Y_BYTES + X_BYTES + (q * 4 + cf) * 1024), 16, offa_, 0, 0, 0); \
       }                                                                                                  \
+    }                                                                                                    \
+    if (has_bits && cf < 2) {      /* 32 rows x 16 bytes of ReLU bits: two wave-instructions of 4 bytes per lane */ \
+      const int ib_ = cf * 64 + lane, p_ = p0_ + (ib_ >> 2);                                             \
+      const int offb_ = p_ < P.M ? (int)(((uint32_t)(p_ * P.CI + slice * SC) >> 3) + (uint32_t)((ib_ & 3) * 4)) : (int)OOB; \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                          \
+          rsrcB, (__attribute__((address_space(3))) void*)(st_ + Y_BYTES + X_BYTES + A_BYTES + cf * 256), 4, offb_, 0, 0, 0); \
     }                                                                                                    \
   }
 
@@ -248,6 +260,16 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice(BsArgs P) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           av[q] = *reinterpret_cast<const uint2*>(As + r31 * XROWB + (((cf * 4 + q) ^ d_swz) << 4) + hi * 8);
+        if (has_bits) {
+          // byte q of this word = the bits of channels cf * 32 + 8 q ..: this lane's four are bits 4 hi .. 4 hi + 3
+          const uint32_t bw = *reinterpret_cast<const uint32_t*>(As + A_BYTES + r31 * 16 + cf * 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t nib = (bw >> (8 * q + 4 * hi)) & 0xFu;
+            av[q].x &= ((nib & 1u) ? 0x0000FFFFu : 0u) | ((nib & 2u) ? 0xFFFF0000u : 0u);
+            av[q].y &= ((nib & 4u) ? 0x0000FFFFu : 0u) | ((nib & 8u) ? 0xFFFF0000u : 0u);
+          }
+        }
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) a0[e] = a1[e] = 0.f;
@@ -369,12 +391,14 @@ static void launch_bs_i(const BsArgs& a, hipStream_t st) {
 }
 // slab == NULL: dX only (the same bits as with the weight-gradient half)
 static void launch_bs(const RiglConvDesc* d, const BsPlan& p, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
-                      const rigl_bf16* addend, rigl_bf16* dx, float* slab, hipStream_t st, int sub_h = 1, int sub_w = 1) {
+                      const rigl_bf16* addend, rigl_bf16* dx, float* slab, hipStream_t st, int sub_h = 1, int sub_w = 1,
+                      const uint8_t* addend_bits = nullptr) {
   BsArgs a = {};
 #ifdef RIGL_BS_TRACE
   { const char* e = getenv("RIGL_BS_TRACE_PTR"); a.TRACE = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr; }
 #endif
   a.X = x; a.DY = dy; a.W = w_hwio; a.ADD = addend; a.DX = dx; a.SLAB = slab;
+  a.ABITS = addend ? addend_bits : nullptr;
   a.M = d->n * d->h * d->w; a.CI = d->cin; a.slices = p.slices; a.G = p.G;
   a.x_bytes = (uint32_t)((size_t)a.M * d->cin * 2); a.dy_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
   a.add_bytes = a.x_bytes; a.IH = d->h; a.IW = d->w;

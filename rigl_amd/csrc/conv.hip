@@ -1765,7 +1765,7 @@ int rigl_masked_conv2d_wgrad(const RiglConvDesc* d, const rigl_bf16* x, const ri
 static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
                     const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
                     const RiglBnReduceFuse* bn, rigl_stream_t stream, AddendSub sub = {1, 1},
-                    const RiglConvDesc* dg = nullptr);
+                    const RiglConvDesc* dg = nullptr, const uint8_t* addend_bits = nullptr);
 
 // rigl_masked_conv2d_bwd with the batch-norm backward reductions of the tensor dX is the gradient of riding in the dgrad
 // epilogue.
@@ -1778,7 +1778,8 @@ int rigl_masked_conv2d_bwd_bn(const RiglConvDesc* d, const rigl_bf16* x, const r
 
 static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
                     const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
-                    const RiglBnReduceFuse* bn, rigl_stream_t stream, AddendSub sub, const RiglConvDesc* dg) {
+                    const RiglBnReduceFuse* bn, rigl_stream_t stream, AddendSub sub, const RiglConvDesc* dg,
+                    const uint8_t* addend_bits) {
   // dg (rigl_masked_conv2d_bwd_grid): the dgrad half runs on THIS descriptor -- the stride-1 twin of a strided 1x1 conv
   // on its own output grid -- while the weight gradient reads x through d; the two halves of the shared launch take
   // their geometry from separate argument blocks anyway.
@@ -1825,7 +1826,7 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
       if (need && (!workspace || workspace_bytes < need))
         return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_bwd: workspace %zu < %zu", workspace_bytes, need);
       ProfFamily prof(PROF_CONV_BWD);
-      launch_bs(d, bp, x, dy, w_hwio, addend, dx, static_cast<float*>(workspace), st, sub.sh, sub.sw);
+      launch_bs(d, bp, x, dy, w_hwio, addend, dx, static_cast<float*>(workspace), st, sub.sh, sub.sw, addend_bits);
       const int64_t n_out = (int64_t)d->cin * d->cout;
       ReduceArgs ra = {static_cast<const float*>(workspace), dw, n_out, n_out, bp.G};
       launch_wgrad_reduce(ra, st);
@@ -1833,6 +1834,7 @@ static int bwd_impl(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* 
       return RIGL_OK;
     }
   }
+  if (addend_bits) return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_bwd_masked: this layer's kernels take no masked addend (ask rigl_conv2d_bwd_takes_masked_addend)");
   // Layers whose dgrad streams rows (rowstream.hpp): the weight gradient with its stand-alone plan, then the dgrad -- two
   // launches (+ reduce) instead of the shared one
   {
@@ -1947,6 +1949,23 @@ int rigl_masked_conv2d_bwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl
                            const rigl_bf16* addend, float* dw, rigl_bf16* dx, void* workspace, size_t workspace_bytes,
                            rigl_stream_t stream) {
   return bwd_impl(d, x, dy, w_hwio, addend, dw, dx, workspace, workspace_bytes, nullptr, stream);
+}
+
+// rigl_masked_conv2d_bwd whose addend arrives UNMASKED together with a 1-bit-per-element mask (bit set = the addend counts):
+// the gradient of relu(bn3 + shortcut) w.r.t. the shortcut is the block output's gradient where the ReLU was on
+// (resnet_model.py:497-501), so the batch norm's backward need not write that masked copy -- its consumer, the dgrad
+// epilogue of the block's first conv, masks on the fly.  Only the layers of rigl_conv2d_bwd_takes_masked_addend.
+int32_t rigl_conv2d_bwd_takes_masked_addend(const RiglConvDesc* d) {
+  using namespace rigl;
+  using namespace rigl::k1;
+  if (!d || check_desc(d, "rigl_conv2d_bwd_takes_masked_addend")) return 0;
+  return bs_use(d) ? 1 : 0;
+}
+int rigl_masked_conv2d_bwd_masked(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* dy, const rigl_bf16* w_hwio,
+                                  const rigl_bf16* addend, const uint8_t* addend_bits, float* dw, rigl_bf16* dx,
+                                  void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+  if (!addend || !addend_bits || !dx) return rigl::fail(RIGL_EINVAL, "rigl_masked_conv2d_bwd_masked: addend, addend_bits and dx are required");
+  return bwd_impl(d, x, dy, w_hwio, addend, dw, dx, workspace, workspace_bytes, nullptr, stream, AddendSub{1, 1}, nullptr, addend_bits);
 }
 
 // rigl_masked_conv2d_bwd whose addend is the gradient of a SUBSAMPLED view of the conv's input: [n][ceil(h / sub_h)][ceil(w /

@@ -423,7 +423,18 @@ def dgrad_stats_parts(d):
   return v
 
 
-def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None, bn_fuse=None, addend_sub=None):
+# A shortcut gradient handed over UNMASKED: data_ptr of the gradient tensor -> the 1-bit ReLU mask it still has to pass
+# (left by workloads.nn._FusedBNFn.backward, taken by pruning_layers._MaskedConvForkFn.backward one autograd node later).
+LAZY_ADDEND_BITS = {}
+
+
+def conv_bwd_takes_masked_addend(d):
+  """Does this layer's one-call backward take its addend unmasked + a 1-bit mask (rigl_masked_conv2d_bwd_masked)?"""
+  return bool(_plan_cached(d, 'masked_addend', lambda: int(_lib.load().rigl_conv2d_bwd_takes_masked_addend(C.byref(d)))))
+
+
+def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None, bn_fuse=None, addend_sub=None,
+             addend_bits=None):
   """dW (into ``dw``, dense fp32) and -- when ``need_dx`` -- dX (+ ``addend``) of one conv with a single host
   transition and, for ordinary layers, a single launch (rigl_masked_conv2d_bwd) followed by the split-K reduce that
   completes dW.  ``on_dw_ready`` is called once dW's last kernel has been enqueued (the data-parallel exchange launches
@@ -435,6 +446,25 @@ def conv_bwd(d, x, dy, w_hwio, dw, need_dx=True, addend=None, on_dw_ready=None, 
   [n, ceil(h / sh), ceil(w / sw), cin] -- added at those pixels only (rigl_masked_conv2d_bwd_sub)."""
   if addend_sub is not None and tuple(addend_sub) == (1, 1):
     addend_sub = None
+  if addend_bits is not None:
+    # ``addend_bits`` (uint8, one bit per element of ``addend``): the addend counts only where its bit is set
+    if addend is None or not need_dx or bn_fuse is not None or addend_sub is not None or not conv_bwd_takes_masked_addend(d):
+      raise ValueError('addend_bits needs an addend, dX and a layer whose backward takes a masked addend')
+    _req(x, torch.bfloat16, 'x'); _req(dy, torch.bfloat16, 'dy'); _req(dw, torch.float32, 'dw')
+    _req(addend, torch.bfloat16, 'addend'); _req(addend_bits, torch.uint8, 'addend_bits'); _req(w_hwio, torch.bfloat16, 'w_hwio')
+    if addend.numel() != d.n * d.h * d.w * d.cin or addend_bits.numel() * 8 != addend.numel():
+      raise ValueError('addend must have the shape of dx and addend_bits one bit per element of it')
+    lib = _lib.load()
+    _count_macs('wgrad_macs', d)
+    _count_macs('dgrad_macs', d)
+    need = _plan_cached(d, 'ws_wgrad', lambda: lib.rigl_conv2d_workspace_bytes(C.byref(d), 2))
+    ws = workspace(need, x.device, 'wg') if need else None
+    dx = torch.empty((d.n, d.h, d.w, d.cin), dtype=torch.bfloat16, device=dy.device)
+    check(lib.rigl_masked_conv2d_bwd_masked(C.byref(d), _ptr(x), _ptr(dy), _ptr(w_hwio), _ptr(addend), _ptr(addend_bits), _ptr(dw),
+                                            _ptr(dx), _ptr(ws), ws.numel() if ws is not None else 0, _stream()))
+    if on_dw_ready is not None:
+      on_dw_ready()
+    return dx
   if addend_sub is not None:
     if addend is None or not need_dx or bn_fuse is not None:
       raise ValueError('addend_sub needs an addend and dX, and does not combine with bn_fuse')

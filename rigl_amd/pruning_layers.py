@@ -164,6 +164,12 @@ class _MaskedConvForkFn(torch.autograd.Function):
       dx = ops.conv_bwd_f32(d, x, dy, lv.weights.data.view(-1), _mask_bits(lv), lv.weights.grad.view(-1),
                             need_dx=True, addend=dalias, on_dw_ready=ready)
       return dx, None, None, None, None
+    # the alias' gradient may arrive unmasked with the ReLU bits it still has to pass (workloads.nn._FusedBNFn, lazy_res_grad)
+    lazy = ops.LAZY_ADDEND_BITS.pop(dalias.data_ptr(), None) if dalias is not None else None
+    if lazy is not None:
+      dx = ops.conv_bwd(d, x, dy, lv.hwio, lv.weights.grad.view(-1), need_dx=True, addend=dalias, addend_bits=lazy[0],
+                        on_dw_ready=ready)
+      return dx, None, None, None, None
     # dx = this conv's dgrad + the alias' gradient is the COMPLETE gradient of the forked tensor: the producing batch
     # norm's reductions are taken on it
     req = _bn_fuse_request(ctx.bn_holder, True)
@@ -322,6 +328,14 @@ class MaskedConv2d(_Layer):
     if part.numel():
       y.bn_partials = part
     return y
+
+  def takes_masked_addend(self, x):
+    """Can the gradient of ``fork(x)``'s alias be handed to this conv unmasked with a 1-bit mask (rigl_masked_conv2d_bwd_masked)?
+    Only then may the alias' other consumer (relu(bn3 + alias)) skip writing the masked gradient."""
+    if not (self.need_input_grad and x.requires_grad and x.dtype == torch.bfloat16 and x.dim() == 4) or _BN_FUSE_BWD:
+      return False
+    n, h, w, _ = x.shape
+    return ops.conv_bwd_takes_masked_addend(self.desc_for(n, h, w))
 
   def fork(self, x, bn_stats=False):
     """Returns (conv(x), x'): use x' for x's other consumer and its gradient

@@ -52,18 +52,22 @@ class _BnBwdHolder:
     self.attached = 0
 
 
+_LAZY_RES_GRAD = os.environ.get('RIGL_LAZY_RES_GRAD', '1') != '0'
+
+
 class _FusedBNFn(torch.autograd.Function):
   """y = relu?(bn(x) (+ residual)) through rigl_bn_fwd / rigl_bn_bwd.  The
   parameter gradients go straight into the gradient arena (overwrite), like
   the conv kernels' dW; autograd only routes dx (and the residual's grad)."""
 
   @staticmethod
-  def forward(ctx, x, residual, bn, relu, partials=None, holder=None):
+  def forward(ctx, x, residual, bn, relu, partials=None, holder=None, lazy_res_grad=False):
     from rigl_amd import ops  # pylint: disable=import-outside-toplevel
     x = x.contiguous()
     res = residual.contiguous() if residual is not None else None
     ctx.bn, ctx.relu, ctx.has_res = bn, relu, res is not None
     ctx.holder = holder
+    ctx.lazy_res_grad = bool(lazy_res_grad) and relu and res is not None
     # the ReLU mask of relu(bn + residual) is kept as 1 bit per element (the backward would
     # otherwise re-read the whole output twice); without a residual it is recomputed from x
     if relu and res is not None:
@@ -96,11 +100,18 @@ class _FusedBNFn(torch.autograd.Function):
       if h.partials is not None and h.dx_ptr == dy.data_ptr():
         part = h.partials
       h.partials = h.x = h.saved = h.bits = None
+    if ctx.lazy_res_grad and bits is not None and ctx.needs_input_grad[1]:
+      # the residual's consumer (the block's first conv, pruning_layers._MaskedConvForkFn) masks on the fly: its gradient is
+      # dy where the ReLU was on, so dy itself travels with the ReLU bits and the masked copy is never written
+      dx, _ = ops.bn_bwd(x, None, dy, bn.gamma.data, saved, ctx.relu, bn.gamma.grad, bn.beta.grad, want_dres=False,
+                         relu_bits=bits, partials=part)
+      ops.LAZY_ADDEND_BITS[dy.data_ptr()] = (bits, dy)
+      return dx, dy, None, None, None, None, None
     dx, dres = ops.bn_bwd(x, None, dy, bn.gamma.data, saved, ctx.relu,
                           bn.gamma.grad, bn.beta.grad,
                           want_dres=ctx.has_res and ctx.needs_input_grad[1],
                           relu_bits=bits, partials=part)
-    return dx, dres, None, None, None, None
+    return dx, dres, None, None, None, None, None
 
 
 class _BnAddBnFn(torch.autograd.Function):
@@ -170,14 +181,16 @@ class BatchNorm:
     self.scope = scope
     graph.modules[scope] = self          # creation order = TF's batch_normalization_<k> numbering
 
-  def __call__(self, x, is_training=True, relu=False, residual=None):
+  def __call__(self, x, is_training=True, relu=False, residual=None, lazy_res_grad=False):
+    """``lazy_res_grad``: the residual's ONLY other consumer is a masked conv whose backward takes its addend unmasked with
+    the ReLU bits (conv.takes_masked_addend): the backward then hands the output gradient itself to it."""
     if (self.fused and is_training and x.is_cuda and self.channels % 8 == 0
         and x.dtype == torch.bfloat16):
       partials = getattr(x, 'bn_partials', None)   # left by the producing conv's epilogue
       if not x.requires_grad:
         x = x.detach().requires_grad_(True)
       holder = _BnBwdHolder(relu)
-      y = _FusedBNFn.apply(x, residual, self, relu, partials, holder)
+      y = _FusedBNFn.apply(x, residual, self, relu, partials, holder, lazy_res_grad and _LAZY_RES_GRAD)
       y.bn_ctx = holder                            # a masked conv that is this tensor's only consumer picks it up
       return y
     y = F.batch_norm(nchw_view(x), self.moving_mean, self.moving_variance,

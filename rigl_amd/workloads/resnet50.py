@@ -52,6 +52,9 @@ class _ConvFixedPadding:
   def fork(self, x, bn_stats=True):
     return self.conv.fork(x, bn_stats)
 
+  def takes_masked_addend(self, x):
+    return self.conv.takes_masked_addend(x)
+
 
 class _Bottleneck:
   """bottleneck_block_ (resnet_model.py:396-501)."""
@@ -76,6 +79,7 @@ class _Bottleneck:
       # (a strided projection and conv1 as one autograd node: the projection's input gradient stays on its own grid)
       p, y = PL.conv_pair(self.proj.conv, self.c1.conv, x, bn_stats=True)
     else:
+      lazy = self.c1.takes_masked_addend(x)      # (the shortcut's gradient then reaches conv1 unmasked + the ReLU bits)
       y, shortcut = self.c1.fork(x)
     y = self.bn1(y, is_training, relu=True)
     y = self.bn2(self.c2(y), is_training, relu=True)
@@ -83,7 +87,7 @@ class _Bottleneck:
       # relu(bn3(conv3) + bn_proj(projection)) in one piece: neither the normalised shortcut nor the masked gradient
       # between the two batch norms is written
       return gnn.bn_add_bn_relu(self.bn3, self.c3(y), self.proj_bn, p, is_training)
-    return self.bn3(self.c3(y), is_training, relu=True, residual=shortcut)   # relu(bn3 + shortcut)
+    return self.bn3(self.c3(y), is_training, relu=True, residual=shortcut, lazy_res_grad=lazy)   # relu(bn3 + shortcut)
 
 
 class ResNet50:

@@ -258,6 +258,18 @@ def run_case(case, seed, check_bwd_call=True, check_stats=True):
     dw2 = torch.empty_like(dw1)
     ops.conv_bwd(d, x, dy, hwio, dw2, need_dx=has_dx, addend=add if has_dx else None)
     assert torch.equal(dw1.view(torch.int32), dw2.view(torch.int32)), 'bwd.dw not deterministic'
+    if has_dx and ops.conv_bwd_takes_masked_addend(d):
+      # the addend handed over unmasked with a 1-bit mask (rigl_masked_conv2d_bwd_masked): exactly dgrad + (bit ? addend : 0)
+      m01 = torch.rand(add.numel(), generator=g, device=DEV) < 0.4
+      abits = torch.zeros(add.numel() // 8, dtype=torch.uint8, device=DEV)
+      for j in range(8):
+        abits |= (m01.view(-1, 8)[:, j].to(torch.uint8) << j)
+      dw5 = torch.empty_like(dw1)
+      dx5 = ops.conv_bwd(d, x, dy, hwio, dw5, need_dx=True, addend=add, addend_bits=abits)
+      want5 = dx + torch.where(m01.view(add.shape), add, torch.zeros_like(add))
+      assert torch.equal(dx5.view(torch.int16), want5.view(torch.int16)), 'bwd_masked.dx != dgrad + masked addend'
+      assert torch.equal(dw5.view(torch.int32), dw1.view(torch.int32)), 'bwd_masked.dw != bwd.dw'
+      del dx5, dw5, want5, abits, m01
     if has_dx:
       # the addend as the gradient of a SUBSAMPLED view (rigl_masked_conv2d_bwd_sub): added at the pixels (2i, 2j) only.
       # That call runs on the implicit-GEMM body whatever the layer's default kernel, so its dgrad is taken from the same
