@@ -20,7 +20,7 @@
 // its 16-byte chunks are XORed with ((row & 3) << 2) | ((row >> 2) & 3) on the DMA's source side: the sixteen rows of a
 // ds_read_b128 lane group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}) then sit in sixteen different 16-byte bank
 // slots, and the four rows of a transposing 32-lane pass in four different 64-byte bank quarters (256- and 512-byte rows
-// alike: a row is a whole number of 256-byte bank windows).  tools/emu/bs_emu.py restates the index arithmetic per lane.
+// alike: a row is a whole number of 256-byte bank windows).  tools/experiments/emu/bs_emu.py restates the index arithmetic per lane.
 // Loop: one raw barrier per K-tile; the half that multiplies tile kt waits (counted vmcnt, LOADS only: bwd1x1.hpp) for the
 // pieces it issued three iterations earlier, the other half issues tile kt + 3 and stores dX tile kt - 1.
 // How it got here (gpurun r6a-r6d, 14x14 1024 -> 256 at batch 128, one-call backward alone from HBM, us; the shared-launch

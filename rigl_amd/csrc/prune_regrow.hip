@@ -16,7 +16,6 @@
 
 #include <string.h>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.hpp"
 
@@ -738,7 +737,6 @@ struct ExportDev {
   uint32_t* m2;
   unsigned long long* keys1;
   unsigned long long* keys2;
-  int32_t* idx;
 };
 __global__ __launch_bounds__(BLOCK) void k_export(const LayerDev* __restrict__ Ls, const LayerState* __restrict__ St,
                                                   const uint32_t* __restrict__ tie_cnt, const uint32_t* __restrict__ tie_off,
@@ -783,7 +781,6 @@ __global__ __launch_bounds__(BLOCK) void k_export(const LayerDev* __restrict__ L
           const int64_t e = q[j].e0 + v;
           ex.keys1[e] = ((unsigned long long)((m1[j] >> v) & 1u) << 32) | key1[j][v];
           ex.keys2[e] = ((unsigned long long)((in2 >> v) & 1u) << 32) | key2[j][v];
-          ex.idx[e] = (int32_t)e;
         }
       }
     }
@@ -974,12 +971,94 @@ int rigl_prune_regrow(const RiglPruneRegrowLayer* layers, int32_t n_layers, cons
 }
 
 // ---- the two selections, read back -------------------------------------------------------------------------------------
-static size_t sel_sort_temp_bytes(int64_t n) {
-  size_t t = 0;
-  (void)rocprim::radix_sort_pairs_desc(nullptr, t, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int32_t*)nullptr,
-                                       (int32_t*)nullptr, (size_t)n, 0, 33, (hipStream_t)0);
-  return t;
+// The ordered index lists come from a small STABLE descending LSD radix sort written here (8-bit digits, five passes over
+// the 33-bit keys): an inspection path, not a hot one -- a workgroup counts the digits of its 2048-element chunk, one
+// workgroup turns the [digit][chunk] counts into offsets (digit 255 first), and in the scatter thread d walks the chunk in
+// index order and places the entries whose digit is d: chunk order and in-chunk order are kept, which is the stability
+// tf.nn.top_k's "equal scores by lower index" needs (sparse_optimizers_base.py:293-318).
+}  // extern "C"
+namespace rigl {
+namespace k2 {
+constexpr int SORT_CH = 2048;
+constexpr int SORT_B = 256;
+
+__global__ __launch_bounds__(SORT_B) void k_sort_hist(const unsigned long long* __restrict__ keys, int64_t n, int shift,
+                                                      uint32_t* __restrict__ hist, uint32_t nblocks) {
+  __shared__ uint32_t h[SORT_B];
+  h[threadIdx.x] = 0u;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * SORT_CH;
+  for (int i = threadIdx.x; i < SORT_CH; i += SORT_B)
+    if (base + i < n) atomicAdd(&h[(uint32_t)(keys[base + i] >> shift) & 255u], 1u);
+  __syncthreads();
+  hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
+
+// counts -> exclusive offsets, in the order (digit 255, chunk 0), (255, 1), ... (254, 0), ...; one workgroup
+__global__ __launch_bounds__(1024) void k_sort_scan(uint32_t* __restrict__ hist, uint32_t nblocks) {
+  __shared__ uint32_t part[1024];
+  const uint32_t total = (uint32_t)SORT_B * nblocks;
+  const uint32_t per = (total + 1023u) / 1024u;
+  const uint32_t lo = min(threadIdx.x * per, total), hi = min(lo + per, total);
+  auto at = [&](uint32_t p) { return (size_t)(255u - p / nblocks) * nblocks + p % nblocks; };
+  uint32_t s = 0u;
+  for (uint32_t p = lo; p < hi; ++p) s += hist[at(p)];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0u;
+    for (int i = 0; i < 1024; ++i) { const uint32_t t = part[i]; part[i] = run; run += t; }
+  }
+  __syncthreads();
+  uint32_t run = part[threadIdx.x];
+  for (uint32_t p = lo; p < hi; ++p) { const size_t a = at(p); const uint32_t c = hist[a]; hist[a] = run; run += c; }
+}
+
+// idx_in == NULL: the payload of entry e is e itself (the first pass)
+__global__ __launch_bounds__(SORT_B) void k_sort_scatter(const unsigned long long* __restrict__ keys_in, const int32_t* __restrict__ idx_in,
+                                                         unsigned long long* __restrict__ keys_out, int32_t* __restrict__ idx_out,
+                                                         int64_t n, int shift, const uint32_t* __restrict__ offs, uint32_t nblocks) {
+  __shared__ uint8_t dig[SORT_CH];
+  const int64_t base = (int64_t)blockIdx.x * SORT_CH;
+  const int cnt = (int)((n - base) < (int64_t)SORT_CH ? (n - base) : (int64_t)SORT_CH);
+  for (int i = threadIdx.x; i < cnt; i += SORT_B) dig[i] = (uint8_t)((keys_in[base + i] >> shift) & 255u);
+  __syncthreads();
+  uint32_t o = offs[(size_t)threadIdx.x * nblocks + blockIdx.x];
+  const uint8_t mine = (uint8_t)threadIdx.x;
+  for (int i = 0; i < cnt; ++i) {
+    if (dig[i] == mine) {
+      keys_out[o] = keys_in[base + i];
+      idx_out[o] = idx_in ? idx_in[base + i] : (int32_t)(base + i);
+      ++o;
+    }
+  }
+}
+
+static inline uint32_t sort_blocks(int64_t n) { return (uint32_t)((n + SORT_CH - 1) / SORT_CH); }
+static inline size_t sort_temp_bytes(int64_t n) { return align_up((size_t)n * 4, 256) + (size_t)SORT_B * sort_blocks(n) * 4; }
+
+// keys (consumed) -> out_idx; ko: n keys, ia: n indices, temp: sort_temp_bytes(n)
+static void sort_desc_stable(unsigned long long* keys, unsigned long long* ko, int32_t* ia, char* temp, int32_t* out_idx, int64_t n,
+                             hipStream_t st) {
+  int32_t* ib = reinterpret_cast<int32_t*>(temp);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(temp + align_up((size_t)n * 4, 256));
+  const uint32_t nb = sort_blocks(n);
+  unsigned long long* kin = keys;
+  unsigned long long* kout = ko;
+  const int32_t* iin = nullptr;
+  for (int pass = 0; pass < 5; ++pass) {                       // 5 x 8 bits >= the 33 bits of a key
+    int32_t* iout = pass == 4 ? out_idx : ((pass & 1) ? ib : ia);
+    hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(SORT_B), 0, st, kin, n, 8 * pass, hist, nb);
+    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, st, hist, nb);
+    hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(SORT_B), 0, st, kin, iin, kout, iout, n, 8 * pass, hist, nb);
+    iin = iout;
+    unsigned long long* t = kin; kin = kout; kout = t;
+  }
+}
+}  // namespace k2
+}  // namespace rigl
+extern "C" {
+
 struct SelLayout { size_t k2ws, keys1, keys2, keys_out, idx, temp, total; };
 static SelLayout sel_layout(int64_t n) {
   SelLayout l;
@@ -988,7 +1067,7 @@ static SelLayout sel_layout(int64_t n) {
   l.k2ws = take(rigl::k2::make_layout(&n, 1).total);
   l.keys1 = take((size_t)n * 8); l.keys2 = take((size_t)n * 8); l.keys_out = take((size_t)n * 8);
   l.idx = take((size_t)n * 4);
-  l.temp = take(sel_sort_temp_bytes(n));
+  l.temp = take(rigl::k2::sort_temp_bytes(n));
   l.total = off;
   return l;
 }
@@ -1008,11 +1087,10 @@ int rigl_prune_regrow_selections(const RiglPruneRegrowLayer* layer, const RiglPr
     return rigl::fail(RIGL_EWORKSPACE, "rigl_prune_regrow_selections: workspace %zu < required %zu", workspace_bytes, lo.total);
   char* base = static_cast<char*>(workspace);
   hipStream_t st = rigl::as_stream(stream);
-  rigl::k2::ExportDev ex = {out_mask1_bits, out_mask2_bits, nullptr, nullptr, nullptr};
+  rigl::k2::ExportDev ex = {out_mask1_bits, out_mask2_bits, nullptr, nullptr};
   if (out_idx1) {
     ex.keys1 = reinterpret_cast<unsigned long long*>(base + lo.keys1);
     ex.keys2 = reinterpret_cast<unsigned long long*>(base + lo.keys2);
-    ex.idx = reinterpret_cast<int32_t*>(base + lo.idx);
   }
   rigl::k2::Params p;
   p.drop_fraction = params->drop_fraction; p.grow_init_mode = params->grow_init_mode; p.grow_init_div = params->grow_init_div;
@@ -1021,10 +1099,11 @@ int rigl_prune_regrow_selections(const RiglPruneRegrowLayer* layer, const RiglPr
   int rc = rigl::k2::run(layer, 1, nullptr, p, true, nullptr, out_counts, base + lo.k2ws, lo.total - lo.k2ws, st, &ex);
   if (rc || !out_idx1) return rc;
   // stable descending sort of (selected, key): selected entries first, larger score first, equal scores by lower index
-  size_t tb = sel_sort_temp_bytes(layer->n);
   unsigned long long* ko = reinterpret_cast<unsigned long long*>(base + lo.keys_out);
-  RIGL_HIP(rocprim::radix_sort_pairs_desc(base + lo.temp, tb, ex.keys1, ko, ex.idx, out_idx1, (size_t)layer->n, 0, 33, st));
-  RIGL_HIP(rocprim::radix_sort_pairs_desc(base + lo.temp, tb, ex.keys2, ko, ex.idx, out_idx2, (size_t)layer->n, 0, 33, st));
+  int32_t* ia = reinterpret_cast<int32_t*>(base + lo.idx);
+  rigl::k2::sort_desc_stable(ex.keys1, ko, ia, base + lo.temp, out_idx1, layer->n, st);
+  rigl::k2::sort_desc_stable(ex.keys2, ko, ia, base + lo.temp, out_idx2, layer->n, st);
+  RIGL_CHECK_LAUNCH("rigl_prune_regrow_selections");
   return RIGL_OK;
 }
 
