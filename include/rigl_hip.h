@@ -264,6 +264,28 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x,
                                  float* stats, size_t stats_floats,
                                  void* workspace, size_t workspace_bytes,
                                  rigl_stream_t stream);
+/* y = conv(relu(bn(x_pre)), mask*W) with the batch norm's APPLY pass done on
+ * the conv's operand load (the reference runs batch_norm_relu between every
+ * two convs, resnet_model.py:41-82,456-470: conv2 -> bn -> relu -> conv3):
+ * x_pre = the pre-batch-norm tensor (the previous conv's output), scale_shift
+ * = [2][cin] fp32, the per-channel scale = gamma * invstd and shift = beta -
+ * mean * scale (rows 2-3 of rigl_bn_fwd_statistics' outputs, contiguous).
+ * Every operand element becomes bf16(max(fma(x, scale, shift), 0)) -- the
+ * rounding points of rigl_bn_fwd(relu = 1) -- in registers; a_out (bf16, the
+ * shape of x_pre) receives that activated tensor as a side output (the
+ * backward's weight-gradient operand and ReLU mask), so the separate apply
+ * pass (read x_pre, write a_out) is not run.  y, a_out and the statistics
+ * parts are bit-identical to rigl_bn_fwd + rigl_masked_conv2d_fwd_stats.
+ * Only where rigl_conv2d_fwd_takes_bn_input(d) == 1 (1x1 / stride-1 layers on
+ * the row-streaming body, knob "bn_on_load"); else RIGL_EUNSUPPORTED.  The
+ * statistics parts are those of rigl_conv2d_stats_parts(d).                 */
+int32_t rigl_conv2d_fwd_takes_bn_input(const RiglConvDesc* d);
+int rigl_masked_conv2d_fwd_bnrelu(const RiglConvDesc* d, const rigl_bf16* x_pre,
+                                  const float* scale_shift, rigl_bf16* a_out,
+                                  const rigl_bf16* w_ohwi, rigl_bf16* y,
+                                  float* stats /* nullable */, size_t stats_floats,
+                                  void* workspace, size_t workspace_bytes,
+                                  rigl_stream_t stream);
 /* dx = conv2d_backprop_input(dy, mask*W) + addend: the gradient accumulation
  * TF's autodiff emits (AddN) where a tensor feeds two consumers -- a residual
  * block's input feeds conv1 and the shortcut (resnet_model.py:300-330, 374-420)
@@ -694,7 +716,11 @@ int rigl_probe_mfma_bf16(int32_t blocks, int32_t iters, float* sink, rigl_stream
  * round 5 replaced x1x1.hpp and its knobs by rowstream.hpp).
  * Round 6: "bwdslice" (0 = off, 1 = default: the channel-sliced single-pass
  * backward of the 1x1 / stride-1 layers with cin % 128 == 0 and cout 128 / 256,
- * bwdslice.hpp).
+ * bwdslice.hpp); "bn_on_load" (0: rigl_conv2d_fwd_takes_bn_input says 0 for
+ * every layer; 1 = default: the row-streaming forwards except the 64-channel /
+ * 128-column variant take the transform -- whether a model USES the entry point
+ * is the caller's choice: the host mirror does with RIGL_BN_ON_LOAD=1 only, it
+ * measured 0.03 ms slower per ResNet-50 step).
  * No reference counterpart (the reference selects cuDNN/TPU algorithms inside
  * TensorFlow: rigl/imagenet_resnet/pruning_layers.py:139-157).              */
 int rigl_tune_set(const char* key, int32_t value);

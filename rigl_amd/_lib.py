@@ -107,6 +107,8 @@ SIGNATURES = {
     'rigl_conv2d_stats_parts': (_I32, [C.POINTER(ConvDesc)]),
     'rigl_masked_conv2d_fwd_stats': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P,
                                                _SZ, _P, _SZ, _P]),
+    'rigl_conv2d_fwd_takes_bn_input': (_I32, [C.POINTER(ConvDesc)]),
+    'rigl_masked_conv2d_fwd_bnrelu': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _P]),
     'rigl_masked_conv2d_dgrad_acc': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P,
                                                _P, _P, _SZ, _P]),
     'rigl_conv2d_dgrad_stats_parts': (_I32, [C.POINTER(ConvDesc)]),

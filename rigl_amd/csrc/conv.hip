@@ -1526,6 +1526,37 @@ int rigl_masked_conv2d_fwd_stats(const RiglConvDesc* d, const rigl_bf16* x, cons
   return RIGL_OK;
 }
 
+// y = conv(relu(bn(x_pre)), w) with the apply pass of the batch norm done on the operand load (rowstream.hpp, BNL kernels):
+// scale_shift = [2][cin] fp32 (rows 2-3 of the batch norm's `saved`), a_out = the activated tensor, written as a side output.
+int32_t rigl_conv2d_fwd_takes_bn_input(const RiglConvDesc* d) {
+  using namespace rigl;
+  using namespace rigl::k1;
+  if (!d || check_desc(d, "rigl_conv2d_fwd_takes_bn_input")) return 0;
+  if ((d->cin % 8) || (d->cout % 8)) return 0;
+  return rs_bnl_use(d) ? 1 : 0;
+}
+
+int rigl_masked_conv2d_fwd_bnrelu(const RiglConvDesc* d, const rigl_bf16* x_pre, const float* scale_shift, rigl_bf16* a_out,
+                                  const rigl_bf16* w_ohwi, rigl_bf16* y, float* stats_partial, size_t partial_floats,
+                                  void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
+  using namespace rigl;
+  using namespace rigl::k1;
+  (void)workspace; (void)workspace_bytes;
+  int rc = check_desc(d, "rigl_masked_conv2d_fwd_bnrelu");
+  if (rc) return rc;
+  if (!x_pre || !scale_shift || !a_out || !w_ohwi || !y) return fail(RIGL_EINVAL, "rigl_masked_conv2d_fwd_bnrelu: NULL pointer");
+  RsPlan rp;
+  if ((d->cin % 8) || (d->cout % 8) || !rs_bnl_use(d, &rp))
+    return fail(RIGL_EUNSUPPORTED, "rigl_masked_conv2d_fwd_bnrelu: this layer's forward does not take the transform (rigl_conv2d_fwd_takes_bn_input)");
+  if (stats_partial && partial_floats < (size_t)rp.gprime * 2 * d->cout)
+    return fail(RIGL_EWORKSPACE, "rigl_masked_conv2d_fwd_bnrelu: partial buffer %zu floats < %zu", partial_floats, (size_t)rp.gprime * 2 * d->cout);
+  prof_set_tag(d);
+  ProfFamily prof(PROF_CONV_FWD);
+  launch_rs_bnl(d, rp, x_pre, scale_shift, a_out, w_ohwi, y, stats_partial, as_stream(stream));
+  RIGL_CHECK_LAUNCH("rigl_masked_conv2d_fwd_bnrelu");
+  return RIGL_OK;
+}
+
 int rigl_masked_conv2d_fwd(const RiglConvDesc* d, const rigl_bf16* x, const rigl_bf16* w_ohwi, rigl_bf16* y,
                            void* workspace, size_t workspace_bytes, rigl_stream_t stream) {
   return rigl_masked_conv2d_fwd_stats(d, x, w_ohwi, y, nullptr, 0, workspace, workspace_bytes, stream);

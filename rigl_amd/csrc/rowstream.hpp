@@ -47,6 +47,8 @@ struct RsArgs {
   int slices, gprime;    // N / NS column slices, workgroups per slice (a multiple of 8); grid = slices * gprime
   uint32_t a_bytes, b_bytes, c_bytes;
   unsigned long long* TRACE;   // development (-DRIGL_RS_TRACE): [grid][64] s_memtime stamps of wave 0
+  const float* BNP;            // BNL kernels: [2][K] scale, shift of the batch norm in front of this conv
+  uint16_t* A2;                // BNL kernels: [M][K] bf16, the activated operand (side output, the backward reads it)
 };
 #ifdef RIGL_RS_TRACE
 #define RS_STAMP(i_) { if (tid == 0 && P.TRACE && (i_) < 64) P.TRACE[blockIdx.x * 64 + (i_)] = __builtin_amdgcn_s_memtime(); }
@@ -63,18 +65,43 @@ __device__ __forceinline__ uint32_t rs_add_bf16x2(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(s, bf16x2));
 }
 
+// BNL kernels: the batch-norm apply + ReLU of bn.hip's k_fwd_apply on one A fragment (8 consecutive reduction channels of one
+// row) in registers, bf16(max(fma(x, scale, shift), 0)): ps -> this lane's 8 scales in LDS, ps + K its 8 shifts; rows that do
+// not exist become zeros (they read zeros, and max(shift, 0) would enter the statistics)
+typedef __attribute__((ext_vector_type(4))) float rs_f32x4;
+__device__ __forceinline__ u32x4 rs_bnrelu(bf16x8 v, const float* ps, int K, bool rowok) {
+  const rs_f32x4 s0 = *reinterpret_cast<const rs_f32x4*>(ps), s1 = *reinterpret_cast<const rs_f32x4*>(ps + 4);
+  const rs_f32x4 h0 = *reinterpret_cast<const rs_f32x4*>(ps + K), h1 = *reinterpret_cast<const rs_f32x4*>(ps + K + 4);
+  u32x4 w = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const float sa = d < 2 ? s0[2 * d] : s1[2 * d - 4], sb = d < 2 ? s0[2 * d + 1] : s1[2 * d - 3];
+    const float ha = d < 2 ? h0[2 * d] : h1[2 * d - 4], hb = d < 2 ? h0[2 * d + 1] : h1[2 * d - 3];
+    const f32x2 y = {fmaxf(fmaf(__uint_as_float(w[d] << 16), sa, ha), 0.f), fmaxf(fmaf(__uint_as_float(w[d] & 0xFFFF0000u), sb, hb), 0.f)};
+    w[d] = rowok ? __builtin_bit_cast(uint32_t, __builtin_convertvector(y, bf16x2)) : 0u;
+  }
+  return w;
+}
+
 template <int KC, int TN>
 struct RsGeom {
   static constexpr int K = 64 * KC, NS = 32 * TN, RB = K * 2, CPR = K / 8;
   static constexpr int WBYTES = NS * RB;                         // the filter slice
   static constexpr int SROW = NS * 2 + 8, STG_WAVE = 32 * SROW;  // a wave's staging tile: 32 rows, 8 bytes of padding (below)
   static constexpr int SMEM = WBYTES + 8 * STG_WAVE;
+  static constexpr int SMEM_BNL = SMEM + 2 * K * 4;               // + the batch-norm parameters of the BNL kernels
   static_assert(8 * STG_WAVE >= 8 * 64 * 16 * 4, "the statistics hand-off re-uses the staging tiles");
 };
 
 // MODE 0 = forward (statistics always summed, written if STATS is given), 1 = dgrad, 2 = dgrad + addend
-template <int KC, int TN, int MODE>
+// BNL (forward only; VERDICT r5 item 2, "batch-norm apply + ReLU on the operand load"): A is the PRE-batch-norm tensor; every A
+// fragment becomes bf16(max(x * scale[k] + shift[k], 0)) in its ring registers one k-step before its MFMAs (under the previous
+// step's), so the product is conv(relu(bn(x))) with the rounding points of the separate apply pass, which is then not run;
+// the activated tensor the backward needs (weight-gradient operand) leaves as a side output from the same registers: chunk
+// c of a row is stored by the workgroup of column slice c % slices.
+template <int KC, int TN, int MODE, bool BNL = false>
 __global__ __launch_bounds__(RS_THREADS) void k_rowstream(RsArgs P) {
+  static_assert(!BNL || MODE == 0, "the on-load transform belongs to the forward");
   constexpr bool DGRAD = MODE != 0, ADDEND = MODE == 2;
   using G = RsGeom<KC, TN>;
   constexpr int NS = G::NS, RB = G::RB, CPR = G::CPR, SROW = G::SROW;
@@ -93,6 +120,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rowstream(RsArgs P) {
   const __amdgpu_buffer_rsrc_t rsrcD = make_rsrc(ADDEND ? P.ADD : P.A, ADDEND ? P.c_bytes : 0u);
   const __amdgpu_buffer_rsrc_t rsrcC = make_rsrc(P.C, P.c_bytes);
 
+  float* const prm = reinterpret_cast<float*>(smem_rs + G::SMEM);           // BNL: [2][K]
+  const __amdgpu_buffer_rsrc_t rsrcA2 = make_rsrc(BNL ? P.A2 : P.C, BNL ? P.a_bytes : 0u);
+  if (BNL) {
+    for (int i = tid; i < 2 * G::K; i += RS_THREADS) prm[i] = P.BNP[i];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the raw barrier below does not wait for LDS stores)
+    __builtin_amdgcn_sched_barrier(0);
+  }
   // ---- the filter slice -> LDS: pieces of 1 KB, position p = piece * 64 + lane -> (row, 16-byte slot); the slot holds the
   // row's chunk slot ^ swizzle(row)
 #define RS_SWZ(row_) (CPR == 8 ? (((row_) >> 1) & 7) : ((row_) & 15))
@@ -178,6 +212,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_rowstream(RsArgs P) {
           bq[buf_][j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * RB + ((((2 * (s_) + hi)) ^ swz) << 4));
         RS_READ(0, 0);
         RS_READ(1, 1);
+        const bool rowok = BNL && r31 < P.F && row0 + r31 < P.M;
+#define RS_BNL(st_)                                                                                      \
+        {                                                                                                \
+          const int c_ = (st_) / 4, g_ = (st_) % 4, slot_ = (u * KC + c_) & 3;                           \
+          const u32x4 w_ = rs_bnrelu(a[slot_][g_], prm + c_ * 64 + g_ * 16 + hi * 8, G::K, rowok);       \
+          a[slot_][g_] = __builtin_bit_cast(bf16x8, w_);                                                 \
+          if ((c_ % P.slices) == slice)                                                                  \
+            __builtin_amdgcn_raw_buffer_store_b128(w_, rsrcA2, (int)(row_off(ii) + (uint32_t)(c_ * 128 + g_ * 32)), 0, 0); \
+        }
+        if (BNL) RS_BNL(0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int st = 0; st < S; ++st) {
@@ -194,6 +238,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rowstream(RsArgs P) {
 #if !(defined(RIGL_RS_ABLATE) && (RIGL_RS_ABLATE & 64))      // timing experiment 64: the filter fragments are read once per fragment
           if (st + 2 < S) RS_READ(st + 2, st & 1);
 #endif
+          if (BNL && st + 1 < S) RS_BNL(st + 1);       // the next k-step's A fragment, transformed under this step's MFMAs
           if (g4 == 3) {
             const int t4 = t + 4;
 #if !(defined(RIGL_RS_ABLATE) && (RIGL_RS_ABLATE & 1))      // timing experiment 1: the ring is never refilled (wrong results)
@@ -203,6 +248,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rowstream(RsArgs P) {
           __builtin_amdgcn_sched_barrier(0);
         }
 #undef RS_READ
+#undef RS_BNL
       }
       RS_STAMP(3 + 3 * ii);
       // ---- epilogue: D row = (e & 3) + 8 * (e >> 2) + 4 * hi -> channel of n-tile j, column = lane & 31 -> row of the fragment
@@ -336,6 +382,12 @@ static bool rs_ready_i() {
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, RsGeom<KC, TN>::SMEM) == hipSuccess;
   return ready;
 }
+template <int KC, int TN>
+static bool rs_ready_bnl() {
+  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowstream<KC, TN, 0, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, RsGeom<KC, TN>::SMEM_BNL) == hipSuccess;
+  return ready;
+}
 #define RS_DISPATCH(p_, DG_, WHAT_)                                                                      \
   switch ((p_).kc * 8 + (p_).tn) {                                                                       \
     case 1 * 8 + 2: { WHAT_(1, 2, DG_); } break;                                                         \
@@ -395,5 +447,33 @@ static void launch_rs(const RiglConvDesc* d, const RsPlan& p, const rigl_bf16* a
   const dim3 grid((unsigned)(p.slices * p.gprime)), blk(RS_THREADS);
 #define RS_LAUNCH(KC_, TN_, DG_) RIGL_K_LAUNCH((k_rowstream<KC_, TN_, DG_>), grid, blk, (unsigned)(RsGeom<KC_, TN_>::SMEM), st, a);
   if (MODE == 0) { RS_DISPATCH(p, 0, RS_LAUNCH) } else if (addend) { RS_DISPATCH(p, 2, RS_LAUNCH) } else { RS_DISPATCH(p, 1, RS_LAUNCH) }
+#undef RS_LAUNCH
+}
+
+// ---- the forward with the batch-norm apply + ReLU on the operand load (BNL kernels) -----------------------------------------
+// Taken where the layer's forward is the row-streaming body anyway, except the K = 64 / TN = 4 variant (its four-fragment
+// unrolled body spills 79 registers with the transform: measured twice as slow); knob "bn_on_load": 1 = these layers
+// (default), 0 = none.
+static bool rs_bnl_use(const RiglConvDesc* d, RsPlan* out = nullptr) {
+  RsPlan p;
+  if (!RIGL_TUNE("bn_on_load", 1) || !rs_use<0>(d, &p)) return false;
+  if (p.kc == 1 && p.tn == 4) return false;
+  bool ready = false;
+#define RS_READY(KC_, TN_, DG_) ready = rs_ready_bnl<KC_, TN_>();
+  RS_DISPATCH(p, 0, RS_READY)
+#undef RS_READY
+  if (ready && out) *out = p;
+  return ready;
+}
+static void launch_rs_bnl(const RiglConvDesc* d, const RsPlan& p, const rigl_bf16* x_pre, const float* scale_shift, rigl_bf16* a_out,
+                          const rigl_bf16* w_ohwi, rigl_bf16* y, float* stats, hipStream_t st) {
+  RsArgs a = {};
+  a.A = x_pre; a.B = w_ohwi; a.C = y; a.STATS = stats; a.BNP = scale_shift; a.A2 = a_out;
+  a.M = d->n * d->h * d->w; a.N = d->cout; a.F = p.F; a.nfrag = p.nfrag; a.slices = p.slices; a.gprime = p.gprime;
+  a.a_bytes = (uint32_t)((size_t)a.M * d->cin * 2); a.b_bytes = (uint32_t)((size_t)d->cout * d->cin * 2);
+  a.c_bytes = (uint32_t)((size_t)a.M * d->cout * 2);
+  const dim3 grid((unsigned)(p.slices * p.gprime)), blk(RS_THREADS);
+#define RS_LAUNCH(KC_, TN_, DG_) RIGL_K_LAUNCH((k_rowstream<KC_, TN_, 0, true>), grid, blk, (unsigned)(RsGeom<KC_, TN_>::SMEM_BNL), st, a);
+  RS_DISPATCH(p, 0, RS_LAUNCH)
 #undef RS_LAUNCH
 }

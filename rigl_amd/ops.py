@@ -366,6 +366,37 @@ def conv_fwd(d, x, w_ohwi, y=None, force_ref=False, stats=False):
   return (y, part) if stats else y
 
 
+def conv_fwd_takes_bn_input(d):
+  """Does this layer's forward take the batch norm in front of it on its operand load (rigl_conv2d_fwd_takes_bn_input)?"""
+  if not mfma_supported(d):
+    return False
+  return bool(_plan_cached(d, 'fwd_bn_input', lambda: int(_lib.load().rigl_conv2d_fwd_takes_bn_input(C.byref(d)))))
+
+
+def conv_fwd_bnrelu(d, x_pre, saved, w_ohwi, a_out, y=None, stats=False):
+  """y = conv(relu(bn(x_pre)), w) with the batch norm's apply pass on the operand load (rigl_masked_conv2d_fwd_bnrelu):
+  ``saved`` = fp32 [4, Cin] (mean, invstd, scale, shift: bn_statistics), ``a_out`` (bf16, the shape of x_pre) receives
+  relu(bn(x_pre)) as a side output.  Returns y or (y, partials) like conv_fwd."""
+  _req(x_pre, torch.bfloat16, 'x_pre')
+  _req(a_out, torch.bfloat16, 'a_out')
+  _req(w_ohwi, torch.bfloat16, 'w_ohwi')
+  _req(saved, torch.float32, 'saved')
+  if saved.numel() != 4 * d.cin or a_out.numel() != x_pre.numel() or x_pre.numel() != d.n * d.h * d.w * d.cin:
+    raise ValueError('saved must be [4, Cin]; x_pre and a_out [n, h, w, Cin]')
+  _count_macs('fwd_macs', d)
+  if y is None:
+    y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.bfloat16, device=x_pre.device)
+  _req(y, torch.bfloat16, 'y')
+  lib = _lib.load()
+  part = None
+  if stats:
+    parts = _plan_cached(d, 'stats_parts', lambda: lib.rigl_conv2d_stats_parts(C.byref(d)))
+    part = torch.empty((parts, 2, d.cout), dtype=torch.float32, device=x_pre.device)
+  check(lib.rigl_masked_conv2d_fwd_bnrelu(C.byref(d), _ptr(x_pre), _ptr(saved[2]), _ptr(a_out), _ptr(w_ohwi), _ptr(y), _ptr(part),
+                                          part.numel() if part is not None else 0, None, 0, _stream()))
+  return (y, part) if stats else y
+
+
 def conv_dgrad(d, dy, w_hwio, dx=None, force_ref=False, addend=None):
   """dx = conv2d_backprop_input(dy, w) (+ addend, fused into the epilogue: the
   gradient accumulation of a tensor that feeds this conv and a shortcut)."""

@@ -79,10 +79,20 @@ class _MaskedConvFn(torch.autograd.Function):
   """y = conv(x, mask*W) with dense dW written into lv.weights.grad."""
 
   @staticmethod
-  def forward(ctx, x, lv, desc, need_dx, want_stats=False, bn_holder=None):
+  def forward(ctx, x, lv, desc, need_dx, want_stats=False, bn_holder=None, pending=None):
     ctx.lv, ctx.desc, ctx.need_dx = lv, desc, need_dx
     ctx.bn_holder = bn_holder
     ctx.save_for_backward(x)
+    if pending is not None:
+      # x is the still EMPTY output of a batch norm that only finalised its statistics (workloads.nn.BatchNorm, consumer=):
+      # this conv reads the pre-batch-norm tensor, applies scale / shift / ReLU on its operand load and fills x on the way
+      out = ops.conv_fwd_bnrelu(desc, pending.x, pending.saved, lv.ohwi, x, stats=want_stats)
+      if not want_stats:
+        return out
+      y, part = out
+      ctx.mark_non_differentiable(part)
+      ctx.set_materialize_grads(False)
+      return y, part
     if x.dtype == torch.float32:         # --precision=float32: the fp32 validation kernels, no statistics epilogue
       y = ops.conv_fwd_f32(desc, x, lv.weights.data.view(-1), _mask_bits(lv))
       if not want_stats:
@@ -113,11 +123,11 @@ class _MaskedConvFn(torch.autograd.Function):
     if x.dtype == torch.float32:
       dx = ops.conv_bwd_f32(d, x, dy, lv.weights.data.view(-1), _mask_bits(lv), lv.weights.grad.view(-1),
                             need_dx=ctx.need_dx, on_dw_ready=ready)
-      return dx, None, None, None, None, None
+      return dx, None, None, None, None, None, None
     req = _bn_fuse_request(ctx.bn_holder, ctx.need_dx)
     dx = ops.conv_bwd(d, x, dy, lv.hwio, lv.weights.grad.view(-1), need_dx=ctx.need_dx, on_dw_ready=ready, bn_fuse=req)
     _bn_fuse_publish(ctx.bn_holder, req, dx)
-    return dx, None, None, None, None, None
+    return dx, None, None, None, None, None, None
 
 
 class _MaskedConvForkFn(torch.autograd.Function):
@@ -320,14 +330,25 @@ class MaskedConv2d(_Layer):
     d = self.desc_for(n, h, w)
     need_dx = self.need_input_grad and x.requires_grad
     holder = _bn_source(x) if need_dx else None
+    pending = getattr(x, 'bn_pending', None)   # the batch norm in front left its apply pass to this conv (takes_bn_input)
+    if pending is not None and (pending.x is None or not x.is_contiguous()):
+      raise RuntimeError('a deferred batch-norm output must reach its consumer conv as it was returned')
     if not x.requires_grad:
       x = x.detach().requires_grad_(True)  # keep the node so wgrad runs
     if not bn_stats:
-      return _MaskedConvFn.apply(x.contiguous(), self.vars, d, need_dx, False, holder)
-    y, part = _MaskedConvFn.apply(x.contiguous(), self.vars, d, need_dx, True, holder)
+      return _MaskedConvFn.apply(x.contiguous(), self.vars, d, need_dx, False, holder, pending)
+    y, part = _MaskedConvFn.apply(x.contiguous(), self.vars, d, need_dx, True, holder, pending)
     if part.numel():
       y.bn_partials = part
     return y
+
+  def takes_bn_input(self, x):
+    """Does this conv's forward take relu(bn(.)) of its input on its operand load (rigl_masked_conv2d_fwd_bnrelu)?  ``x`` = the
+    batch norm's input (the shape of this conv's input)."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[-1] == self.cin):
+      return False
+    n, h, w, _ = x.shape
+    return ops.conv_fwd_takes_bn_input(self.desc_for(n, h, w))
 
   def takes_masked_addend(self, x):
     """Can the gradient of ``fork(x)``'s alias be handed to this conv unmasked with a 1-bit mask (rigl_masked_conv2d_bwd_masked)?

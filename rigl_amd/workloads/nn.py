@@ -53,6 +53,9 @@ class _BnBwdHolder:
 
 
 _LAZY_RES_GRAD = os.environ.get('RIGL_LAZY_RES_GRAD', '1') != '0'
+# relu(bn(x)) applied on the operand load of the conv that consumes it (ops.conv_fwd_bnrelu): built and bit-identical, measured
+# SLOWER than the separate apply pass (profiles/r6/README.md: the activated tensor still has to be written for the backward), so off
+_BN_ON_LOAD = os.environ.get('RIGL_BN_ON_LOAD', '0') == '1'
 
 
 class _FusedBNFn(torch.autograd.Function):
@@ -61,13 +64,21 @@ class _FusedBNFn(torch.autograd.Function):
   the conv kernels' dW; autograd only routes dx (and the residual's grad)."""
 
   @staticmethod
-  def forward(ctx, x, residual, bn, relu, partials=None, holder=None, lazy_res_grad=False):
+  def forward(ctx, x, residual, bn, relu, partials=None, holder=None, lazy_res_grad=False, defer=False):
     from rigl_amd import ops  # pylint: disable=import-outside-toplevel
     x = x.contiguous()
     res = residual.contiguous() if residual is not None else None
     ctx.bn, ctx.relu, ctx.has_res = bn, relu, res is not None
     ctx.holder = holder
     ctx.lazy_res_grad = bool(lazy_res_grad) and relu and res is not None
+    if defer:
+      # statistics only: the consumer conv applies the batch norm + ReLU on its operand load and FILLS y as a side output
+      # (MaskedConv2d picks x and saved up from the holder: y.bn_pending)
+      saved = ops.bn_statistics(x, bn.gamma.data, bn.beta.data, bn.moving_mean, bn.moving_variance, 1.0 - bn.decay, bn.eps,
+                                partials=partials)
+      ctx.save_for_backward(x, saved)
+      holder.x, holder.saved, holder.bits = x, saved, None
+      return torch.empty_like(x)
     # the ReLU mask of relu(bn + residual) is kept as 1 bit per element (the backward would
     # otherwise re-read the whole output twice); without a residual it is recomputed from x
     if relu and res is not None:
@@ -106,12 +117,12 @@ class _FusedBNFn(torch.autograd.Function):
       dx, _ = ops.bn_bwd(x, None, dy, bn.gamma.data, saved, ctx.relu, bn.gamma.grad, bn.beta.grad, want_dres=False,
                          relu_bits=bits, partials=part)
       ops.LAZY_ADDEND_BITS[dy.data_ptr()] = (bits, dy)
-      return dx, dy, None, None, None, None, None
+      return dx, dy, None, None, None, None, None, None
     dx, dres = ops.bn_bwd(x, None, dy, bn.gamma.data, saved, ctx.relu,
                           bn.gamma.grad, bn.beta.grad,
                           want_dres=ctx.has_res and ctx.needs_input_grad[1],
                           relu_bits=bits, partials=part)
-    return dx, dres, None, None, None, None, None
+    return dx, dres, None, None, None, None, None, None
 
 
 class _BnAddBnFn(torch.autograd.Function):
@@ -181,17 +192,22 @@ class BatchNorm:
     self.scope = scope
     graph.modules[scope] = self          # creation order = TF's batch_normalization_<k> numbering
 
-  def __call__(self, x, is_training=True, relu=False, residual=None, lazy_res_grad=False):
+  def __call__(self, x, is_training=True, relu=False, residual=None, lazy_res_grad=False, consumer=None):
     """``lazy_res_grad``: the residual's ONLY other consumer is a masked conv whose backward takes its addend unmasked with
-    the ReLU bits (conv.takes_masked_addend): the backward then hands the output gradient itself to it."""
+    the ReLU bits (conv.takes_masked_addend): the backward then hands the output gradient itself to it.
+    ``consumer``: the masked conv that is the ONLY reader of the output and is called on it next; where its forward takes the
+    batch norm on its operand load (conv.takes_bn_input) only the statistics are finalised here and the conv fills the output."""
     if (self.fused and is_training and x.is_cuda and self.channels % 8 == 0
         and x.dtype == torch.bfloat16):
       partials = getattr(x, 'bn_partials', None)   # left by the producing conv's epilogue
       if not x.requires_grad:
         x = x.detach().requires_grad_(True)
       holder = _BnBwdHolder(relu)
-      y = _FusedBNFn.apply(x, residual, self, relu, partials, holder, lazy_res_grad and _LAZY_RES_GRAD)
+      defer = bool(_BN_ON_LOAD and consumer is not None and relu and residual is None and consumer.takes_bn_input(x))
+      y = _FusedBNFn.apply(x, residual, self, relu, partials, holder, lazy_res_grad and _LAZY_RES_GRAD, defer)
       y.bn_ctx = holder                            # a masked conv that is this tensor's only consumer picks it up
+      if defer:
+        y.bn_pending = holder
       return y
     y = F.batch_norm(nchw_view(x), self.moving_mean, self.moving_variance,
                      bias_tensor(self.gamma), bias_tensor(self.beta),

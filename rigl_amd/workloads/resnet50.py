@@ -55,6 +55,9 @@ class _ConvFixedPadding:
   def takes_masked_addend(self, x):
     return self.conv.takes_masked_addend(x)
 
+  def takes_bn_input(self, x):
+    return self.conv.takes_bn_input(x)
+
 
 class _Bottleneck:
   """bottleneck_block_ (resnet_model.py:396-501)."""
@@ -82,7 +85,7 @@ class _Bottleneck:
       lazy = self.c1.takes_masked_addend(x)      # (the shortcut's gradient then reaches conv1 unmasked + the ReLU bits)
       y, shortcut = self.c1.fork(x)
     y = self.bn1(y, is_training, relu=True)
-    y = self.bn2(self.c2(y), is_training, relu=True)
+    y = self.bn2(self.c2(y), is_training, relu=True, consumer=self.c3)   # (RIGL_BN_ON_LOAD=1: conv3 applies it on its operand load)
     if self.proj is not None:
       # relu(bn3(conv3) + bn_proj(projection)) in one piece: neither the normalised shortcut nor the masked gradient
       # between the two batch norms is written
