@@ -324,8 +324,8 @@ def test_resnet50_every_conv_in_situ_and_loss_vs_cpu_oracle(rn50, monkeypatch):
   rec = []
   fwd0, bwd0 = PL._MaskedConvFn.forward, PL._MaskedConvFn.backward
 
-  def fwd(ctx, x, lv, desc, need_dx, want_stats=False, bn_holder=None):
-    out = fwd0(ctx, x, lv, desc, need_dx, want_stats, bn_holder)
+  def fwd(ctx, x, lv, desc, need_dx, want_stats=False, bn_holder=None, pending=None):
+    out = fwd0(ctx, x, lv, desc, need_dx, want_stats, bn_holder, pending)   # (pending: the conv fills x itself, so x is read after it)
     y = out[0] if want_stats else out
     rec.append(dict(lv=lv, d=desc, x=x.detach().clone(), y=y.detach().clone()))
     ctx.rec = rec[-1]
