@@ -82,6 +82,8 @@ __global__ __launch_bounds__(THREADS) void k_bwd1x1(Bwd1x1Args P) {
   const int KT = P.interleave ? (split < KT_all ? (KT_all - split + P.splits - 1) / P.splits : 0)
                               : (int)((int64_t)KT_all * (split + 1) / P.splits) - kt_begin;
   const __amdgpu_buffer_rsrc_t rsrcY = make_rsrc(P.DY, P.dy_bytes), rsrcX = make_rsrc(P.X, P.x_bytes);
+  const u32x4 rsrcY4 = make_rsrc4(P.DY, P.dy_bytes), rsrcX4 = make_rsrc4(P.X, P.x_bytes);
+  (void)rsrcY4; (void)rsrcX4; (void)rsrcY; (void)rsrcX;
 
   // ---- DMA lanes ------------------------------------------------------------------------------------------------------
   // wave-instruction i of a tile with ROWB-byte rows fills rows i * (1024 / ROWB) ..; lane l: row + l / (ROWB / 16),
@@ -103,15 +105,13 @@ __global__ __launch_bounds__(THREADS) void k_bwd1x1(Bwd1x1Args P) {
     _Pragma("unroll") for (int q = 0; q < YPW; ++q) {                                                    \
       const int p_ = p0_ + y_row[q];                                                                     \
       const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * CO + y_col[q]) * 2u) : (int)OOB;                 \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                          \
-          rsrcY, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + (q * 4 + wave) * 1024), 16, off_, 0, 0, 0); \
+      RIGL_DMA16(rsrcY, smem + (stage_) * STAGE + (q * 4 + wave) * 1024, off_); \
     }                                                                                                    \
     if (DO_W) {                                                                                          \
       _Pragma("unroll") for (int q = 0; q < XPW; ++q) {                                                  \
         const int p_ = p0_ + x_row[q];                                                                   \
         const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * CI + x_col[q]) * 2u) : (int)OOB;               \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
-            rsrcX, (__attribute__((address_space(3))) void*)(smem + (stage_) * STAGE + Y_BYTES + (q * 4 + wave) * 1024), 16, off_, 0, 0, 0); \
+        RIGL_DMA16(rsrcX, smem + (stage_) * STAGE + Y_BYTES + (q * 4 + wave) * 1024, off_); \
       }                                                                                                  \
     }                                                                                                    \
   }

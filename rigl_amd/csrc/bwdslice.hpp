@@ -60,6 +60,15 @@ struct BsArgs {
 #endif
 
 constexpr int BS_THREADS = 512;
+// LDS-DMA through inline assembly (lds_dma16 in conv.hip: the compiler then puts no vmcnt(0) of its own between a wave's DMA
+// issue and its next LDS read); -DRIGL_DMA_BUILTIN restores the builtin for A/B runs
+#ifdef RIGL_DMA_BUILTIN
+#define BS_DMA16(r_, lds_, off_) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (__attribute__((address_space(3))) void*)(lds_), 16, off_, 0, 0, 0)
+#define BS_DMA4(r_, lds_, off_) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (__attribute__((address_space(3))) void*)(lds_), 4, off_, 0, 0, 0)
+#else
+#define BS_DMA16(r_, lds_, off_) lds_dma16(r_##4, lds_, off_)
+#define BS_DMA4(r_, lds_, off_) lds_dma4(r_##4, lds_, off_)
+#endif
 
 __device__ __forceinline__ int bs_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
@@ -113,6 +122,10 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice(BsArgs P) {
   const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.ADD ? P.ADD : P.DY, P.ADD ? P.add_bytes : 0u);
   const bool has_add = P.ADD != nullptr, has_bits = P.ABITS != nullptr;
   const __amdgpu_buffer_rsrc_t rsrcB = make_rsrc(has_bits ? (const void*)P.ABITS : (const void*)P.DY, has_bits ? P.add_bytes / 16u : 0u);
+  const u32x4 rsrcY4 = make_rsrc4(P.DY, P.dy_bytes), rsrcX4 = make_rsrc4(P.X, P.x_bytes);
+  const u32x4 rsrcA4 = make_rsrc4(P.ADD ? P.ADD : P.DY, P.ADD ? P.add_bytes : 0u);
+  const u32x4 rsrcB4 = make_rsrc4(has_bits ? (const void*)P.ABITS : (const void*)P.DY, has_bits ? P.add_bytes / 16u : 0u);
+  (void)rsrcY; (void)rsrcX; (void)rsrcA; (void)rsrcB; (void)rsrcY4; (void)rsrcX4; (void)rsrcA4; (void)rsrcB4;
   constexpr int A_BYTES = G::A_BYTES;
   // the two halves of the workgroup: cf = the wave's 32-channel fragment of the slice, par = the parity of the tiles whose dX it
   // computes (and whose DMA it issued); waves w and w + 4 share a SIMD
@@ -138,15 +151,13 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice(BsArgs P) {
     _Pragma("unroll") for (int q = 0; q < YPW; ++q) {                                                    \
       const int p_ = p0_ + y_row[q];                                                                     \
       const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * CO + y_col[q]) * 2u) : (int)OOB;                 \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                          \
-          rsrcY, (__attribute__((address_space(3))) void*)(st_ + (q * 4 + cf) * 1024), 16, off_, 0, 0, 0); \
+      BS_DMA16(rsrcY, st_ + (q * 4 + cf) * 1024, off_); \
     }                                                                                                    \
     _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
       const int p_ = p0_ + x_row[q];                                                                     \
       const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * P.CI + x_col[q]) * 2u) : (int)OOB;               \
       if (DO_W)                                                                                          \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
-            rsrcX, (__attribute__((address_space(3))) void*)(st_ + Y_BYTES + (q * 4 + cf) * 1024), 16, off_, 0, 0, 0); \
+        BS_DMA16(rsrcX, st_ + Y_BYTES + (q * 4 + cf) * 1024, off_); \
       if (has_add) {                                                                                     \
         int offa_ = off_;                                                                                \
         if (P.add_sh) {      /* the addend row of pixel p_ (if it has one: else zeros) */                 \
@@ -155,15 +166,13 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice(BsArgs P) {
           const bool on_ = p_ < P.M && qh_ * P.add_sh == hi_ && qw_ * P.add_sw == wi_;                   \
           offa_ = on_ ? (int)((uint32_t)(((im_ * P.add_ho + qh_) * P.add_wo + qw_) * P.CI + x_col[q]) * 2u) : (int)OOB; \
         }                                                                                                \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
-            rsrcA, (__attribute__((address_space(3))) void*)(st_ + Y_BYTES + X_BYTES + (q * 4 + cf) * 1024), 16, offa_, 0, 0, 0); \
+        BS_DMA16(rsrcA, st_ + Y_BYTES + X_BYTES + (q * 4 + cf) * 1024, offa_); \
       }                                                                                                  \
     }                                                                                                    \
     if (has_bits && cf < 2) {      /* 32 rows x 16 bytes of ReLU bits: two wave-instructions of 4 bytes per lane */ \
       const int ib_ = cf * 64 + lane, p_ = p0_ + (ib_ >> 2);                                             \
       const int offb_ = p_ < P.M ? (int)(((uint32_t)(p_ * P.CI + slice * SC) >> 3) + (uint32_t)((ib_ & 3) * 4)) : (int)OOB; \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                          \
-          rsrcB, (__attribute__((address_space(3))) void*)(st_ + Y_BYTES + X_BYTES + A_BYTES + cf * 256), 4, offb_, 0, 0, 0); \
+      BS_DMA4(rsrcB, st_ + Y_BYTES + X_BYTES + A_BYTES + cf * 256, offb_); \
     }                                                                                                    \
   }
 
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice(BsArgs P) {
     wfr[ks] = *reinterpret_cast<const bf16x8*>(P.W + (int64_t)ci * CO + co);
   }
   // dY fragment of k-step ks: lane l = row l & 31, logical chunk 2 * ks + (l >> 5)
-  const int d_base = r31 * YROWB, d_swz = bs_swz(r31);
+  const int d_swz = bs_swz(r31);
 
   // ---- wgrad: transposing fragment reads (lane geometry of bwd1x1.hpp / wgrad_tr_body)
   const int gq = lane >> 4, j16 = lane & 15;
@@ -273,12 +282,28 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice(BsArgs P) {
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) a0[e] = a1[e] = 0.f;
+      {
+        // (opaque copies: the fragment addresses are recomputed per tile instead of living in sixteen registers; the reads of
+        // k-steps ks + 2, ks + 3 are issued before the MFMAs of ks, ks + 1: no exposed LDS latency between MFMAs)
+        int r_ = r31, h_ = hi;
+        asm volatile("" : "+v"(r_), "+v"(h_));
+        const unsigned char* const yb_ = Ys + r_ * YROWB;
+        const int ds_ = bs_swz(r_);
+        bf16x8 yq[2][2];
+        yq[0][0] = *reinterpret_cast<const bf16x8*>(yb_ + ((h_ ^ ds_) << 4));
+        yq[0][1] = *reinterpret_cast<const bf16x8*>(yb_ + (((2 + h_) ^ ds_) << 4));
 #pragma unroll
-      for (int ks = 0; ks < KS; ks += 2) {
-        const bf16x8 y0 = *reinterpret_cast<const bf16x8*>(Ys + d_base + (((2 * ks + hi) ^ d_swz) << 4));
-        const bf16x8 y1 = *reinterpret_cast<const bf16x8*>(Ys + d_base + (((2 * ks + 2 + hi) ^ d_swz) << 4));
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[ks], y0, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[ks + 1], y1, a1, 0, 0, 0);
+        for (int ks = 0; ks < KS; ks += 2) {
+          const int cur = (ks >> 1) & 1;
+          if (ks + 2 < KS) {
+            yq[cur ^ 1][0] = *reinterpret_cast<const bf16x8*>(yb_ + (((2 * ks + 4 + h_) ^ ds_) << 4));
+            yq[cur ^ 1][1] = *reinterpret_cast<const bf16x8*>(yb_ + (((2 * ks + 6 + h_) ^ ds_) << 4));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[ks], yq[cur][0], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[ks + 1], yq[cur][1], a1, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       BS_STAMP(4);
     }
@@ -346,16 +371,309 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice(BsArgs P) {
 #endif
 }
 
+// ---- cout = 512: slices of 64 input channels ----------------------------------------------------------------------------
+// With 512 output channels the W fragment (32 x 512: 128 registers) and the slice's dW accumulators (128 x 512 fp32 over eight
+// waves: 128 registers) do not fit a wave together.  Here a slice is SC = 64 channels: dW[64][512] is 64 registers per wave
+// (2 x 2 fragments of 32 x 32, wave w = the cout fragments 2 w, 2 w + 1), and the dgrad of a tile is split over the FOUR waves
+// of the multiplying half as (cf = channel fragment of 32) x (kh = half of the output channels): a wave holds the 32 x 256 W
+// fragment of its (cf, kh) (64 registers), multiplies its half of the reduction, and the two halves of one channel fragment
+// meet through LDS: the kh = 1 wave leaves its fp32 partial ([4][64 lanes] x 16 bytes: conflict-free) at the end of its
+// multiplying iteration, the kh = 0 wave adds it to its own in its NEXT iteration -- the one in which its half has the
+// vector-memory duty -- converts, adds the shortcut gradient it picked up from the ring while multiplying, and stores the
+// [32 pixels][32 channels] block through a wave-private staging tile (no second barrier; 64-byte row segments).  In that
+// iteration the kh = 1 waves of the half issue the DMA of tile kt + 2.  Ring: three stages of 40.25 KB (dY rows [32][512],
+// X slice [32][64], addend slice + bits): the issuing waves wait for their latest tile with vmcnt(0) -- nothing younger of
+// theirs is in flight, the other half's tile is.  128-byte rows (X, addend) hold two rows per 256-byte bank window: the X
+// tile, read only by the transposing reads (4 rows x 64 bytes per 32-lane pass), flips chunk bit 2 with row bit 1; the
+// addend tile, read row-per-lane, spreads rows 0 .. 15 over the 16 (row parity, chunk ^ (row >> 1)) slots.
+// Summation order of a dX element: (even k-steps + odd k-steps of kh = 0) + (the same of kh = 1), identical with and without
+// the weight-gradient half.  tools/experiments/emu/bs_emu.py restates the index arithmetic (run_workgroup64).
+template <int CO, bool DO_W>
+struct Bs64Geom {
+  static constexpr int SC = 64, PX = 32, NST = 3;
+  static constexpr int YROWB = CO * 2, XROWB = SC * 2;
+  static constexpr int Y_BYTES = PX * YROWB, X_BYTES = DO_W ? PX * XROWB : 0, A_BYTES = PX * XROWB, B_BYTES = PX * SC / 8;
+  static constexpr int STAGE = Y_BYTES + X_BYTES + A_BYTES + B_BYTES;
+  static constexpr int PART_BYTES = 64 * 16 * 4;                 // one wave's fp32 dgrad partial
+  static constexpr int SROWB = 32 * 2 + 8, STG_BYTES = PX * SROWB;   // a wave's staging tile: [32 pixels][32 channels] + 8 bytes of padding
+  static constexpr int SMEM = NST * STAGE + 4 * PART_BYTES + 4 * STG_BYTES;
+};
+__device__ __forceinline__ int bs64_swz_x(int row) { return ((row >> 1) & 1) << 2; }
+__device__ __forceinline__ int bs64_swz_a(int row) { return (row >> 1) & 7; }
+
+template <int CO, bool DO_W>
+__global__ __launch_bounds__(BS_THREADS) void k_bwdslice64(BsArgs P) {
+  using G = Bs64Geom<CO, DO_W>;
+  constexpr int SC = G::SC, PX = G::PX, NST = G::NST, YROWB = G::YROWB, XROWB = G::XROWB;
+  constexpr int Y_BYTES = G::Y_BYTES, X_BYTES = G::X_BYTES, A_BYTES = G::A_BYTES, STAGE = G::STAGE;
+  constexpr int YPW = PX / 2;                                  // dY rows (1 KB wave-instructions) per issuing wave
+  static_assert(YROWB == 1024 && XROWB == 128 && NST == 3, "one DMA instruction per dY row, eight X rows per instruction");
+  constexpr int KSH = CO / 32;                                 // dgrad k-steps of one wave (half of the output channels)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_bs[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, r31 = lane & 31;
+  const int xcd = (int)(blockIdx.x & 7u), idx = (int)(blockIdx.x >> 3);
+  const int slice = idx % P.slices, g = xcd + 8 * (idx / P.slices);
+  const int KT_all = (P.M + PX - 1) / PX;
+  const int KT = g < KT_all ? (KT_all - g + P.G - 1) / P.G : 0;
+  const __amdgpu_buffer_rsrc_t rsrcY = make_rsrc(P.DY, P.dy_bytes), rsrcX = make_rsrc(P.X, P.x_bytes);
+  const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.ADD ? P.ADD : P.DY, P.ADD ? P.add_bytes : 0u);
+  const bool has_add = P.ADD != nullptr, has_bits = P.ABITS != nullptr;
+  const __amdgpu_buffer_rsrc_t rsrcB = make_rsrc(has_bits ? (const void*)P.ABITS : (const void*)P.DY, has_bits ? P.add_bytes / 16u : 0u);
+  const u32x4 rsrcY4 = make_rsrc4(P.DY, P.dy_bytes), rsrcX4 = make_rsrc4(P.X, P.x_bytes);
+  const u32x4 rsrcA4 = make_rsrc4(P.ADD ? P.ADD : P.DY, P.ADD ? P.add_bytes : 0u);
+  const u32x4 rsrcB4 = make_rsrc4(has_bits ? (const void*)P.ABITS : (const void*)P.DY, has_bits ? P.add_bytes / 16u : 0u);
+  (void)rsrcY; (void)rsrcX; (void)rsrcA; (void)rsrcB; (void)rsrcY4; (void)rsrcX4; (void)rsrcA4; (void)rsrcB4;
+  // par = the parity of the tiles this wave multiplies for dX, kh = its half of the output channels, cf = its channel fragment
+  const int par = wave >> 2, kh = (wave >> 1) & 1, cf = wave & 1;
+  unsigned char* const part = smem_bs + NST * STAGE + (par * 2 + cf) * G::PART_BYTES;
+  unsigned char* const stg = smem_bs + NST * STAGE + 4 * G::PART_BYTES + (par * 2 + cf) * G::STG_BYTES;
+
+  // ---- DMA (the kh = 1 waves of a half, piece = q * 2 + cf): a dY row per instruction, lane = 16-byte slot; X / addend: eight
+  // rows per instruction, lane l: row + l / 8, slot l % 8
+  int x_row[2], x_col[2], a_col[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = q * 2 + cf, row = i * 8 + lane / 8, slot = lane % 8;
+    x_row[q] = row;
+    x_col[q] = slice * SC + ((slot ^ bs64_swz_x(row)) * 8);
+    a_col[q] = slice * SC + ((slot ^ bs64_swz_a(row)) * 8);
+  }
+#define BS64_ISSUE(kt_, stage_)                                                                          \
+  {                                                                                                      \
+    const int p0_ = (g + (kt_) * P.G) * PX;                                                              \
+    unsigned char* const st_ = smem_bs + (stage_) * STAGE;                                               \
+    int ln_ = lane;      /* (opaque: the sixteen per-row offsets are recomputed here instead of living in sixteen registers) */ \
+    asm volatile("" : "+v"(ln_));                                                                        \
+    _Pragma("unroll") for (int q = 0; q < YPW; ++q) {                                                    \
+      const int row_ = q * 2 + cf, p_ = p0_ + row_;                                                      \
+      const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * CO + ((ln_ ^ bs_swz(row_)) * 8)) * 2u) : (int)OOB; \
+      BS_DMA16(rsrcY, st_ + row_ * 1024, off_);        \
+    }                                                                                                    \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
+      const int p_ = p0_ + x_row[q];                                                                     \
+      if (DO_W) {                                                                                        \
+        const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * P.CI + x_col[q]) * 2u) : (int)OOB;             \
+        BS_DMA16(rsrcX, st_ + Y_BYTES + (q * 2 + cf) * 1024, off_); \
+      }                                                                                                  \
+      if (has_add) {                                                                                     \
+        int offa_ = p_ < P.M ? (int)((uint32_t)(p_ * P.CI + a_col[q]) * 2u) : (int)OOB;                  \
+        if (P.add_sh) {      /* the addend row of pixel p_ (if it has one: else zeros) */                 \
+          const int t_ = fdiv(p_, P.fd_w), wi_ = p_ - t_ * P.IW, im_ = fdiv(t_, P.fd_h), hi_ = t_ - im_ * P.IH; \
+          const int qh_ = hi_ / P.add_sh, qw_ = wi_ / P.add_sw;                                          \
+          const bool on_ = p_ < P.M && qh_ * P.add_sh == hi_ && qw_ * P.add_sw == wi_;                   \
+          offa_ = on_ ? (int)((uint32_t)(((im_ * P.add_ho + qh_) * P.add_wo + qw_) * P.CI + a_col[q]) * 2u) : (int)OOB; \
+        }                                                                                                \
+        BS_DMA16(rsrcA, st_ + Y_BYTES + X_BYTES + (q * 2 + cf) * 1024, offa_); \
+      }                                                                                                  \
+    }                                                                                                    \
+    if (has_bits && cf == 0) {     /* 32 rows x 8 bytes of ReLU bits: one wave-instruction of 4 bytes per lane */ \
+      const int p_ = p0_ + (lane >> 1);                                                                  \
+      const int offb_ = p_ < P.M ? (int)(((uint32_t)(p_ * P.CI + slice * SC) >> 3) + (uint32_t)((lane & 1) * 4)) : (int)OOB; \
+      BS_DMA4(rsrcB, st_ + Y_BYTES + X_BYTES + A_BYTES, offb_); \
+    }                                                                                                    \
+  }
+
+  // ---- dgrad: the wave's W fragment (32 input channels x its 256 output channels) in registers
+  bf16x8 wfr[KSH];
+#pragma unroll
+  for (int ks = 0; ks < KSH; ++ks) {
+    const int ci = slice * SC + cf * 32 + r31, co = (kh * KSH + ks) * 16 + hi * 8;
+    wfr[ks] = *reinterpret_cast<const bf16x8*>(P.W + (int64_t)ci * CO + co);
+  }
+  const int a_swz = bs64_swz_a(r31);
+
+  // ---- wgrad: transposing fragment reads; wave w: both channel fragments x the output-channel fragments 2 w, 2 w + 1
+  const int gq = lane >> 4, j16 = lane & 15;
+  const int t_row = 8 * (gq >> 1) + (j16 >> 2);
+  const int t_low = 2 * (gq & 1) + ((j16 >> 1) & 1), t_half = (j16 & 1) * 8;
+  const int fo0 = wave * 2;
+  f32x16 acc2[DO_W ? 2 : 1][2];
+  if (DO_W) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
+  }
+  // (tr_, tl_, th_: opaque per-tile copies of t_row, t_low, t_half -- the eight fragment offsets are recomputed per tile instead
+  // of living in eight registers)
+#define BS64_TR_Y(chunk_, plus4_) ((tr_ + (plus4_)) * YROWB + ((((chunk_) + tl_) ^ bs_swz(tr_ + (plus4_))) << 4) + th_)
+#define BS64_TR_X(chunk_, plus4_) ((tr_ + (plus4_)) * XROWB + ((((chunk_) + tl_) ^ bs64_swz_x(tr_ + (plus4_))) << 4) + th_)
+
+  f32x16 a0;                 // the wave's dgrad partial of the tile it multiplied last (kh = 0: until it is combined)
+  uint2 av[4];               // kh = 0: the shortcut-gradient fragment of that tile
+#pragma unroll
+  for (int e = 0; e < 16; ++e) a0[e] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) av[q] = make_uint2(0u, 0u);
+  // kh = 0 of the half that multiplied tile ktp: own partial + the partner's, bf16, + the shortcut gradient, staged, stored
+#define BS64_COMBINE(ktp_)                                                                               \
+  {                                                                                                      \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
+      const rs_f32x4 o_ = *reinterpret_cast<const rs_f32x4*>(part + q * 1024 + lane * 16);               \
+      const f32x2 lo_ = {a0[4 * q] + o_[0], a0[4 * q + 1] + o_[1]}, hi_ = {a0[4 * q + 2] + o_[2], a0[4 * q + 3] + o_[3]}; \
+      uint2 pk_;                                                                                         \
+      pk_.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo_, bf16x2));                        \
+      pk_.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi_, bf16x2));                        \
+      if (has_add) { pk_.x = bs_add_bf16x2(pk_.x, av[q].x); pk_.y = bs_add_bf16x2(pk_.y, av[q].y); }     \
+      *reinterpret_cast<uint2*>(stg + r31 * G::SROWB + (8 * q + 4 * hi) * 2) = pk_;                      \
+    }                                                                                                    \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
+      const int pc_ = q * 64 + lane, row_ = pc_ >> 2, ch_ = pc_ & 3;                                     \
+      const unsigned char* src_ = stg + row_ * G::SROWB + ch_ * 16;                                      \
+      const uint2 lo8_ = *reinterpret_cast<const uint2*>(src_), hi8_ = *reinterpret_cast<const uint2*>(src_ + 8); \
+      const int p_ = (g + (ktp_) * P.G) * PX + row_;                                                     \
+      if (p_ < P.M)                                                                                      \
+        *reinterpret_cast<uint4*>(P.DX + (int64_t)p_ * P.CI + slice * SC + cf * 32 + ch_ * 8) = make_uint4(lo8_.x, lo8_.y, hi8_.x, hi8_.y); \
+    }                                                                                                    \
+  }
+
+#ifdef RIGL_BS_TRACE
+  unsigned long long tr_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+  unsigned long long tr_last = __builtin_amdgcn_s_memtime();
+#endif
+  // tile t is issued two iterations before it is multiplied, by the kh = 1 waves of the half that is NOT multiplying then
+  // (par = (t & 1) ^ 1); prologue: tiles 0 and 1
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t)
+    if (((t & 1) ^ 1) == par && kh == 1 && t < KT) BS64_ISSUE(t, t);
+  BS_STAMP(7);
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool mine = (kt & 1) == par;
+    if (!mine && kh == 1) wait_vmcnt<0>();        // this wave issued tile kt (its latest loads; it stores nothing)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    BS_STAMP(0);
+    const unsigned char* Ys = smem_bs + (kt % NST) * STAGE;
+    const unsigned char* Xs = Ys + Y_BYTES;
+    const unsigned char* As = Xs + X_BYTES;
+    if (!mine) {
+      if (kh == 1) {
+        if (kt + NST - 1 < KT) BS64_ISSUE(kt + NST - 1, (kt + NST - 1) % NST);
+      } else if (kt > 0) {
+        BS64_COMBINE(kt - 1);
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      BS_STAMP(1 + (kh == 0));
+    } else {
+      if (kh == 0 && has_add) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          av[q] = *reinterpret_cast<const uint2*>(As + r31 * XROWB + (((cf * 4 + q) ^ a_swz) << 4) + hi * 8);
+        if (has_bits) {
+          // byte q of this word = the bits of channels cf * 32 + 8 q ..: this lane's four are bits 4 hi .. 4 hi + 3
+          const uint32_t bw = *reinterpret_cast<const uint32_t*>(As + A_BYTES + r31 * 8 + cf * 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t nib = (bw >> (8 * q + 4 * hi)) & 0xFu;
+            av[q].x &= ((nib & 1u) ? 0x0000FFFFu : 0u) | ((nib & 2u) ? 0xFFFF0000u : 0u);
+            av[q].y &= ((nib & 4u) ? 0x0000FFFFu : 0u) | ((nib & 8u) ? 0xFFFF0000u : 0u);
+          }
+        }
+      }
+      BS_STAMP(3);
+      f32x16 a1;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a0[e] = a1[e] = 0.f;
+      // (opaque copies: the sixteen fragment addresses are recomputed per tile instead of living in sixteen registers)
+      int r_ = r31, h_ = hi;
+      asm volatile("" : "+v"(r_), "+v"(h_));
+      const unsigned char* const yb_ = Ys + r_ * YROWB;
+      const int ds_ = bs_swz(r_), cb_ = 2 * kh * KSH + h_;
+      // (the reads of k-steps ks + 2, ks + 3 are issued before the MFMAs of ks, ks + 1: no exposed LDS latency between MFMAs)
+      bf16x8 yq[2][2];
+      yq[0][0] = *reinterpret_cast<const bf16x8*>(yb_ + ((cb_ ^ ds_) << 4));
+      yq[0][1] = *reinterpret_cast<const bf16x8*>(yb_ + (((cb_ + 2) ^ ds_) << 4));
+#pragma unroll
+      for (int ks = 0; ks < KSH; ks += 2) {
+        const int cur = (ks >> 1) & 1;
+        if (ks + 2 < KSH) {
+          yq[cur ^ 1][0] = *reinterpret_cast<const bf16x8*>(yb_ + (((cb_ + 2 * ks + 4) ^ ds_) << 4));
+          yq[cur ^ 1][1] = *reinterpret_cast<const bf16x8*>(yb_ + (((cb_ + 2 * ks + 6) ^ ds_) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[ks], yq[cur][0], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[ks + 1], yq[cur][1], a1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a0[e] += a1[e];
+      if (kh == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const rs_f32x4 o = {a0[4 * q], a0[4 * q + 1], a0[4 * q + 2], a0[4 * q + 3]};
+          *reinterpret_cast<rs_f32x4*>(part + q * 1024 + lane * 16) = o;
+        }
+      }
+      BS_STAMP(4);
+    }
+    // ---- dW partial: D2[ci][co] += X^T-fragment x dY^T-fragment, two k-steps of 16 pixels
+    if (DO_W) {
+      int tr_ = t_row, tl_ = t_low, th_ = t_half;
+      asm volatile("" : "+v"(tr_), "+v"(tl_), "+v"(th_));
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        bf16x8 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          fa[i] = lds_read_tr_pair(Xs + k2 * 16 * XROWB + BS64_TR_X(i * 4, 0), Xs + k2 * 16 * XROWB + BS64_TR_X(i * 4, 4));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          fb[j] = lds_read_tr_pair(Ys + k2 * 16 * YROWB + BS64_TR_Y((fo0 + j) * 4, 0), Ys + k2 * 16 * YROWB + BS64_TR_Y((fo0 + j) * 4, 4));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc2[i][j], 0, 0, 0);
+      }
+    }
+    BS_STAMP(5);
+  }
+  if (KT > 0) {
+    __syncthreads();
+    if (((KT - 1) & 1) == par && kh == 0) BS64_COMBINE(KT - 1);
+  }
+#undef BS64_COMBINE
+#undef BS64_ISSUE
+#undef BS64_TR_X
+#undef BS64_TR_Y
+  if (DO_W) {
+    float* const out = P.SLAB + ((int64_t)g * P.CI + slice * SC) * CO;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ci = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi, co = (fo0 + j) * 32 + r31;
+          out[(int64_t)ci * CO + co] = acc2[i][j][e];
+        }
+  }
+#ifdef RIGL_BS_TRACE
+  if (P.TRACE && lane == 0 && (wave == 0 || wave == 2)) {     // the combining and the issuing wave of half 0, channel fragment 0
+    const unsigned long long n_ = __builtin_amdgcn_s_memtime();
+    tr_acc[7] += n_ - tr_last;
+    for (int i = 0; i < 8; ++i) P.TRACE[((int64_t)blockIdx.x * 2 + (wave >> 1)) * 8 + i] = tr_acc[i];
+  }
+#endif
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------
-// Legal: 1x1, stride 1, no padding, same output grid; cout 128 or 256; cin a multiple of 128 with cin / 128 a power of two
-// <= 32; enough 32-pixel tiles for every row group.  "bwdslice": 0 = off, 1 = the measured layers, 2 = every legal layer.
-struct BsPlan { int co, slices, G; };
+// Legal: 1x1, stride 1, no padding, same output grid; cout 128 or 256 (slices of 128 input channels) or 512 (slices of 64:
+// k_bwdslice64, knob "bwdslice512"); cin a multiple of the slice with cin / slice a power of two <= 32; enough 32-pixel tiles
+// for every row group.  "bwdslice": 0 = off, 1 = on.
+struct BsPlan { int co, sc, slices, G; };
 static bool bs_plan(const RiglConvDesc* d, BsPlan& p) {
   if (d->kh != 1 || d->kw != 1 || d->stride_h != 1 || d->stride_w != 1 || d->pad_top || d->pad_left) return false;
   if (d->ho != d->h || d->wo != d->w) return false;
-  if (d->cout != 128 && d->cout != 256) return false;
-  if (d->cin % 128) return false;
-  p.co = d->cout; p.slices = d->cin / 128;
+  if (d->cout != 128 && d->cout != 256 && d->cout != 512) return false;
+  p.sc = d->cout == 512 ? 64 : 128;
+  if (d->cin % p.sc) return false;
+  p.co = d->cout; p.slices = d->cin / p.sc;
   if (p.slices > 32 || (p.slices & (p.slices - 1))) return false;
   const int64_t M = (int64_t)d->n * d->h * d->w;
   if (M * d->cin * 2 >= (1ll << 31)) return false;
@@ -371,13 +689,21 @@ static bool bs_ready_i() {
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, BsGeom<CO, DO_W>::SMEM) == hipSuccess;
   return ready;
 }
+template <int CO, bool DO_W>
+static bool bs64_ready_i() {
+  static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwdslice64<CO, DO_W>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, Bs64Geom<CO, DO_W>::SMEM) == hipSuccess;
+  return ready;
+}
 static bool bs_use(const RiglConvDesc* d, BsPlan* out = nullptr) {
   BsPlan p;
   if (!bs_plan(d, p)) return false;
   const int knob = RIGL_TUNE("bwdslice", 1);
   if (knob == 0) return false;
-  const bool ready = p.co == 256 ? (bs_ready_i<256, true>() && bs_ready_i<256, false>())
-                                 : (bs_ready_i<128, true>() && bs_ready_i<128, false>());
+  if (p.co == 512 && !RIGL_TUNE("bwdslice512", 1)) return false;
+  const bool ready = p.co == 512 ? (bs64_ready_i<512, true>() && bs64_ready_i<512, false>())
+                     : p.co == 256 ? (bs_ready_i<256, true>() && bs_ready_i<256, false>())
+                                   : (bs_ready_i<128, true>() && bs_ready_i<128, false>());
   if (ready && out) *out = p;
   return ready;
 }
@@ -407,6 +733,10 @@ static void launch_bs(const RiglConvDesc* d, const BsPlan& p, const rigl_bf16* x
     a.add_bytes = (uint32_t)((size_t)d->n * a.add_ho * a.add_wo * d->cin * 2);
     a.fd_w = make_fastdiv(d->w); a.fd_h = make_fastdiv(d->h);
   }
-  if (p.co == 256) { if (slab) launch_bs_i<256, true>(a, st); else launch_bs_i<256, false>(a, st); }
+  if (p.co == 512) {
+    const dim3 grid((unsigned)(a.slices * a.G)), blk(BS_THREADS);
+    if (slab) { RIGL_K_LAUNCH((k_bwdslice64<512, true>), grid, blk, (unsigned)(Bs64Geom<512, true>::SMEM), st, a); }
+    else { RIGL_K_LAUNCH((k_bwdslice64<512, false>), grid, blk, (unsigned)(Bs64Geom<512, false>::SMEM), st, a); }
+  } else if (p.co == 256) { if (slab) launch_bs_i<256, true>(a, st); else launch_bs_i<256, false>(a, st); }
   else { if (slab) launch_bs_i<128, true>(a, st); else launch_bs_i<128, false>(a, st); }
 }

@@ -96,6 +96,8 @@ __global__ __launch_bounds__(C3_THREADS, 2) void k_c3x3(C3Args P) {
   const int patch_bytes = P.alloc_px * 128;
   unsigned char* const stg = smem_c3 + 2 * patch_bytes + wave * C3_STG_WAVE;
   const __amdgpu_buffer_rsrc_t rsrcX = make_rsrc(P.X, P.x_bytes);
+  const u32x4 rsrcX4 = make_rsrc4(P.X, P.x_bytes);
+  (void)rsrcX4; (void)rsrcX;
   const int npx = (P.TH + 2) * PW;
   const int n_inst = P.alloc_px >> 3;
 
@@ -126,8 +128,7 @@ __global__ __launch_bounds__(C3_THREADS, 2) void k_c3x3(C3Args P) {
         const int h = iq.h0 - 1 + iq.pr, w = iq.pc - 1;                                                  \
         const bool ok = px < npx && (unsigned)h < (unsigned)P.H && (unsigned)w < (unsigned)P.W;         \
         const int off = ((iq.n * P.H + h) * P.W + w) * 64 + chunk * 8;                                   \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (__attribute__((address_space(3))) void*)(iq.dst + iq.i * 1024), 16, \
-                                                 ok ? (int)((uint32_t)off * 2u) : (int)OOB, 0, 0, 0);    \
+        RIGL_DMA16(rsrcX, iq.dst + iq.i * 1024, ok ? (int)((uint32_t)off * 2u) : (int)OOB);    \
         iq.i += (nw_);                                                                                   \
         iq.pc += 8 * (nw_);                                                                              \
         if (iq.pc >= PW) { iq.pc -= PW; ++iq.pr; }                                                       \
@@ -334,6 +335,8 @@ __global__ __launch_bounds__(C3_THREADS, 2) void k_c3x3_wgrad(C3WArgs P) {
   const int PW = P.PW;
   const int stage_bytes = (P.x_px + P.kp) * 128;
   const __amdgpu_buffer_rsrc_t rsrcX = make_rsrc(P.X, P.x_bytes), rsrcY = make_rsrc(P.DY, P.dy_bytes);
+  const u32x4 rsrcX4 = make_rsrc4(P.X, P.x_bytes), rsrcY4 = make_rsrc4(P.DY, P.dy_bytes);
+  (void)rsrcX4; (void)rsrcY4; (void)rsrcX; (void)rsrcY;
   // transposing fragment reads (the k_wgrad_tr recipe): lane (g, j) of a 16-pixel k-step: pixel 8 * (g >> 1) + (j >> 2)
   // (+ 4 for the second read), 16-byte chunk 2 * (g & 1) + ((j >> 1) & 1) of the fragment's four, bytes (j & 1) * 8; the
   // row's 64-byte quads are XORed with bit 1 of the pixel index on the DMA's source side
@@ -372,8 +375,8 @@ __global__ __launch_bounds__(C3_THREADS, 2) void k_c3x3_wgrad(C3WArgs P) {
                            : (pr < q_rows && pc < P.W);                                                  \
       const int off = ((q_n * P.H + h) * P.W + w) * 64 + chunk * 8;                                      \
       const int boff = ok ? (int)((uint32_t)off * 2u) : (int)OOB;                                        \
-      if (isx_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (__attribute__((address_space(3))) void*)(q_dst + q_i * 1024), 16, boff, 0, 0, 0); \
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (__attribute__((address_space(3))) void*)(q_dst + q_i * 1024), 16, boff, 0, 0, 0); \
+      if (isx_) RIGL_DMA16(rsrcX, q_dst + q_i * 1024, boff); \
+      else RIGL_DMA16(rsrcY, q_dst + q_i * 1024, boff); \
       q_i += 8;                                                                                          \
     }                                                                                                    \
   }

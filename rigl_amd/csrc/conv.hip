@@ -85,6 +85,36 @@ constexpr uint32_t OOB = 0x80000000u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
+// LDS-DMA issued through inline assembly.  The builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) works, but the compiler's
+// wait-count pass then treats every later LDS read of the wave as a possible reader of the DMA's destination and puts an
+// s_waitcnt vmcnt in front of it that waits for the wave's YOUNGEST DMA -- a wave that issues tile t + 3 and then reads tile t
+// out of LDS stalls for the full memory latency in every iteration, and a prefetch ring is one tile deep whatever its size
+// (found in round 6 in the ISA of bwdslice.hpp / bwd1x1.hpp: "DMA x5 ... s_waitcnt vmcnt(0) ... ds_read").  Hidden in an asm
+// statement the DMA is an opaque memory operation: the kernels' own counted s_waitcnt vmcnt + barrier (which they had anyway)
+// are then the ONLY synchronisation.  The compiler's counts for ordinary loads stay safe: it does not see these operations,
+// so a vmcnt(N) it computes allows fewer operations in flight than it thinks, never more (loads return in order).
+// rsrc4: the buffer descriptor as four dwords (make_rsrc4: base, base_hi, bytes, 0x00020000), lds: wave-uniform destination.
+__device__ __forceinline__ u32x4 make_rsrc4(const void* p, uint32_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  u32x4 r = {(uint32_t)a, (uint32_t)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
+  return r;
+}
+__device__ __forceinline__ void lds_dma16(u32x4 rsrc4, const void* lds, int byte_off) {
+  const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const void*)lds));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(l), "v"(byte_off), "s"(rsrc4) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(u32x4 rsrc4, const void* lds, int byte_off) {
+  const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const void*)lds));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+               :: "s"(l), "v"(byte_off), "s"(rsrc4) : "memory");
+}
+// RIGL_DMA16(rsrcQ, lds, off): the kernel holds the descriptor twice, rsrcQ (builtin form, -DRIGL_DMA_BUILTIN for A/B runs) and rsrcQ4
+#ifdef RIGL_DMA_BUILTIN
+#define RIGL_DMA16(r_, lds_, off_) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (__attribute__((address_space(3))) void*)(lds_), 16, off_, 0, 0, 0)
+#else
+#define RIGL_DMA16(r_, lds_, off_) lds_dma16(r_##4, lds_, off_)
+#endif
 __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
   u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
   return make_uint4(v.x, v.y, v.z, v.w);
@@ -299,6 +329,8 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P, unsigned char* sm
 #endif
   uint4 ra[APASS], rb[BPASS];
   __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(P.A, P.a_bytes), rsrcB = make_rsrc(P.B, P.b_bytes);
+  const u32x4 rsrcA4 = make_rsrc4(P.A, P.a_bytes), rsrcB4 = make_rsrc4(P.B, P.b_bytes);
+  (void)rsrcA4; (void)rsrcB4;
   // dgrad with batch-norm reductions in the epilogue: request the x tile (and its ReLU bits) NOW -- nothing depends on
   // it until the tile is stored, so it travels under the whole K loop instead of stalling the epilogue.  (Class-major
   // rows only know their pixels in the epilogue; those few strided layers load there.)
@@ -395,17 +427,13 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P, unsigned char* sm
       }                                                                                               \
       ok = ok && (unsigned)gh < (unsigned)P.GH && (unsigned)gw < (unsigned)P.GW;                      \
       const int off = (a_pix[p] + gh * P.GW + gw) * P.a_pix_stride + cofs;                            \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                       \
-          rsrcA, (__attribute__((address_space(3))) void*)(As_ + (p * RPP + wave_u * (64 / CPR)) * (BK * 2)), 16, \
-          ok ? (int)((uint32_t)off * 2u) : (int)OOB, 0, 0, 0);                                        \
+      RIGL_DMA16(rsrcA, As_ + (p * RPP + wave_u * (64 / CPR)) * (BK * 2), ok ? (int)((uint32_t)off * 2u) : (int)OOB);                                        \
     }                                                                                                 \
     const int tap = (r_) * P.KW + (s_);                                                               \
     _Pragma("unroll") for (int p = 0; p < BPASS; ++p) {                                               \
       const int off = b_off[p] + tap * P.b_tap_stride + cofs;                                         \
       const bool okb = b_ok[p] && c_ok;   /* (a parenthesised condition inline here made the host pass drop the stub) */ \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                       \
-          rsrcB, (__attribute__((address_space(3))) void*)(Bs_ + (p * RPP + wave_u * (64 / CPR)) * (BK * 2)), 16, \
-          okb ? (int)((uint32_t)off * 2u) : (int)OOB, 0, 0, 0);                                       \
+      RIGL_DMA16(rsrcB, Bs_ + (p * RPP + wave_u * (64 / CPR)) * (BK * 2), okb ? (int)((uint32_t)off * 2u) : (int)OOB);                                       \
     }                                                                                                 \
   }
   // Fast DMA issue: everything about a gathered row that does not change along the K loop is
@@ -456,17 +484,13 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& P, unsigned char* sm
       const uint32_t bits = (ti_) < 32 ? f_lo[p] >> (ti_) : f_hi[p] >> ((ti_) - 32);                  \
       const bool ok = (bits & 1u) != 0u && c_ok;                                                      \
       const int boff = ok ? (int)((uint32_t)(f_base[p] + sdelta) * 2u) : (int)OOB;                    \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                       \
-          rsrcA, (__attribute__((address_space(3))) void*)(As_ + (p * RPP + wave_u * (64 / CPR)) * (BK * 2)), 16, \
-          boff, 0, 0, 0);                                                                             \
+      RIGL_DMA16(rsrcA, As_ + (p * RPP + wave_u * (64 / CPR)) * (BK * 2), boff);                                                                             \
     }                                                                                                 \
     const int bdelta = ((r_) * P.KW + (s_)) * P.b_tap_stride + (cb_) * BK;                            \
     _Pragma("unroll") for (int p = 0; p < BPASS; ++p) {                                               \
       const bool okb = b_ok[p] && c_ok;                                                               \
       const int boff = okb ? (int)((uint32_t)(fb_base[p] + bdelta) * 2u) : (int)OOB;                  \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                       \
-          rsrcB, (__attribute__((address_space(3))) void*)(Bs_ + (p * RPP + wave_u * (64 / CPR)) * (BK * 2)), 16, \
-          boff, 0, 0, 0);                                                                             \
+      RIGL_DMA16(rsrcB, Bs_ + (p * RPP + wave_u * (64 / CPR)) * (BK * 2), boff);                                                                             \
     }                                                                                                 \
   }
 #define RIGL_COMPUTE_TILE(stage_)                                                                     \
@@ -827,6 +851,8 @@ __device__ __forceinline__ void wgrad_tr_body(const WgradArgs& P, unsigned char*
   const int inc_w = BK % P.Wo, inc_h = BK / P.Wo;
   const int hi0 = r - P.ph, wi0 = s - P.pw;
   const __amdgpu_buffer_rsrc_t rsrcX = make_rsrc(P.X, P.x_bytes), rsrcY = make_rsrc(P.DY, P.dy_bytes);
+  const u32x4 rsrcX4 = make_rsrc4(P.X, P.x_bytes), rsrcY4 = make_rsrc4(P.DY, P.dy_bytes);
+  (void)rsrcX4; (void)rsrcY4; (void)rsrcX; (void)rsrcY;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
   // ---- DMA lanes: slot q*256+tid of a stage = (pixel row, 16-B slot) ----------
@@ -867,8 +893,7 @@ __device__ __forceinline__ void wgrad_tr_body(const WgradArgs& P, unsigned char*
         off = ((a_n[q] * P.H + hi) * P.W + wi) * P.x_pix_stride + a_ch[q];                            \
       }                                                                                               \
       const int boff = ok ? (int)((uint32_t)off * 2u) : (int)OOB;                                     \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                       \
-          rsrcX, (__attribute__((address_space(3))) void*)(As_ + (q * THREADS + wave_u * 64) * 16), 16, boff, 0, 0, 0); \
+      RIGL_DMA16(rsrcX, As_ + (q * THREADS + wave_u * 64) * 16, boff); \
       a_m[q] += m_step;                                                                                \
       if (!direct) {                                                                                  \
         if (fast_inc) {                                                                               \
@@ -883,8 +908,7 @@ __device__ __forceinline__ void wgrad_tr_body(const WgradArgs& P, unsigned char*
     _Pragma("unroll") for (int q = 0; q < BPASS; ++q) {                                               \
       const bool okb = b_cok[q] && b_m[q] < P.M;                                                      \
       const int boff = okb ? (int)((uint32_t)(b_m[q] * P.Cout + b_ch[q]) * 2u) : (int)OOB;            \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                       \
-          rsrcY, (__attribute__((address_space(3))) void*)(Bs_ + (q * THREADS + wave_u * 64) * 16), 16, boff, 0, 0, 0); \
+      RIGL_DMA16(rsrcY, Bs_ + (q * THREADS + wave_u * 64) * 16, boff); \
       b_m[q] += m_step;                                                                                \
     }                                                                                                 \
   }

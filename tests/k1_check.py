@@ -117,6 +117,10 @@ BS_CASES = [
     (130, 23, 19, 128, 128, 1, 1, 0, 0, 23, 19),   # one slice, 256 row groups, ragged
     (67, 14, 14, 2048, 128, 1, 1, 0, 0, 14, 14),   # 16 slices x 16 row groups, ragged
     (20, 14, 14, 4096, 128, 1, 1, 0, 0, 14, 14),   # 32 slices x 8 row groups
+    (128, 7, 7, 2048, 512, 1, 1, 0, 0, 7, 7),      # cout 512: 32 slices of 64 channels x 8 row groups (k_bwdslice64)
+    (128, 14, 14, 1024, 512, 1, 1, 0, 0, 14, 14),  # 16 slices x 16 row groups
+    (37, 11, 13, 256, 512, 1, 1, 0, 0, 11, 13),    # 4 slices x 64 row groups, 5 291 rows: ragged
+    (9, 14, 14, 64, 512, 1, 1, 0, 0, 14, 14),      # one slice x 256 row groups... too few tiles: stays on the former body
 ]
 
 

@@ -27,3 +27,11 @@ def test_bank_layout_of_the_dual_use_tile():
 def test_one_slice_ragged_rows_with_addend():
   # 8 row groups x 1 slice of 128 channels, cout 128, five tiles per group minus a ragged tail, addend through the ring
   _emu().check(8 * 5 * 32 - 7, 128, 128, 8, 4, add=True, seed=3)
+
+
+def test_the_64_channel_slices_of_cout_512():
+  # k_bwdslice64: the (channel fragment, output-channel half) split of the dgrad, the LDS hand-over of the partials, the
+  # wave-private staging tile, the 128-byte-row swizzles; 8 row groups x 1 slice, ragged tail, addend through the ring
+  m = _emu()
+  m.bank_check64()
+  m.check64(8 * 4 * 32 + 19, 64, 8, add=True, seed=5)

@@ -100,8 +100,8 @@ def test_row_streaming_1x1_shapes(env):
 @pytest.mark.parametrize('env', [{}, {'RIGL_BWDSLICE': '0'}])
 def test_channel_sliced_single_pass_backward_shapes(env):
   """The channel-sliced single-pass backward of the many-input-channel 1x1 layers (bwdslice.hpp: W slice in registers, dY
-  and the X slice through one LDS-DMA ring, dX and the slice's dW from the same tiles) on 1 .. 32 slices, cout 128 / 256,
-  ragged last tiles: dgrad (+ addend), the one-call backward (dX bit-equal to dgrad + addend, dW deterministic) against
+  and the X slice through one LDS-DMA ring, dX and the slice's dW from the same tiles) on 1 .. 32 slices, cout 128 / 256
+  and 512 (slices of 64 channels: k_bwdslice64), ragged last tiles: dgrad (+ addend), the one-call backward (dX bit-equal to dgrad + addend, dW deterministic) against
   the fp64 reference; with the knob off the same shapes on the shared-launch bodies (pins the cases themselves)."""
   out = _run(['--set', 'bs'], env)
-  assert out['cases'] == 8
+  assert out['cases'] == 12

@@ -178,6 +178,190 @@ def run_workgroup(block, X, DY, W, ADD, DX, SLAB, M, CI, CO, slices, G, NST, do_
               SLAB[g, slice_ * SC + ci, co] = acc2[wave, i, j][l, e]
 
 
+def swz_x64(row):
+  return ((row >> 1) & 1) << 2
+
+
+def swz_a64(row):
+  return (row >> 1) & 7
+
+
+def run_workgroup64(block, X, DY, W, ADD, DX, SLAB, M, CI, CO, slices, G, do_w=True):
+  """k_bwdslice64: slices of 64 input channels, dgrad split (cf, kh) over the four waves of a half, NST = 3"""
+  SC64, NST = 64, 3
+  YROWB, XROWB = CO * 2, SC64 * 2
+  assert YROWB == 1024 and XROWB == 128
+  Y_BYTES, X_BYTES, A_BYTES = PX * YROWB, (PX * XROWB if do_w else 0), PX * XROWB
+  STAGE = Y_BYTES + X_BYTES + A_BYTES + 256
+  KSH = CO // 32
+  lds = Lds(NST * STAGE)
+  lane = np.arange(64)
+  hi, r31 = lane >> 5, lane & 31
+  xcd, idx = block & 7, block >> 3
+  slice_, g = idx % slices, xcd + 8 * (idx // slices)
+  KT_all = (M + PX - 1) // PX
+  KT = (KT_all - g + G - 1) // G if g < KT_all else 0
+  Xf, Yf, Wf = X.reshape(-1), DY.reshape(-1), W.reshape(-1)
+  Af = ADD.reshape(-1) if ADD is not None else None
+
+  def issue(kt, stage, par):
+    assert ((kt & 1) ^ 1) == par, "tile t is issued by the half that is not multiplying two iterations earlier"
+    p0 = (g + kt * G) * PX
+    for cf in range(2):                    # the two kh = 1 waves of the half
+      for q in range(PX // 2):
+        row = q * 2 + cf
+        p = p0 + row
+        col = (lane ^ bs_swz(row)) * 8
+        off = np.where(p < M, (p * CO + col) * 2, OOB) if p < M else np.full(64, OOB)
+        lds.dma(Yf, stage * STAGE + row * 1024, off)
+      for q in range(2):
+        i = q * 2 + cf
+        row = i * 8 + lane // 8
+        slot = lane % 8
+        p = p0 + row
+        if do_w:
+          col = slice_ * SC64 + ((slot ^ swz_x64(row)) * 8)
+          lds.dma(Xf, stage * STAGE + Y_BYTES + i * 1024, np.where(p < M, (p * CI + col) * 2, OOB))
+        if Af is not None:
+          col = slice_ * SC64 + ((slot ^ swz_a64(row)) * 8)
+          lds.dma(Af, stage * STAGE + Y_BYTES + X_BYTES + i * 1024, np.where(p < M, (p * CI + col) * 2, OOB))
+
+  wfr = {}
+  for wave in range(8):
+    kh, cf = (wave >> 1) & 1, wave & 1
+    for ks in range(KSH):
+      ci = slice_ * SC64 + cf * 32 + r31
+      co = (kh * KSH + ks) * 16 + hi * 8
+      wfr[wave, ks] = np.stack([Wf[c * CO + o:c * CO + o + 8] for c, o in zip(ci, co)])
+  gq, j16 = lane >> 4, lane & 15
+  t_row = 8 * (gq >> 1) + (j16 >> 2)
+  t_low = 2 * (gq & 1) + ((j16 >> 1) & 1)
+  t_half = (j16 & 1) * 8
+
+  def tr_y(chunk, plus4):
+    return (t_row + plus4) * YROWB + (((chunk + t_low) ^ bs_swz(t_row + plus4)) << 4) + t_half
+
+  def tr_x(chunk, plus4):
+    return (t_row + plus4) * XROWB + (((chunk + t_low) ^ swz_x64(t_row + plus4)) << 4) + t_half
+
+  acc2 = {(w, i, j): np.zeros((64, 16)) for w in range(8) for i in range(2) for j in range(2)}
+  a0s = {w: np.zeros((64, 16)) for w in range(8)}
+  avs = {w: None for w in range(8)}
+  parts = {}
+
+  def combine(ktp, wave):
+    par, cf = wave >> 2, wave & 1
+    tot = a0s[wave] + parts[par, cf]
+    stg = np.full((32, 32), np.nan, np.float32)
+    for l in range(64):
+      for q in range(4):
+        v = tot[l, 4 * q:4 * q + 4].copy()
+        if avs[wave] is not None:
+          v = v + avs[wave][q][l]
+        c = 8 * q + 4 * int(hi[l])
+        stg[int(r31[l]), c:c + 4] = v
+    for q in range(2):
+      for l in range(64):
+        pc = q * 64 + l
+        row, ch = pc >> 2, pc & 3
+        p = (g + ktp * G) * PX + row
+        if p < M:
+          c0 = slice_ * SC64 + cf * 32 + ch * 8
+          assert np.all(np.isnan(DX[p, c0:c0 + 8])), "written twice"
+          DX[p, c0:c0 + 8] = stg[row, ch * 8:ch * 8 + 8]
+
+  for t in range(NST - 1):
+    if t < KT:
+      issue(t, t, (t & 1) ^ 1)
+  for kt in range(KT):
+    Ys = (kt % NST) * STAGE
+    Xs = Ys + Y_BYTES
+    As = Xs + X_BYTES
+    light = (kt & 1) ^ 1
+    if kt + NST - 1 < KT:
+      issue(kt + NST - 1, (kt + NST - 1) % NST, light)
+    if kt > 0:
+      for wave in range(8):
+        if (wave >> 2) == light and ((wave >> 1) & 1) == 0:
+          combine(kt - 1, wave)
+    for wave in range(8):
+      par, kh, cf = wave >> 2, (wave >> 1) & 1, wave & 1
+      if (kt & 1) == par:
+        if kh == 0 and Af is not None:
+          avs[wave] = [np.stack([lds.v[int(a) // 2:int(a) // 2 + 4] for a in (As + r31 * XROWB + (((cf * 4 + q) ^ swz_a64(r31)) << 4) + hi * 8)])
+                       for q in range(4)]
+        a0 = np.zeros((64, 16))
+        a1 = np.zeros((64, 16))
+        for ks in range(0, KSH, 2):
+          c0 = 2 * (kh * KSH + ks) + hi
+          y0 = lds.read16(Ys + r31 * YROWB + ((c0 ^ bs_swz(r31)) << 4))
+          y1 = lds.read16(Ys + r31 * YROWB + (((c0 + 2) ^ bs_swz(r31)) << 4))
+          mfma_32x32x16(wfr[wave, ks], y0, a0)
+          mfma_32x32x16(wfr[wave, ks + 1], y1, a1)
+        a0 = a0 + a1
+        if kh == 1:
+          parts[par, cf] = a0
+        else:
+          a0s[wave] = a0
+      if do_w:
+        fo0 = wave * 2
+        for k2 in range(2):
+          fa = [read_tr_pair(lds, Xs + k2 * 16 * XROWB + tr_x(i * 4, 0), Xs + k2 * 16 * XROWB + tr_x(i * 4, 4)) for i in range(2)]
+          fb = [read_tr_pair(lds, Ys + k2 * 16 * YROWB + tr_y((fo0 + j) * 4, 0), Ys + k2 * 16 * YROWB + tr_y((fo0 + j) * 4, 4)) for j in range(2)]
+          for i in range(2):
+            for j in range(2):
+              mfma_32x32x16(fa[i], fb[j], acc2[wave, i, j])
+  if KT > 0:
+    for wave in range(8):
+      if (wave >> 2) == ((KT - 1) & 1) and ((wave >> 1) & 1) == 0:
+        combine(KT - 1, wave)
+  if do_w:
+    for wave in range(8):
+      fo0 = wave * 2
+      for i in range(2):
+        for j in range(2):
+          for l in range(64):
+            for e in range(16):
+              ci = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * int(hi[l])
+              co = (fo0 + j) * 32 + int(r31[l])
+              assert np.isnan(SLAB[g, slice_ * SC64 + ci, co]), "slab element written twice"
+              SLAB[g, slice_ * SC64 + ci, co] = acc2[wave, i, j][l, e]
+
+
+def check64(M, CI, G, add=True, seed=0):
+  CO = 512
+  rng = np.random.RandomState(seed)
+  X = rng.randint(-2, 3, (M, CI)).astype(np.float32)
+  DY = rng.randint(-2, 3, (M, CO)).astype(np.float32)
+  W = rng.randint(-2, 3, (CI, CO)).astype(np.float32)
+  ADD = rng.randint(-2, 3, (M, CI)).astype(np.float32) if add else None
+  slices = CI // 64
+  DX = np.full((M, CI), np.nan, np.float32)
+  SLAB = np.full((G, CI, CO), np.nan, np.float32)
+  for block in range(slices * G):
+    run_workgroup64(block, X, DY, W, ADD, DX, SLAB, M, CI, CO, slices, G)
+  ref_dx = DY.astype(np.float64) @ W.T.astype(np.float64) + (ADD if add else 0)
+  ref_dw = X.T.astype(np.float64) @ DY.astype(np.float64)
+  assert not np.isnan(DX).any() and not np.isnan(SLAB).any()
+  assert np.array_equal(DX, ref_dx), (M, CI, CO, "dX")
+  assert np.array_equal(SLAB.sum(0), ref_dw), (M, CI, CO, "dW")
+  print(f"ok  (64-channel slices) M={M} cin={CI} cout={CO} G={G} addend={add}")
+
+
+def bank_check64():
+  """128-byte rows: the X tile under the transposing reads (4 rows x 64 bytes per 32-lane pass -> four bank quarters), the addend
+  tile under the row-per-lane ds_read_b64 (rows 0 .. 15 of a 32-lane pass -> sixteen different 16-byte slots of the window)"""
+  for base in (0, 4):
+    for p0 in range(0, 32, 4):
+      quarters = {((r * 128 + ((base ^ swz_x64(r)) << 4)) // 64) % 4 for r in range(p0, p0 + 4)}
+      assert len(quarters) == 4, (base, p0)
+  for c in range(8):
+    for r0 in (0, 16):
+      slots = {((r * 128 + ((c ^ swz_a64(r)) << 4)) // 16) % 16 for r in range(r0, r0 + 16)}
+      assert len(slots) == 16, (c, r0)
+  print("bank layout ok for the 64-channel slices")
+
+
 def check(M, CI, CO, G, NST, add=True, seed=0):
   rng = np.random.RandomState(seed)
   X = rng.randint(-2, 3, (M, CI)).astype(np.float32)
@@ -220,3 +404,6 @@ if __name__ == "__main__":
   check(8 * 8 * 32 + 40, 256, 256, 8, 4)
   check(8 * 5 * 32 - 7, 128, 128, 8, 5, add=False)
   check(16 * 3 * 32, 256, 128, 16, 5)
+  bank_check64()
+  check64(8 * 5 * 32 + 19, 128, 8)
+  check64(8 * 4 * 32, 64, 8, add=False)
