@@ -381,9 +381,10 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice(BsArgs P) {
 // multiplying iteration, the kh = 0 wave adds it to its own in its NEXT iteration -- the one in which its half has the
 // vector-memory duty -- converts, adds the shortcut gradient it picked up from the ring while multiplying, and stores the
 // [32 pixels][32 channels] block through a wave-private staging tile (no second barrier; 64-byte row segments).  In that
-// iteration the kh = 1 waves of the half issue the DMA of tile kt + 2.  Ring: three stages of 40.25 KB (dY rows [32][512],
-// X slice [32][64], addend slice + bits): the issuing waves wait for their latest tile with vmcnt(0) -- nothing younger of
-// theirs is in flight, the other half's tile is.  128-byte rows (X, addend) hold two rows per 256-byte bank window: the X
+// iteration the four waves of the half issue the DMA of tile kt + 2 (ten instructions each; issued by two waves, twenty each,
+// the issue was as long as the dgrad phase).  Ring: three stages of 40.25 KB (dY rows [32][512], X slice [32][64], addend slice
+// + bits): the issuing waves wait for their latest tile with vmcnt(0) -- nothing younger of theirs is in flight, the other
+// half's tile is.  128-byte rows (X, addend) hold two rows per 256-byte bank window: the X
 // tile, read only by the transposing reads (4 rows x 64 bytes per 32-lane pass), flips chunk bit 2 with row bit 1; the
 // addend tile, read row-per-lane, spreads rows 0 .. 15 over the 16 (row parity, chunk ^ (row >> 1)) slots.
 // Summation order of a dX element: (even k-steps + odd k-steps of kh = 0) + (the same of kh = 1), identical with and without
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice64(BsArgs P) {
   using G = Bs64Geom<CO, DO_W>;
   constexpr int SC = G::SC, PX = G::PX, NST = G::NST, YROWB = G::YROWB, XROWB = G::XROWB;
   constexpr int Y_BYTES = G::Y_BYTES, X_BYTES = G::X_BYTES, A_BYTES = G::A_BYTES, STAGE = G::STAGE;
-  constexpr int YPW = PX / 2;                                  // dY rows (1 KB wave-instructions) per issuing wave
+  constexpr int YPW = PX / 4;                                  // dY rows (1 KB wave-instructions) per issuing wave
   static_assert(YROWB == 1024 && XROWB == 128 && NST == 3, "one DMA instruction per dY row, eight X rows per instruction");
   constexpr int KSH = CO / 32;                                 // dgrad k-steps of one wave (half of the output channels)
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_bs[];
@@ -430,16 +431,11 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice64(BsArgs P) {
   unsigned char* const part = smem_bs + NST * STAGE + (par * 2 + cf) * G::PART_BYTES;
   unsigned char* const stg = smem_bs + NST * STAGE + 4 * G::PART_BYTES + (par * 2 + cf) * G::STG_BYTES;
 
-  // ---- DMA (the kh = 1 waves of a half, piece = q * 2 + cf): a dY row per instruction, lane = 16-byte slot; X / addend: eight
-  // rows per instruction, lane l: row + l / 8, slot l % 8
-  int x_row[2], x_col[2], a_col[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int i = q * 2 + cf, row = i * 8 + lane / 8, slot = lane % 8;
-    x_row[q] = row;
-    x_col[q] = slice * SC + ((slot ^ bs64_swz_x(row)) * 8);
-    a_col[q] = slice * SC + ((slot ^ bs64_swz_a(row)) * 8);
-  }
+  // ---- DMA (the four waves of a half, w4 = wave & 3): a dY row per instruction (row q * 4 + w4), lane = 16-byte slot; X / addend:
+  // eight rows per instruction (piece w4), lane l: row + l / 8, slot l % 8
+  const int w4 = wave & 3;
+  const int x_row = w4 * 8 + lane / 8;
+  const int x_col = slice * SC + (((lane % 8) ^ bs64_swz_x(x_row)) * 8), a_col = slice * SC + (((lane % 8) ^ bs64_swz_a(x_row)) * 8);
 #define BS64_ISSUE(kt_, stage_)                                                                          \
   {                                                                                                      \
     const int p0_ = (g + (kt_) * P.G) * PX;                                                              \
@@ -447,28 +443,28 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice64(BsArgs P) {
     int ln_ = lane;      /* (opaque: the sixteen per-row offsets are recomputed here instead of living in sixteen registers) */ \
     asm volatile("" : "+v"(ln_));                                                                        \
     _Pragma("unroll") for (int q = 0; q < YPW; ++q) {                                                    \
-      const int row_ = q * 2 + cf, p_ = p0_ + row_;                                                      \
+      const int row_ = q * 4 + w4, p_ = p0_ + row_;                                                      \
       const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * CO + ((ln_ ^ bs_swz(row_)) * 8)) * 2u) : (int)OOB; \
       BS_DMA16(rsrcY, st_ + row_ * 1024, off_);        \
     }                                                                                                    \
-    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
-      const int p_ = p0_ + x_row[q];                                                                     \
+    {                                                                                                    \
+      const int p_ = p0_ + x_row;                                                                        \
       if (DO_W) {                                                                                        \
-        const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * P.CI + x_col[q]) * 2u) : (int)OOB;             \
-        BS_DMA16(rsrcX, st_ + Y_BYTES + (q * 2 + cf) * 1024, off_); \
+        const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * P.CI + x_col) * 2u) : (int)OOB;                \
+        BS_DMA16(rsrcX, st_ + Y_BYTES + w4 * 1024, off_);                                                \
       }                                                                                                  \
       if (has_add) {                                                                                     \
-        int offa_ = p_ < P.M ? (int)((uint32_t)(p_ * P.CI + a_col[q]) * 2u) : (int)OOB;                  \
+        int offa_ = p_ < P.M ? (int)((uint32_t)(p_ * P.CI + a_col) * 2u) : (int)OOB;                     \
         if (P.add_sh) {      /* the addend row of pixel p_ (if it has one: else zeros) */                 \
           const int t_ = fdiv(p_, P.fd_w), wi_ = p_ - t_ * P.IW, im_ = fdiv(t_, P.fd_h), hi_ = t_ - im_ * P.IH; \
           const int qh_ = hi_ / P.add_sh, qw_ = wi_ / P.add_sw;                                          \
           const bool on_ = p_ < P.M && qh_ * P.add_sh == hi_ && qw_ * P.add_sw == wi_;                   \
-          offa_ = on_ ? (int)((uint32_t)(((im_ * P.add_ho + qh_) * P.add_wo + qw_) * P.CI + a_col[q]) * 2u) : (int)OOB; \
+          offa_ = on_ ? (int)((uint32_t)(((im_ * P.add_ho + qh_) * P.add_wo + qw_) * P.CI + a_col) * 2u) : (int)OOB; \
         }                                                                                                \
-        BS_DMA16(rsrcA, st_ + Y_BYTES + X_BYTES + (q * 2 + cf) * 1024, offa_); \
+        BS_DMA16(rsrcA, st_ + Y_BYTES + X_BYTES + w4 * 1024, offa_);                                     \
       }                                                                                                  \
     }                                                                                                    \
-    if (has_bits && cf == 0) {     /* 32 rows x 8 bytes of ReLU bits: one wave-instruction of 4 bytes per lane */ \
+    if (has_bits && w4 == 0) {     /* 32 rows x 8 bytes of ReLU bits: one wave-instruction of 4 bytes per lane */ \
       const int p_ = p0_ + (lane >> 1);                                                                  \
       const int offb_ = p_ < P.M ? (int)(((uint32_t)(p_ * P.CI + slice * SC) >> 3) + (uint32_t)((lane & 1) * 4)) : (int)OOB; \
       BS_DMA4(rsrcB, st_ + Y_BYTES + X_BYTES + A_BYTES, offb_); \
@@ -535,15 +531,15 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice64(BsArgs P) {
   unsigned long long tr_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
   unsigned long long tr_last = __builtin_amdgcn_s_memtime();
 #endif
-  // tile t is issued two iterations before it is multiplied, by the kh = 1 waves of the half that is NOT multiplying then
-  // (par = (t & 1) ^ 1); prologue: tiles 0 and 1
+  // tile t is issued two iterations before it is multiplied, by the half that is NOT multiplying then (par = (t & 1) ^ 1);
+  // prologue: tiles 0 and 1
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t)
-    if (((t & 1) ^ 1) == par && kh == 1 && t < KT) BS64_ISSUE(t, t);
+    if (((t & 1) ^ 1) == par && t < KT) BS64_ISSUE(t, t);
   BS_STAMP(7);
   for (int kt = 0; kt < KT; ++kt) {
     const bool mine = (kt & 1) == par;
-    if (!mine && kh == 1) wait_vmcnt<0>();        // this wave issued tile kt (its latest loads; it stores nothing)
+    if (!mine) wait_vmcnt<0>();                   // this wave issued its share of tile kt: its latest loads (and its dX stores)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -552,11 +548,8 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice64(BsArgs P) {
     const unsigned char* Xs = Ys + Y_BYTES;
     const unsigned char* As = Xs + X_BYTES;
     if (!mine) {
-      if (kh == 1) {
-        if (kt + NST - 1 < KT) BS64_ISSUE(kt + NST - 1, (kt + NST - 1) % NST);
-      } else if (kt > 0) {
-        BS64_COMBINE(kt - 1);
-      }
+      if (kt + NST - 1 < KT) BS64_ISSUE(kt + NST - 1, (kt + NST - 1) % NST);
+      if (kh == 0 && kt > 0) BS64_COMBINE(kt - 1);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       BS_STAMP(1 + (kh == 0));

@@ -149,12 +149,14 @@ __global__ __launch_bounds__(C3_THREADS, 2) void k_c3x3(C3Args P) {
   // of a row's chunk index are XORed with (row >> 1) & 7 on the DMA's source side -- conflict-free ds_read_b128.
   {
     const __amdgpu_buffer_rsrc_t rsrcW = make_rsrc(P.WT, 9 * 64 * 64 * 2);
+    const u32x4 rsrcW4 = make_rsrc4(P.WT, 9 * 64 * 64 * 2);
+    (void)rsrcW; (void)rsrcW4;
     unsigned char* const wl = smem_c3 + patch_bytes;
     constexpr int CPR = DGRAD ? 8 : 72;                // chunks per row
     for (int i = wave; i < 72; i += 8) {
       const int p = i * 64 + lane, row = p / CPR, c = p - row * CPR;
       const int src = row * CPR + (c ^ ((row >> 1) & 7));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(wl + i * 1024), 16, src * 16, 0, 0, 0);
+      RIGL_DMA16(rsrcW, wl + i * 1024, src * 16);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

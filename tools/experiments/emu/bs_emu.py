@@ -207,24 +207,22 @@ def run_workgroup64(block, X, DY, W, ADD, DX, SLAB, M, CI, CO, slices, G, do_w=T
   def issue(kt, stage, par):
     assert ((kt & 1) ^ 1) == par, "tile t is issued by the half that is not multiplying two iterations earlier"
     p0 = (g + kt * G) * PX
-    for cf in range(2):                    # the two kh = 1 waves of the half
-      for q in range(PX // 2):
-        row = q * 2 + cf
+    for w4 in range(4):                    # the four waves of the half
+      for q in range(PX // 4):
+        row = q * 4 + w4
         p = p0 + row
         col = (lane ^ bs_swz(row)) * 8
         off = np.where(p < M, (p * CO + col) * 2, OOB) if p < M else np.full(64, OOB)
         lds.dma(Yf, stage * STAGE + row * 1024, off)
-      for q in range(2):
-        i = q * 2 + cf
-        row = i * 8 + lane // 8
-        slot = lane % 8
-        p = p0 + row
-        if do_w:
-          col = slice_ * SC64 + ((slot ^ swz_x64(row)) * 8)
-          lds.dma(Xf, stage * STAGE + Y_BYTES + i * 1024, np.where(p < M, (p * CI + col) * 2, OOB))
-        if Af is not None:
-          col = slice_ * SC64 + ((slot ^ swz_a64(row)) * 8)
-          lds.dma(Af, stage * STAGE + Y_BYTES + X_BYTES + i * 1024, np.where(p < M, (p * CI + col) * 2, OOB))
+      row = w4 * 8 + lane // 8
+      slot = lane % 8
+      p = p0 + row
+      if do_w:
+        col = slice_ * SC64 + ((slot ^ swz_x64(row)) * 8)
+        lds.dma(Xf, stage * STAGE + Y_BYTES + w4 * 1024, np.where(p < M, (p * CI + col) * 2, OOB))
+      if Af is not None:
+        col = slice_ * SC64 + ((slot ^ swz_a64(row)) * 8)
+        lds.dma(Af, stage * STAGE + Y_BYTES + X_BYTES + w4 * 1024, np.where(p < M, (p * CI + col) * 2, OOB))
 
   wfr = {}
   for wave in range(8):
