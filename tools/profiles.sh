@@ -45,6 +45,7 @@ timeout 400 python tools/rs_bench.py > $O/rs_bench.txt 2>&1; echo "rs_bench rc=$
 # round 6: the channel-sliced single-pass backward alone (A/B), where an in-step kernel's time goes relative to alone
 timeout 400 python tools/bs_bench.py > $O/bs_bench.txt 2>&1; echo "bs_bench rc=$?" | tee -a $O/log.txt
 timeout 300 python tools/instep_probe.py > $O/instep_probe.txt 2>&1; echo "instep_probe rc=$?" | tee -a $O/log.txt
+timeout 300 python tools/bnload_bench.py > $O/bnload_bench_kernels.txt 2>&1; echo "bnload_bench rc=$?" | tee -a $O/log.txt
 timeout 300 python tools/bench_kernels.py --out $O/bk_warm.json > /dev/null 2>&1
 timeout 300 python tools/bench_kernels.py --cold --out $O/bk_cold.json > /dev/null 2>&1
 timeout 300 python tools/instep_table.py --alone $O/bk_warm.json --cold $O/bk_cold.json --out $O/instep_table.json > $O/instep_table.txt 2>&1; echo "instep rc=$?" | tee -a $O/log.txt
