@@ -69,6 +69,13 @@ constexpr int BS_THREADS = 512;
 #define BS_DMA16(r_, lds_, off_) lds_dma16(r_##4, lds_, off_)
 #define BS_DMA4(r_, lds_, off_) lds_dma4(r_##4, lds_, off_)
 #endif
+// the once-read streams (X slice, addend slice) carry the non-temporal hint (-DRIGL_BS_NO_NT: without; alone 56x56 256->128
+// 134.7 -> 127.3 us, 14x14 1024->512 87.0 -> 82.8, the others level; in the step -0.005 ms in both alternating pairs)
+#if !defined(RIGL_BS_NO_NT) && !defined(RIGL_DMA_BUILTIN)
+#define BS_DMA16_ONCE(r_, lds_, off_) lds_dma16_nt(r_##4, lds_, off_)
+#else
+#define BS_DMA16_ONCE(r_, lds_, off_) BS_DMA16(r_, lds_, off_)
+#endif
 
 __device__ __forceinline__ int bs_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice(BsArgs P) {
       const int p_ = p0_ + x_row[q];                                                                     \
       const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * P.CI + x_col[q]) * 2u) : (int)OOB;               \
       if (DO_W)                                                                                          \
-        BS_DMA16(rsrcX, st_ + Y_BYTES + (q * 4 + cf) * 1024, off_); \
+        BS_DMA16_ONCE(rsrcX, st_ + Y_BYTES + (q * 4 + cf) * 1024, off_); \
       if (has_add) {                                                                                     \
         int offa_ = off_;                                                                                \
         if (P.add_sh) {      /* the addend row of pixel p_ (if it has one: else zeros) */                 \
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice(BsArgs P) {
           const bool on_ = p_ < P.M && qh_ * P.add_sh == hi_ && qw_ * P.add_sw == wi_;                   \
           offa_ = on_ ? (int)((uint32_t)(((im_ * P.add_ho + qh_) * P.add_wo + qw_) * P.CI + x_col[q]) * 2u) : (int)OOB; \
         }                                                                                                \
-        BS_DMA16(rsrcA, st_ + Y_BYTES + X_BYTES + (q * 4 + cf) * 1024, offa_); \
+        BS_DMA16_ONCE(rsrcA, st_ + Y_BYTES + X_BYTES + (q * 4 + cf) * 1024, offa_); \
       }                                                                                                  \
     }                                                                                                    \
     if (has_bits && cf < 2) {      /* 32 rows x 16 bytes of ReLU bits: two wave-instructions of 4 bytes per lane */ \
@@ -451,7 +458,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice64(BsArgs P) {
       const int p_ = p0_ + x_row;                                                                        \
       if (DO_W) {                                                                                        \
         const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * P.CI + x_col) * 2u) : (int)OOB;                \
-        BS_DMA16(rsrcX, st_ + Y_BYTES + w4 * 1024, off_);                                                \
+        BS_DMA16_ONCE(rsrcX, st_ + Y_BYTES + w4 * 1024, off_);                                                \
       }                                                                                                  \
       if (has_add) {                                                                                     \
         int offa_ = p_ < P.M ? (int)((uint32_t)(p_ * P.CI + a_col) * 2u) : (int)OOB;                     \
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice64(BsArgs P) {
           const bool on_ = p_ < P.M && qh_ * P.add_sh == hi_ && qw_ * P.add_sw == wi_;                   \
           offa_ = on_ ? (int)((uint32_t)(((im_ * P.add_ho + qh_) * P.add_wo + qw_) * P.CI + a_col) * 2u) : (int)OOB; \
         }                                                                                                \
-        BS_DMA16(rsrcA, st_ + Y_BYTES + X_BYTES + w4 * 1024, offa_);                                     \
+        BS_DMA16_ONCE(rsrcA, st_ + Y_BYTES + X_BYTES + w4 * 1024, offa_);                                     \
       }                                                                                                  \
     }                                                                                                    \
     if (has_bits && w4 == 0) {     /* 32 rows x 8 bytes of ReLU bits: one wave-instruction of 4 bytes per lane */ \

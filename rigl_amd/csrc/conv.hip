@@ -107,6 +107,12 @@ __device__ __forceinline__ void lds_dma16(u32x4 rsrc4, const void* lds, int byte
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                :: "s"(l), "v"(byte_off), "s"(rsrc4) : "memory");
 }
+// the same with the non-temporal hint (a stream that is read once: keeps it out of the way of the lines other workgroups share)
+__device__ __forceinline__ void lds_dma16_nt(u32x4 rsrc4, const void* lds, int byte_off) {
+  const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const void*)lds));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
+               :: "s"(l), "v"(byte_off), "s"(rsrc4) : "memory");
+}
 __device__ __forceinline__ void lds_dma4(u32x4 rsrc4, const void* lds, int byte_off) {
   const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const void*)lds));
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
