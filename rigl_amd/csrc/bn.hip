@@ -126,21 +126,31 @@ __global__ __launch_bounds__(THREADS) void k_reduce(Geom G, const uint16_t* __re
       }
     }
   }
-  // combine the `rpb` row-lanes of each channel group (fixed tree order)
+  // combine the `rpb` row-lanes of each channel group (fixed tree order).  A thread keeps its own sums in registers and reads
+  // its partner's sixteen with ONE wait per round (written as `red[t][j] += red[t + s * tpr][j]` the compiler serialised
+  // read -> wait -> write sixteen times a round: ~2 us of tail in a 9-15 us launch); same additions in the same order.
+  float own[16];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = q0[j]; red[threadIdx.x][8 + j] = q1[j]; }
+  for (int j = 0; j < 8; ++j) { own[j] = q0[j]; own[8 + j] = q1[j]; red[threadIdx.x][j] = q0[j]; red[threadIdx.x][8 + j] = q1[j]; }
   __syncthreads();
   for (int s = G.rpb >> 1; s > 0; s >>= 1) {
     if (ty < s) {
+      float oth[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) red[threadIdx.x][j] += red[threadIdx.x + s * G.tpr][j];
+      for (int j = 0; j < 16; ++j) oth[j] = red[threadIdx.x + s * G.tpr][j];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) own[j] += oth[j];
+      if (s > 1) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) red[threadIdx.x][j] = own[j];
+      }
     }
-    __syncthreads();
+    if (s > 1) __syncthreads();
   }
   if (ty == 0 && c_ok) {
     float* p = partial + ((int64_t)blockIdx.x * 2) * G.C + cgi * 8;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { p[j] = red[threadIdx.x][j]; p[G.C + j] = red[threadIdx.x][8 + j]; }
+    for (int j = 0; j < 8; ++j) { p[j] = own[j]; p[G.C + j] = own[8 + j]; }
   }
 }
 
@@ -453,23 +463,34 @@ __global__ __launch_bounds__(THREADS) void k_reduce_pair(Geom G, const uint16_t*
       }
     }
   }
+  float own[24];          // (as in k_reduce: own sums in registers, the partner's read with one wait per round)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = q0[j]; red[threadIdx.x][8 + j] = q1[j]; red[threadIdx.x][16 + j] = q2[j]; }
+  for (int j = 0; j < 8; ++j) {
+    own[j] = q0[j]; own[8 + j] = q1[j]; own[16 + j] = q2[j];
+    red[threadIdx.x][j] = q0[j]; red[threadIdx.x][8 + j] = q1[j]; red[threadIdx.x][16 + j] = q2[j];
+  }
   __syncthreads();
   for (int s = G.rpb >> 1; s > 0; s >>= 1) {
     if (ty < s) {
+      float oth[24];
 #pragma unroll
-      for (int j = 0; j < 24; ++j) red[threadIdx.x][j] += red[threadIdx.x + s * G.tpr][j];
+      for (int j = 0; j < 24; ++j) oth[j] = red[threadIdx.x + s * G.tpr][j];
+#pragma unroll
+      for (int j = 0; j < 24; ++j) own[j] += oth[j];
+      if (s > 1) {
+#pragma unroll
+        for (int j = 0; j < 24; ++j) red[threadIdx.x][j] = own[j];
+      }
     }
-    __syncthreads();
+    if (s > 1) __syncthreads();
   }
   if (ty == 0 && c_ok) {
     float* p = partial + ((int64_t)blockIdx.x * 2) * G.C + cgi * 8;
     float* p2 = partial2 + ((int64_t)blockIdx.x * 2) * G.C + cgi * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      p[j] = red[threadIdx.x][j]; p[G.C + j] = red[threadIdx.x][8 + j];
-      p2[j] = red[threadIdx.x][j]; p2[G.C + j] = red[threadIdx.x][16 + j];
+      p[j] = own[j]; p[G.C + j] = own[8 + j];
+      p2[j] = own[j]; p2[G.C + j] = own[16 + j];
     }
   }
 }
