@@ -140,20 +140,28 @@ __global__ __launch_bounds__(THREADS) void k_wgrad_partial(RiglConvDesc d, WGeom
       }
     }
     __syncthreads();
+    // (own sums stay in registers, the partner's are read with one wait per tree round: bn.hip k_reduce; same additions)
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = acc[j];
     __syncthreads();
     for (int st = G.rpb >> 1; st > 0; st >>= 1) {
       if (ty < st) {
+        float oth[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) red[threadIdx.x][j] += red[threadIdx.x + st * G.tpr][j];
+        for (int j = 0; j < 8; ++j) oth[j] = red[threadIdx.x + st * G.tpr][j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += oth[j];
+        if (st > 1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = acc[j];
+        }
       }
-      __syncthreads();
+      if (st > 1) __syncthreads();
     }
     if (ty == 0 && c_ok) {
       float* p = partial + ((int64_t)blockIdx.x * taps + tap) * d.cin + cgi * 8;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) p[j] = red[threadIdx.x][j];
+      for (int j = 0; j < 8; ++j) p[j] = acc[j];
     }
   }
 }
@@ -460,19 +468,27 @@ __global__ __launch_bounds__(THREADS, 2) void k_wgrad3(G3 g, WG3 G, const uint16
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     __syncthreads();
+    float own[9];
 #pragma unroll
-    for (int tpi = 0; tpi < 9; ++tpi) red[threadIdx.x][tpi] = acc[tpi][c];
+    for (int tpi = 0; tpi < 9; ++tpi) { own[tpi] = acc[tpi][c]; red[threadIdx.x][tpi] = own[tpi]; }
     __syncthreads();
     for (int st = G.rpb >> 1; st > 0; st >>= 1) {
       if (ty < st) {
+        float oth[9];
 #pragma unroll
-        for (int tpi = 0; tpi < 9; ++tpi) red[threadIdx.x][tpi] += red[threadIdx.x + st * G.tpr][tpi];
+        for (int tpi = 0; tpi < 9; ++tpi) oth[tpi] = red[threadIdx.x + st * G.tpr][tpi];
+#pragma unroll
+        for (int tpi = 0; tpi < 9; ++tpi) own[tpi] += oth[tpi];
+        if (st > 1) {
+#pragma unroll
+          for (int tpi = 0; tpi < 9; ++tpi) red[threadIdx.x][tpi] = own[tpi];
+        }
       }
-      __syncthreads();
+      if (st > 1) __syncthreads();
     }
     if (ty == 0 && c_ok) {
 #pragma unroll
-      for (int tpi = 0; tpi < 9; ++tpi) partial[((int64_t)part * 9 + tpi) * g.C + c0 + c] = red[threadIdx.x][tpi];
+      for (int tpi = 0; tpi < 9; ++tpi) partial[((int64_t)part * 9 + tpi) * g.C + c0 + c] = own[tpi];
     }
   }
 }
