@@ -515,8 +515,10 @@ __global__ __launch_bounds__(BS_THREADS) void k_bwdslice64(BsArgs P) {
   // kh = 0 of the half that multiplied tile ktp: own partial + the partner's, bf16, + the shortcut gradient, staged, stored
 #define BS64_COMBINE(ktp_)                                                                               \
   {                                                                                                      \
+    rs_f32x4 oq_[4];       /* (the four reads first: one wait instead of read -> wait -> write four times) */ \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) oq_[q] = *reinterpret_cast<const rs_f32x4*>(part + q * 1024 + lane * 16); \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
-      const rs_f32x4 o_ = *reinterpret_cast<const rs_f32x4*>(part + q * 1024 + lane * 16);               \
+      const rs_f32x4 o_ = oq_[q];                                                                        \
       const f32x2 lo_ = {a0[4 * q] + o_[0], a0[4 * q + 1] + o_[1]}, hi_ = {a0[4 * q + 2] + o_[2], a0[4 * q + 3] + o_[3]}; \
       uint2 pk_;                                                                                         \
       pk_.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo_, bf16x2));                        \

@@ -1043,6 +1043,10 @@ __global__ __launch_bounds__(THREADS) void k_wgrad_reduce(const float* __restric
   }
 }
 
+// (Round 6: a one-thread-per-float4-column form of the kernel above -- all slabs of a column walked by one thread, sixteen loads in
+// flight, 1 KB of a slab per wave instruction, the same additions in the same order (dW bit-equal on seven layer shapes) --
+// measured SLOWER in the step: conv_bwd 3.53 / 3.57 -> 3.68 ms; the 4096 four-wave workgroups of two loads per thread hide
+// their latency better than 1024 single-wave workgroups of thirty-two.  Removed.)
 // Few splits (the large layers: 3-7 slabs of up to 2.4 M outputs): the 16 split-groups above would leave most of
 // the workgroup idle, so G = 4 or 8 groups x 256 / G float4 columns.  With G >= splits every group holds at most
 // one slab and the combine is the plain sum in split order -- the same bits as the 16-group kernel.

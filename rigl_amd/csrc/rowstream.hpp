@@ -336,10 +336,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_rowstream(RsArgs P) {
     __syncthreads();
     if (tid < 2 * NS) {
       const int k = tid / NS, n = tid % NS, ch = n / 8, e = n % 8;
-      float s = 0.f;
+      float v[8 * RPI];         // (all reads first, then the additions in the fixed order: one wait instead of one per value)
+#pragma unroll
       for (int w8 = 0; w8 < 8; ++w8)
 #pragma unroll
-        for (int q = 0; q < RPI; ++q) s += area[(w8 * 64 + q * CHR + ch) * 16 + k * 8 + e];
+        for (int q = 0; q < RPI; ++q) v[w8 * RPI + q] = area[(w8 * 64 + q * CHR + ch) * 16 + k * 8 + e];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8 * RPI; ++i) s += v[i];
       P.STATS[((int64_t)gp * 2 + k) * P.N + slice * NS + n] = s;
     }
   }
