@@ -142,6 +142,48 @@ __global__ __launch_bounds__(BLOCK) void k_pack(PackTable T) {
   const uint32_t tl = blockIdx.x - T.tile_begin[li];
   const int tiles_c = (L.cout + 63) / 64;
   const int k0 = (int)(tl / tiles_c) * 64, c0 = (int)(tl % tiles_c) * 64;
+  if ((L.cout & 3) == 0 && (L.k & 3) == 0) {
+    // four consecutive output channels per lane (16-byte loads, 8-byte stores), the four row passes requested before the first is
+    // used (unconditional loads at clamped positions: a load inside `if` waits for itself); the transposed copy leaves as four
+    // consecutive reduction rows per lane.  Same conversions as the element-wise form below (the 7x7x3 stem keeps that one).
+    __shared__ __attribute__((aligned(8))) uint16_t t4[64][68];
+    const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;
+    float4 wv[4];
+    uint32_t nib[4];
+    bool ok[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int kk = k0 + rr + 16 * p, co = c0 + q * 4;
+      ok[p] = kk < L.k && co < L.cout;
+      const int64_t i = ok[p] ? (int64_t)kk * L.cout + co : 0;
+      wv[p] = *reinterpret_cast<const float4*>(L.w + i);
+      nib[p] = L.mask ? (L.mask[i >> 5] >> (uint32_t)(i & 31)) & 0xFu : 0xFu;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      ushort4 v = make_ushort4(0, 0, 0, 0);
+      if (ok[p]) {
+        v.x = (nib[p] & 1u) ? f2bf(wv[p].x) : (uint16_t)0;
+        v.y = (nib[p] & 2u) ? f2bf(wv[p].y) : (uint16_t)0;
+        v.z = (nib[p] & 4u) ? f2bf(wv[p].z) : (uint16_t)0;
+        v.w = (nib[p] & 8u) ? f2bf(wv[p].w) : (uint16_t)0;
+        if (L.hwio) *reinterpret_cast<ushort4*>(L.hwio + (int64_t)(k0 + rr + 16 * p) * L.cout + c0 + q * 4) = v;
+      }
+      *reinterpret_cast<ushort4*>(&t4[rr + 16 * p][q * 4]) = v;
+    }
+    if (!L.ohwi) return;
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int col = rr + 16 * p, co = c0 + col, kk = k0 + q * 4;
+      if (co < L.cout && kk < L.k) {
+        ushort4 v;
+        v.x = t4[q * 4 + 0][col]; v.y = t4[q * 4 + 1][col]; v.z = t4[q * 4 + 2][col]; v.w = t4[q * 4 + 3][col];
+        *reinterpret_cast<ushort4*>(L.ohwi + (int64_t)co * L.k + kk) = v;
+      }
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll 4
   for (int r = ty; r < 64; r += 4) {
