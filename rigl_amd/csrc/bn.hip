@@ -171,7 +171,10 @@ __device__ __forceinline__ void sum_partials(const Geom& G, const float* __restr
     // FLIGHT rows of both quantities are requested before the first is added: the partials were written by other XCDs
     // (they come from the fabric, not this L2), so the kernel's time is round trips, not bytes.  Rows past the end read
     // as zero; the additions run in the same ascending order whatever FLIGHT is.
-    constexpr int FLIGHT = 16;
+#ifndef RIGL_BN_FIN_FLIGHT
+#define RIGL_BN_FIN_FLIGHT 16
+#endif
+    constexpr int FLIGHT = RIGL_BN_FIN_FLIGHT;
     for (int p0 = pl; p0 < G.parts; p0 += PL * FLIGHT) {
       float v0[FLIGHT], v1[FLIGHT];
 #pragma unroll
