@@ -19,6 +19,7 @@
 // Reference: resnet_model.py:456-501 (conv2d_fixed_padding 7x7/2 + batch norm), pruning_layers.py:139-157.
 #pragma once
 
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_stem;
 struct StemArgs {
   const uint16_t* X;     // [N][H][W][3] bf16
   const uint16_t* WP;    // [64][7][32] bf16: k_stem_weights_shift's packed filter (kw' * 4 + c)
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_stem_fwd(StemArgs P) {
     for (int s = 0; s < 14; ++s)
       wfr[cf][s] = *reinterpret_cast<const bf16x8*>(P.WP + ((cf * 32 + (lane & 31)) * 7 + (s >> 1)) * 32 + 16 * (s & 1) + 8 * (lane >> 5));
 
+  const __amdgpu_buffer_rsrc_t rsrcXs = make_rsrc(P.X, (uint32_t)((size_t)P.N * P.H * P.W * 6));
   // ---- patch tasks of this thread: (row, group of 4 pixels), 37 x 10 = 370 of them over 256 threads
   constexpr int NTASK = STEM_PROWS * 10;
   const int t1 = tid + THREADS;
@@ -71,9 +73,12 @@ __global__ __launch_bounds__(THREADS, 2) void k_stem_fwd(StemArgs P) {
   {                                                                                                       \
     const int ih_ = (ih0_) + (pr_), iw_ = (iw0_) + 4 * (pg_);                                             \
     const bool ok_ = (unsigned)ih_ < (unsigned)P.H && iw_ >= 0 && iw_ + 3 < P.W;                          \
-    const uint2* src_ = reinterpret_cast<const uint2*>(P.X + (((int64_t)(n_) * P.H + (ok_ ? ih_ : 0)) * P.W + (ok_ ? iw_ : 0)) * 3); \
-    const uint2 z_ = make_uint2(0u, 0u);                                                                  \
-    ld[slot_][0] = ok_ ? src_[0] : z_; ld[slot_][1] = ok_ ? src_[1] : z_; ld[slot_][2] = ok_ ? src_[2] : z_; \
+    /* buffer loads, out of range where the pixels do not exist: `ok ? src[i] : 0` had become six dword loads under branches */ \
+    const uint32_t off_ = ok_ ? (uint32_t)((((n_) * P.H + ih_) * P.W + iw_) * 6) : OOB;                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                                    \
+      const u32x2_stem v_ = __builtin_amdgcn_raw_buffer_load_b64(rsrcXs, (int)(off_ + 8u * i_), 0, 0);     \
+      ld[slot_][i_] = make_uint2(v_.x, v_.y);                                                             \
+    }                                                                                                     \
   }
   // 24 bytes = 12 bf16 = 4 pixels x 3 channels  ->  4 x (3 channels + 0) as two 16-byte LDS writes
 #define STEM_STORE(slot_, buf_, pr_, pg_)                                                                 \
