@@ -95,7 +95,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
 // so a vmcnt(N) it computes allows fewer operations in flight than it thinks, never more (loads return in order).
 // rsrc4: the buffer descriptor as four dwords (make_rsrc4: base, base_hi, bytes, 0x00020000), lds: wave-uniform destination.
 // M0 is a reserved register that cannot be named as a clobber: a kernel issues ALL its LDS-DMA this way or all through the builtin
-// (rowstream.hpp, convpp.hpp, stem.hpp keep the builtin: no later LDS read of the issuing wave sits between issue and its wait),
+// (rowstream.hpp and convpp.hpp keep the builtin: no later LDS read of the issuing wave sits between issue and its wait),
 // so the compiler never holds a value of its own in M0 across one of these statements.
 __device__ __forceinline__ u32x4 make_rsrc4(const void* p, uint32_t bytes) {
   const uint64_t a = reinterpret_cast<uint64_t>(p);

@@ -250,6 +250,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_stem_wgrad(StemWgradArgs P) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const __amdgpu_buffer_rsrc_t rsrcY = make_rsrc(P.DY, P.dy_bytes);
+  const u32x4 rsrcY4 = make_rsrc4(P.DY, P.dy_bytes);
+  const __amdgpu_buffer_rsrc_t rsrcXs = make_rsrc(P.X, (uint32_t)((size_t)P.N * P.H * P.W * 6));
+  (void)rsrcY; (void)rsrcY4;
 
   f32x16 acc[2][2];                              // [filter row slot: wave, wave + 4][channel half]
 #pragma unroll
@@ -273,9 +276,11 @@ __global__ __launch_bounds__(THREADS, 2) void k_stem_wgrad(StemWgradArgs P) {
   {                                                                                                       \
     const int ih_ = (ih0_) + pr0, iw_ = (iw0_) + 4 * pg0;                                                 \
     const bool ok_ = has0 && (unsigned)ih_ < (unsigned)P.H && iw_ >= 0 && iw_ + 3 < P.W;                  \
-    const uint2* src_ = reinterpret_cast<const uint2*>(P.X + (((int64_t)(n_) * P.H + (ok_ ? ih_ : 0)) * P.W + (ok_ ? iw_ : 0)) * 3); \
-    const uint2 z_ = make_uint2(0u, 0u);                                                                  \
-    ld[0] = ok_ ? src_[0] : z_; ld[1] = ok_ ? src_[1] : z_; ld[2] = ok_ ? src_[2] : z_;                   \
+    const uint32_t off_ = ok_ ? (uint32_t)((((n_) * P.H + ih_) * P.W + iw_) * 6) : OOB;   /* (buffer loads: k_stem_fwd) */ \
+    _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                                    \
+      const u32x2_stem v_ = __builtin_amdgcn_raw_buffer_load_b64(rsrcXs, (int)(off_ + 8u * i_), 0, 0);     \
+      ld[i_] = make_uint2(v_.x, v_.y);                                                                    \
+    }                                                                                                     \
   }
   // the dY tile: 16 wave-instructions of 8 pixels x 128 B, four per wave; lane l: pixel + (l >> 3), 16-byte slot l & 7,
   // fetching the logical chunk slot ^ swizzle(pixel)
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_stem_wgrad(StemWgradArgs P) {
       const int i_ = q * 4 + wave, px_ = i_ * 8 + (lane >> 3);                                            \
       const int64_t m_ = ((int64_t)(n_) * P.Ho + (oh0_) + (px_ >> 4)) * P.Wo + (ow0_) + (px_ & 15);       \
       const int off_ = (int)((uint32_t)m_ * 128u + (uint32_t)(((lane & 7) ^ dual_swz<128>(px_)) << 4));   \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (__attribute__((address_space(3))) void*)((buf_) + i_ * 1024), 16, off_, 0, 0, 0); \
+      RIGL_DMA16(rsrcY, (buf_) + i_ * 1024, off_);   /* (asm form: the loop reads LDS behind its DMA issue, conv.hip lds_dma16) */ \
     }                                                                                                     \
   }
 
