@@ -99,19 +99,26 @@ __global__ __launch_bounds__(THREADS) void k_bwd1x1(Bwd1x1Args P) {
     const int i = q * 4 + wave, row = i * (1024 / XROWB) + lane / (XROWB / 16), slot = lane % (XROWB / 16);
     x_row[q] = row; x_col[q] = (slot ^ dual_swz<XROWB>(row)) * 8;
   }
+// both streams (dY rows, X rows) are read once: non-temporal (-DRIGL_B1_NO_NT: without; in the step conv_bwd 3.601 / 3.598 ->
+// 3.542 / 3.544 ms, 10.409 / 10.392 -> 10.344 / 10.354 ms)
+#if !defined(RIGL_B1_NO_NT) && !defined(RIGL_DMA_BUILTIN)
+#define B1_DMA16(r_, lds_, off_) lds_dma16_nt(r_##4, lds_, off_)
+#else
+#define B1_DMA16(r_, lds_, off_) RIGL_DMA16(r_, lds_, off_)
+#endif
 #define B1_ISSUE(kt_, stage_)                                                                            \
   {                                                                                                      \
     const int p0_ = (kt_begin + (kt_) * kt_step) * PX;                                                             \
     _Pragma("unroll") for (int q = 0; q < YPW; ++q) {                                                    \
       const int p_ = p0_ + y_row[q];                                                                     \
       const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * CO + y_col[q]) * 2u) : (int)OOB;                 \
-      RIGL_DMA16(rsrcY, smem + (stage_) * STAGE + (q * 4 + wave) * 1024, off_); \
+      B1_DMA16(rsrcY, smem + (stage_) * STAGE + (q * 4 + wave) * 1024, off_); \
     }                                                                                                    \
     if (DO_W) {                                                                                          \
       _Pragma("unroll") for (int q = 0; q < XPW; ++q) {                                                  \
         const int p_ = p0_ + x_row[q];                                                                   \
         const int off_ = p_ < P.M ? (int)((uint32_t)(p_ * CI + x_col[q]) * 2u) : (int)OOB;               \
-        RIGL_DMA16(rsrcX, smem + (stage_) * STAGE + Y_BYTES + (q * 4 + wave) * 1024, off_); \
+        B1_DMA16(rsrcX, smem + (stage_) * STAGE + Y_BYTES + (q * 4 + wave) * 1024, off_); \
       }                                                                                                  \
     }                                                                                                    \
   }
