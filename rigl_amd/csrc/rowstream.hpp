@@ -194,7 +194,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rowstream(RsArgs P) {
       uint4 addv[ITERS];
       if (ADDEND) {
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it) addv[it] = buf_load16(rsrcD, coff[it]);
+        for (int it = 0; it < ITERS; ++it) addv[it] = buf_load16(rsrcD, coff[it]);   // (non-temporal measured level: profiles/r6)
       }
       f32x16 acc[TN];
 #pragma unroll
