@@ -716,7 +716,8 @@ int rigl_probe_mfma_bf16(int32_t blocks, int32_t iters, float* sink, rigl_stream
  * round 5 replaced x1x1.hpp and its knobs by rowstream.hpp).
  * Round 6: "bwdslice" (0 = off, 1 = default: the channel-sliced single-pass
  * backward of the 1x1 / stride-1 layers with cin % 128 == 0 and cout 128 / 256,
- * bwdslice.hpp); "bn_on_load" (0: rigl_conv2d_fwd_takes_bn_input says 0 for
+ * bwdslice.hpp) with "bwdslice512" (0 / 1 = default: its 64-channel-slice form
+ * for cout 512, cin % 64 == 0); "bn_on_load" (0: rigl_conv2d_fwd_takes_bn_input says 0 for
  * every layer; 1 = default: the row-streaming forwards except the 64-channel /
  * 128-column variant take the transform -- whether a model USES the entry point
  * is the caller's choice: the host mirror does with RIGL_BN_ON_LOAD=1 only, it
