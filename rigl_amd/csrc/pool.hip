@@ -298,23 +298,34 @@ __global__ __launch_bounds__(THREADS) void k_bn_relu_bwd(Geom G, int kb, int lb,
       for (int b = 0; b < 2; ++b) {
         const int ho = k - 1 + a, wo = l - 1 + b;
         ok[a][b] = ho >= 0 && ho < G.ho && wo >= 0 && wo < G.wo;
-        if (ok[a][b]) {
-          const uint32_t o = ((uint32_t)(n * G.ho + ho) * (uint32_t)G.wo + (uint32_t)wo) * ng + gi;
-          av[a][b] = *reinterpret_cast<const uint32_t*>(idx + (size_t)o * SCH);
-          const uint2 v = *reinterpret_cast<const uint2*>(dy + (size_t)o * SCH);
-          f[a][b][0] = bf_lo(v.x); f[a][b][1] = bf_hi(v.x); f[a][b][2] = bf_lo(v.y); f[a][b][3] = bf_hi(v.y);
-        }
+        // unconditional loads at clamped positions (a load inside `if` waits for itself: the twelve loads of an item ran as
+        // twelve round trips); a window that does not exist is never added (ok)
+        const int hoc = ho < 0 ? 0 : (ho >= G.ho ? G.ho - 1 : ho), woc = wo < 0 ? 0 : (wo >= G.wo ? G.wo - 1 : wo);
+        const uint32_t o = ((uint32_t)(n * G.ho + hoc) * (uint32_t)G.wo + (uint32_t)woc) * ng + gi;
+        av[a][b] = *reinterpret_cast<const uint32_t*>(idx + (size_t)o * SCH);
+        const uint2 v = *reinterpret_cast<const uint2*>(dy + (size_t)o * SCH);
+        f[a][b][0] = bf_lo(v.x); f[a][b][1] = bf_hi(v.x); f[a][b][2] = bf_lo(v.y); f[a][b][3] = bf_hi(v.y);
+      }
+    uint2 xq[2][2];
+    uint32_t xiq[2][2];
+    bool xok[2][2];
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int pw = 0; pw < 2; ++pw) {
+        const int h = 2 * k + ph - G.pt, w = 2 * l + pw - G.pl;
+        xok[ph][pw] = h >= 0 && h < G.h && w >= 0 && w < G.w;
+        const int hc = h < 0 ? 0 : (h >= G.h ? G.h - 1 : h), wc = w < 0 ? 0 : (w >= G.w ? G.w - 1 : w);
+        xiq[ph][pw] = ((uint32_t)(n * G.h + hc) * (uint32_t)G.w + (uint32_t)wc) * ng + gi;
+        xq[ph][pw] = *reinterpret_cast<const uint2*>(x + (size_t)xiq[ph][pw] * SCH);
       }
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {
-      const int h = 2 * k + ph - G.pt;
-      if (h < 0 || h >= G.h) continue;
 #pragma unroll
       for (int pw = 0; pw < 2; ++pw) {
-        const int w = 2 * l + pw - G.pl;
-        if (w < 0 || w >= G.w) continue;
-        const uint32_t xi = ((uint32_t)(n * G.h + h) * (uint32_t)G.w + (uint32_t)w) * ng + gi;
-        const uint2 xr = *reinterpret_cast<const uint2*>(x + (size_t)xi * SCH);
+        if (!xok[ph][pw]) continue;
+        const uint32_t xi = xiq[ph][pw];
+        const uint2 xr = xq[ph][pw];
         const float xv[SCH] = {bf_lo(xr.x), bf_hi(xr.x), bf_lo(xr.y), bf_hi(xr.y)};
         float acc[SCH];
 #pragma unroll
