@@ -227,6 +227,32 @@ __global__ __launch_bounds__(THREADS) void k_bn_relu_fwd(Geom G, const uint16_t*
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { bestf[j] = -INFINITY; arg[j] = 0; sc[j] = prm[cgi * 8 + j]; sh[j] = prm[G.c + cgi * 8 + j]; }
+    if (G.kh == 3 && G.kw == 3) {
+      // the 3 x 3 window (the ImageNet stem): nine unconditional loads at clamped positions, all in flight, then the same
+      // comparisons in the same order (a load under `continue` waits for itself: nine round trips per output)
+      uint4 xr[9];
+      bool vld[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int hi = ho * G.sh - G.pt + t / 3, wi = wo * G.sw - G.pl + t % 3;
+        vld[t] = (unsigned)hi < (unsigned)G.h && (unsigned)wi < (unsigned)G.w;
+        const int hc = hi < 0 ? 0 : (hi >= G.h ? G.h - 1 : hi), wc = wi < 0 ? 0 : (wi >= G.w ? G.w - 1 : wi);
+        xr[t] = *reinterpret_cast<const uint4*>(x + (((int64_t)n * G.h + hc) * G.w + wc) * G.c + cgi * 8);
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (!vld[t]) continue;
+        float f[8];
+        unpack8(xr[t], f);
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const uint32_t pk = pack2(fmaxf(fmaf(f[j], sc[j], sh[j]), 0.f), fmaxf(fmaf(f[j + 1], sc[j + 1], sh[j + 1]), 0.f));
+          const float a0 = bf_lo(pk), a1 = bf_hi(pk);
+          if (a0 > bestf[j]) { bestf[j] = a0; arg[j] = (uint32_t)t; }
+          if (a1 > bestf[j + 1]) { bestf[j + 1] = a1; arg[j + 1] = (uint32_t)t; }
+        }
+      }
+    } else
     for (int r = 0; r < G.kh; ++r) {
       const int hi = ho * G.sh - G.pt + r;
       if ((unsigned)hi >= (unsigned)G.h) continue;
