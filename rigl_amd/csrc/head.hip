@@ -40,6 +40,42 @@ __global__ __launch_bounds__(THREADS) void k_avgpool_fwd(int n, int p, int c2, c
   y[i] = f2bf(a / inv) | (f2bf(b / inv) << 16);
 }
 
+// The same with 8 channels (16 bytes) per lane (c % 8 == 0): the two-channel form moves 256 bytes per wave instruction and
+// ran at 1.5 TB/s; the additions of a channel run in the same pixel order, so the bits are those of the form above.
+__global__ __launch_bounds__(THREADS) void k_avgpool_fwd8(int n, int p, int c8, const uint4* __restrict__ x, uint4* __restrict__ y) {
+  const int i = blockIdx.x * THREADS + threadIdx.x;
+  if (i >= n * c8) return;
+  const int img = i / c8, ch = i % c8;
+  const uint4* src = x + (int64_t)img * p * c8 + ch;
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = 0.f;
+#pragma unroll 7
+  for (int q = 0; q < p; ++q) {
+    const uint4 v = src[(int64_t)q * c8];
+    a[0] += bf_lo(v.x); a[1] += bf_hi(v.x); a[2] += bf_lo(v.y); a[3] += bf_hi(v.y);
+    a[4] += bf_lo(v.z); a[5] += bf_hi(v.z); a[6] += bf_lo(v.w); a[7] += bf_hi(v.w);
+  }
+  const float inv = (float)p;
+  uint4 o;
+  o.x = f2bf(a[0] / inv) | (f2bf(a[1] / inv) << 16); o.y = f2bf(a[2] / inv) | (f2bf(a[3] / inv) << 16);
+  o.z = f2bf(a[4] / inv) | (f2bf(a[5] / inv) << 16); o.w = f2bf(a[6] / inv) | (f2bf(a[7] / inv) << 16);
+  y[i] = o;
+}
+__global__ __launch_bounds__(THREADS) void k_avgpool_bwd8(int n, int p, int c8, const uint4* __restrict__ dy, uint4* __restrict__ dx) {
+  const int64_t total = (int64_t)n * p * c8;
+  const float inv = (float)p;
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * THREADS) {
+    const int ch = (int)(i % c8);
+    const int img = (int)(i / ((int64_t)p * c8));
+    const uint4 v = dy[(int64_t)img * c8 + ch];
+    uint4 o;
+    o.x = f2bf(bf_lo(v.x) / inv) | (f2bf(bf_hi(v.x) / inv) << 16); o.y = f2bf(bf_lo(v.y) / inv) | (f2bf(bf_hi(v.y) / inv) << 16);
+    o.z = f2bf(bf_lo(v.z) / inv) | (f2bf(bf_hi(v.z) / inv) << 16); o.w = f2bf(bf_lo(v.w) / inv) | (f2bf(bf_hi(v.w) / inv) << 16);
+    dx[i] = o;
+  }
+}
+
 __global__ __launch_bounds__(THREADS) void k_avgpool_bwd(int n, int p, int c2, const uint32_t* __restrict__ dy,
                                                           uint32_t* __restrict__ dx) {
   const int64_t total = (int64_t)n * p * c2;
@@ -113,6 +149,13 @@ int rigl_global_avgpool_fwd(int32_t n, int32_t pixels, int32_t c, const rigl_bf1
   if (n <= 0 || pixels <= 0 || c <= 0 || (c & 1)) return fail(RIGL_EINVAL, "rigl_global_avgpool_fwd: need n, pixels > 0 and an even channel count");
   if (!x || !y) return fail(RIGL_EINVAL, "rigl_global_avgpool_fwd: NULL tensor");
   const int c2 = c / 2;
+  if ((c & 7) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0) {
+    const int c8 = c / 8;
+    hipLaunchKernelGGL(k_avgpool_fwd8, dim3((unsigned)((n * c8 + THREADS - 1) / THREADS)), dim3(THREADS), 0, as_stream(stream),
+                       n, pixels, c8, reinterpret_cast<const uint4*>(x), reinterpret_cast<uint4*>(y));
+    RIGL_CHECK_LAUNCH("rigl_global_avgpool_fwd");
+    return RIGL_OK;
+  }
   hipLaunchKernelGGL(k_avgpool_fwd, dim3((unsigned)((n * c2 + THREADS - 1) / THREADS)), dim3(THREADS), 0, as_stream(stream),
                      n, pixels, c2, reinterpret_cast<const uint32_t*>(x), reinterpret_cast<uint32_t*>(y));
   RIGL_CHECK_LAUNCH("rigl_global_avgpool_fwd");
@@ -125,6 +168,15 @@ int rigl_global_avgpool_bwd(int32_t n, int32_t pixels, int32_t c, const rigl_bf1
   if (n <= 0 || pixels <= 0 || c <= 0 || (c & 1)) return fail(RIGL_EINVAL, "rigl_global_avgpool_bwd: need n, pixels > 0 and an even channel count");
   if (!dy || !dx) return fail(RIGL_EINVAL, "rigl_global_avgpool_bwd: NULL tensor");
   const int c2 = c / 2;
+  if ((c & 7) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0) {
+    const int c8 = c / 8;
+    int64_t blocks8 = ((int64_t)n * pixels * c8 + THREADS - 1) / THREADS;
+    if (blocks8 > 8192) blocks8 = 8192;
+    hipLaunchKernelGGL(k_avgpool_bwd8, dim3((unsigned)blocks8), dim3(THREADS), 0, as_stream(stream), n, pixels, c8,
+                       reinterpret_cast<const uint4*>(dy), reinterpret_cast<uint4*>(dx));
+    RIGL_CHECK_LAUNCH("rigl_global_avgpool_bwd");
+    return RIGL_OK;
+  }
   int64_t blocks = ((int64_t)n * pixels * c2 + THREADS - 1) / THREADS;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(k_avgpool_bwd, dim3((unsigned)blocks), dim3(THREADS), 0, as_stream(stream), n, pixels, c2,
